@@ -1,0 +1,76 @@
+"""ctypes binding of libcvmhip.so (C ABI: include/cvmhip.h).
+
+torch is imported first on purpose: PyTorch-ROCm ships its own libamdhip64.so.7 and the
+kernels must run in that HIP runtime instance so that torch's device pointers and streams
+are valid inside the library (same SONAME -> the loader reuses the loaded runtime)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime that libcvmhip.so binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcvmhip.so")
+
+CVM_OK, CVM_EINVAL, CVM_EWORKSPACE, CVM_ELAUNCH = 0, 1, 2, 3
+CVM_F32, CVM_F64 = 0, 1
+RET_XTX, RET_XTY = 0x01, 0x02
+CENTER_X, CENTER_Y, SCALE_X, SCALE_Y = 0x04, 0x08, 0x10, 0x20
+
+EXPORTS = (
+    "cvm_version", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
+    "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_plan_fold",
+)
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -m cvmatrix_amd.build, or __graft_entry__.build()). "
+            "cvmatrix_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, sz, u32, dbl = C.c_void_p, C.c_int64, C.c_size_t, C.c_uint, C.c_double
+    lib.cvm_version.restype = C.c_char_p
+    lib.cvm_last_error.restype = C.c_char_p
+    lib.cvm_gstats_len.restype = sz
+    lib.cvm_gstats_len.argtypes = [C.c_int, C.c_int]
+    lib.cvm_fit_workspace_bytes.restype = sz
+    lib.cvm_fit_workspace_bytes.argtypes = [i64, C.c_int, C.c_int, C.c_int]
+    lib.cvm_gram_fit.restype = C.c_int
+    lib.cvm_gram_fit.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
+                                 vp, sz, vp]
+    lib.cvm_fold_workspace_bytes.restype = sz
+    lib.cvm_fold_workspace_bytes.argtypes = [i64, i64, i64, C.c_int, C.c_int, C.c_int, u32]
+    lib.cvm_fold_update.restype = C.c_int
+    lib.cvm_fold_update.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int,
+                                    C.c_int, u32, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp,
+                                    vp, vp, vp, sz, vp]
+    lib.cvm_plan_fold.restype = C.c_int
+    lib.cvm_plan_fold.argtypes = [i64, i64, C.c_int, C.c_int, C.c_int, u32, sz, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != CVM_OK:
+        msg = load().cvm_last_error().decode()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a tensor / ndarray, 0 for None."""
+    if t is None:
+        return 0
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

@@ -1,0 +1,831 @@
+// cvmhip.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI for the cvmatrix hot path.
+//
+// Two stages of the reference are replaced (see include/cvmhip.h for the mapping):
+//   fit stage   cvmatrix/cvmatrix.py:1193-1243   G = X^T W X, H = X^T W Y, column sums
+//   fold stage  cvmatrix/cvmatrix.py:589-1129    per fold: G - G_V, rank-1 centring,
+//                                                outer-std scaling
+// Both are the same contraction  A^T diag(w) [A | B]  reduced over ROWS, so one MFMA kernel
+// (`wgram_kernel`) serves both: the fit stage runs it over all rows, the fold stage over
+// the validation rows of every fold of a batch gathered by index.  Small deterministic
+// finalize kernels then reduce the row-split partials in a fixed order and apply the
+// reference's correction arithmetic in the reference's operation order.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// (-ffp-contract=off: the finalize arithmetic must round like NumPy's separate ufuncs,
+//  and the VALU column sums must round like the MFMA's A operand (w*x rounded first).)
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cvmhip.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------
+// geometry
+// ----------------------------------------------------------------------------------
+constexpr int TILE = 128;     // columns per panel; a workgroup owns a TILE x TILE output tile
+constexpr int STAGE_ROWS = 16;  // rows staged in LDS per pipeline stage (4 MFMA k-steps)
+constexpr int PITCH = 144;    // LDS row pitch of a panel, in elements (see bank note below)
+constexpr int YT = 32;        // Y columns handled per diagonal work item (2 MFMA col tiles)
+constexpr int YPITCH = 48;    // LDS row pitch of the Y tile, in elements
+constexpr int NTHREADS = 512; // 8 waves, two per SIMD
+constexpr int PANEL_ELEMS = STAGE_ROWS * PITCH;             // 2304
+constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + STAGE_ROWS;     // A panel, B panel | Y tile, w
+constexpr int TARGET_WG = 256;  // resident workgroups: one per CU (raised if two fit)
+// LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
+// f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
+// the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
+// ds_read_b32 (32 banks): lanes 0-15 cover 64 B; pitch must be = 64 mod 128: 144*4 = 576.
+// Same for the Y tile: 48*8 = 384 = 256+128, 48*4 = 192 = 128+64.
+
+template <typename T> struct MF;
+template <> struct MF<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // v_mfma_f64_16x16x4_f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg
+  static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct MF<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // v_mfma_f32_16x16x4_f32 C/D map: col = lane&15, row = 4*(lane>>4) + reg
+  static __device__ __forceinline__ int drow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+struct Geom {
+  int K, M;
+  int P;        // column panels = ceil(K/128)
+  int Kp;       // P*128
+  int Yc;       // Y chunks of 32 columns (>= 1 even when M == 0)
+  int Mp;       // Yc*32
+  int nTiles;   // P(P+1)/2 upper-triangular tiles
+  int nT;       // work items per unit
+  int diag_only;  // 1: only diagonal items (XTY / statistics only), no G tiles
+  size_t tile_elems, h_elems;   // per unit, in elements of T
+  size_t stat_len;              // per unit, float64 entries
+  size_t unit_bytes;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+Geom make_geom(int K, int M, int esize, int diag_only) {
+  Geom g;
+  g.K = K; g.M = M;
+  g.P = (K + TILE - 1) / TILE;
+  g.Kp = g.P * TILE;
+  g.Yc = M > 0 ? (M + YT - 1) / YT : 1;
+  g.Mp = g.Yc * YT;
+  g.nTiles = g.P * (g.P + 1) / 2;
+  g.diag_only = diag_only;
+  g.nT = diag_only ? g.P * g.Yc : g.nTiles + g.P * (g.Yc - 1);
+  g.tile_elems = diag_only ? 0 : (size_t)g.nTiles * TILE * TILE;
+  g.h_elems = (size_t)g.P * TILE * g.Mp;
+  g.stat_len = 2 * (size_t)g.Kp + 2 * (size_t)g.Mp + 4;
+  g.unit_bytes = align_up(g.tile_elems * esize, 256) + align_up(g.h_elems * esize, 256) +
+                 align_up(g.stat_len * 8, 256);
+  return g;
+}
+
+template <typename T> struct WgramArgs {
+  const T *X, *Y, *w;
+  const int64_t *idx;   // nullptr: rows are offs[seg]..offs[seg+1] themselves
+  const int64_t *offs;  // device; nullptr: one segment [0, N)
+  int64_t N;
+  int64_t seg0;         // first segment of this batch
+  int n_seg, splits;
+  Geom g;
+  long n_items, items_per_xcd;
+  char *ws;             // unit u at ws + u*unit_bytes
+};
+
+template <typename T> __device__ __forceinline__ T *unit_tiles(char *ws, const Geom &g, long u) {
+  return (T *)(ws + (size_t)u * g.unit_bytes);
+}
+template <typename T> __device__ __forceinline__ T *unit_h(char *ws, const Geom &g, long u) {
+  return (T *)(ws + (size_t)u * g.unit_bytes + ((g.tile_elems * sizeof(T) + 255) / 256 * 256));
+}
+template <typename T> __device__ __forceinline__ double *unit_stats(char *ws, const Geom &g, long u) {
+  return (double *)(ws + (size_t)u * g.unit_bytes + ((g.tile_elems * sizeof(T) + 255) / 256 * 256) +
+                    ((g.h_elems * sizeof(T) + 255) / 256 * 256));
+}
+
+__device__ __forceinline__ void decode_tile(int t, int P, int &ti, int &tj) {
+  // row-major upper triangle: (0,0),(0,1)..(0,P-1),(1,1)...
+  int i = 0, rem = t;
+  while (rem >= P - i) { rem -= P - i; ++i; }
+  ti = i; tj = i + rem;
+}
+__host__ __device__ __forceinline__ int tile_id(int i, int j, int P) {
+  return i * P - i * (i - 1) / 2 + (j - i);
+}
+
+// rows of segment `seg` handled by split `sp`
+__device__ __forceinline__ void split_range(int64_t n, int splits, int sp, int64_t &r0, int64_t &r1) {
+  int64_t per = (n + splits - 1) / splits;
+  per = (per + STAGE_ROWS - 1) / STAGE_ROWS * STAGE_ROWS;
+  r0 = (int64_t)sp * per; if (r0 > n) r0 = n;
+  r1 = r0 + per; if (r1 > n) r1 = n;
+}
+
+// ----------------------------------------------------------------------------------
+// wgram_kernel: partial  P[a][b] = sum_{rows r in split} w_r * X[r][a] * [X|Y][r][b]
+// plus the weighted column sums of the same rows.
+//
+// Workgroup = 8 waves (2 per SIMD) = one 128x128 tile (i,j), i <= j, of one
+// (segment, split) unit.  Wave (wr,wc), wr in 0..1, wc in 0..3, owns the 64x32 block
+// rows 64wr.., cols 32wc.. of the tile: 4x2 MFMA 16x16 tiles, 8 accumulators.
+//   diagonal tile: blocks (1,0),(1,1) lie strictly below the diagonal (mirror of data the
+//     other waves produce) and are not computed.  The two freed waves ("H waves") compute
+//     panel_i[:, 64h..64h+64)^T W Y[:, 32c..32c+32)  (again 4x2 MFMA tiles) and, on the
+//     VALU, the column sums sX,qX of their 64 columns (+ sY,qY,sw,nz on panel 0).
+// Every wave therefore runs the same loop: 4 A fragments x 2 B fragments per k-step.
+// Rows reach LDS through registers (global_load_dwordx4 -> ds_write_b128), one 16-row stage
+// ahead of the MFMAs (loads issued before the stage's MFMAs, LDS written after them, one
+// barrier per stage).  Row numbers come from a 3-slot LDS ring filled three stages ahead,
+// so no global load in the loop depends on another one.
+// ----------------------------------------------------------------------------------
+template <typename T, bool WEIGHTED, bool GATHER, bool ALIGNED>
+__global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a) {
+  typedef typename MF<T>::acc_t acc_t;
+  constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte chunk
+  constexpr int CPR = TILE / VEC;                   // chunks per panel row
+  constexpr int NCH = STAGE_ROWS * CPR / NTHREADS;  // chunks per thread per panel (2 / 1)
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  int64_t *ring = reinterpret_cast<int64_t *>(smem_raw + 2 * BUF_ELEMS * sizeof(T));
+
+  const Geom &g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- which work item: contiguous ranges of the (unit, tile) list per XCD ----------
+  const long b = blockIdx.x;
+  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
+  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+  const long u = item / g.nT;
+  const int it = (int)(item - u * g.nT);
+  const int seg = (int)(u / a.splits);
+  const int sp = (int)(u - (long)seg * a.splits);
+  int ti, tj, yc;
+  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
+  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
+  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  const bool diag = (ti == tj);
+  const int wr = wave >> 2, wc = wave & 3;
+  const bool h_wave = diag && wr == 1 && wc < 2;
+  const bool do_g = !g.diag_only && yc == 0;       // the G tile of this item is wanted
+  const bool mfma_wave = h_wave ? (g.M > 0) : do_g;
+
+  int64_t seg_begin, seg_rows;
+  if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
+  else { seg_begin = 0; seg_rows = a.N; }
+  int64_t r0, r1;
+  split_range(seg_rows, a.splits, sp, r0, r1);
+  const int nstages = (int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS);
+
+  // ---- per-thread staging coordinates -----------------------------------------------
+  const int st_row0 = tid / CPR, st_col = (tid % CPR) * VEC;   // chunk j: row st_row0 + j*(512/CPR)
+  constexpr int ST_ROW_STEP = NTHREADS / CPR;
+  const int colA0 = ti * TILE, colB0 = tj * TILE;
+  const int y_row = tid >> 5, y_m = tid & 31;       // Y tile: one element per thread
+  const int y_col = yc * YT + y_m;
+
+  vec_t ra[NCH], rb[NCH];
+  T ry = 0, rw = 0;
+
+  // threads 0..15: row number of stage s, row tid (or -1 past the end).  The global load
+  // is issued early (ring_load) and parked in LDS after the stage's MFMAs (ring_store).
+  auto ring_load = [&](int s) -> int64_t {
+    int64_t row = -1;
+    if (tid < STAGE_ROWS) {
+      int64_t r = r0 + (int64_t)s * STAGE_ROWS + tid;
+      if (r < r1) row = GATHER ? a.idx[seg_begin + r] : seg_begin + r;
+    }
+    return row;
+  };
+  auto ring_store = [&](int s, int64_t row) {
+    if (tid < STAGE_ROWS) ring[(s % 3) * STAGE_ROWS + tid] = row;
+  };
+  auto load_panel = [&](vec_t *dst, int col0, int s) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int64_t row = ring[(s % 3) * STAGE_ROWS + st_row0 + j * ST_ROW_STEP];
+      const int col = col0 + st_col;
+      vec_t v;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = 0;
+      if (row >= 0) {
+        const T *src = a.X + row * (int64_t)g.K + col;
+        if (ALIGNED) {
+          if (col < g.K) v = *reinterpret_cast<const vec_t *>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) if (col + e < g.K) v[e] = src[e];
+        }
+      }
+      dst[j] = v;
+    }
+  };
+  auto issue_loads = [&](int s) {
+    load_panel(ra, colA0, s);
+    if (!diag) load_panel(rb, colB0, s);
+    else {
+      const int64_t row = ring[(s % 3) * STAGE_ROWS + y_row];
+      T v = 0;
+      if (row >= 0 && y_col < g.M) v = a.Y[row * (int64_t)g.M + y_col];
+      ry = v;
+    }
+    if (tid < STAGE_ROWS) {
+      const int64_t row = ring[(s % 3) * STAGE_ROWS + tid];
+      T v = 0;
+      if (row >= 0) v = WEIGHTED ? a.w[row] : (T)1;
+      rw = v;
+    }
+  };
+  auto write_lds = [&](int buf) {
+    T *base = smem + buf * BUF_ELEMS;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+      *reinterpret_cast<vec_t *>(base + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = ra[j];
+    if (!diag) {
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+        *reinterpret_cast<vec_t *>(base + PANEL_ELEMS + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = rb[j];
+    } else {
+      base[PANEL_ELEMS + y_row * YPITCH + y_m] = ry;
+    }
+    if (tid < STAGE_ROWS) base[2 * PANEL_ELEMS + tid] = rw;
+  };
+
+  // ---- accumulators -------------------------------------------------------------------
+  acc_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (acc_t){0, 0, 0, 0};
+  double s_x = 0, q_x = 0, s_y = 0, q_y = 0, s_w = 0, n_z = 0, neg = 0;
+
+  // wave -> operand blocks inside the LDS stage buffer
+  const int lk = lane >> 4, lc = lane & 15;
+  int a_off, b_off, b_pitch;     // element offsets of this lane's A / B fragment, row 0
+  int a_col, b_col;              // block origin inside the tile (for the store)
+  if (h_wave) { a_col = 64 * wc; b_col = 0; a_off = a_col + lc; b_off = PANEL_ELEMS + lc; b_pitch = YPITCH; }
+  else {
+    a_col = 64 * wr; b_col = 32 * wc;
+    a_off = a_col + lc; b_off = (diag ? 0 : PANEL_ELEMS) + b_col + lc; b_pitch = PITCH;
+  }
+
+  // ---- prologue -------------------------------------------------------------------------
+  if (nstages > 0) {
+    ring_store(0, ring_load(0));
+    ring_store(1, ring_load(1));
+    ring_store(2, ring_load(2));
+    __syncthreads();
+    issue_loads(0);
+    write_lds(0);
+    __syncthreads();
+  }
+
+#pragma unroll 1
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = (s + 1 < nstages);
+    if (more) issue_loads(s + 1);
+    const int64_t ring_next = ring_load(s + 3);
+    const T *buf = smem + (s & 1) * BUF_ELEMS;
+    const T *wb = buf + 2 * PANEL_ELEMS;
+
+    if (mfma_wave) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int r = 4 * ks + lk;
+        T af[4], bf[2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = buf[a_off + r * PITCH + 16 * m];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[n] = buf[b_off + r * b_pitch + 16 * n];
+        if (WEIGHTED) {
+          const T wv = wb[r];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) af[m] *= wv;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m * 2 + n] = MF<T>::mfma(af[m], bf[n], acc[m * 2 + n]);
+      }
+    }
+    if (h_wave) {
+      // VALU column sums, sequential over rows: p = w*x rounded like the MFMA A operand,
+      // s += p, q += p*x.  For x == 1 the three sums sw, s, q are the same sequence of
+      // additions, so a constant-one column gets variance exactly 0.
+      if (yc == 0) {
+#pragma unroll
+        for (int r = 0; r < STAGE_ROWS; ++r) {
+          const T x = buf[r * PITCH + a_col + lane];
+          if (sizeof(T) == 8) {
+            const T p = WEIGHTED ? (T)(wb[r] * x) : x;
+            s_x += (double)p; q_x += (double)(p * x);
+          } else {
+            const double p = (WEIGHTED ? (double)wb[r] : 1.0) * (double)x;
+            s_x += p; q_x += p * (double)x;
+          }
+        }
+      }
+      if (ti == 0 && wc == 0) {
+#pragma unroll
+        for (int r = 0; r < STAGE_ROWS; ++r) {
+          const double wv = (double)wb[r];
+          const T yv = (lane < YT) ? buf[PANEL_ELEMS + r * YPITCH + lane] : (T)0;
+          if (sizeof(T) == 8) {
+            const T p = WEIGHTED ? (T)(wb[r] * yv) : yv;
+            s_y += (double)p; q_y += (double)(p * yv);
+          } else {
+            const double p = wv * (double)yv;
+            s_y += p; q_y += p * (double)yv;
+          }
+          s_w += wv;                       // padded rows carry w = 0
+          n_z += (wv != 0.0) ? 1.0 : 0.0;
+          neg += (wv < 0.0) ? 1.0 : 0.0;
+        }
+      }
+    }
+    if (more) write_lds((s + 1) & 1);
+    ring_store(s + 3, ring_next);   // slot (s%3) was last read for stage s, one barrier ago
+    __syncthreads();
+  }
+
+  // ---- store partials -------------------------------------------------------------------
+  if (h_wave) {
+    if (g.M > 0) {
+      T *hp = unit_h<T>(a.ws, g, u) + (size_t)ti * TILE * g.Mp + yc * YT;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            hp[(size_t)(a_col + 16 * m + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] = acc[m * 2 + n][r];
+    }
+    double *st = unit_stats<T>(a.ws, g, u);
+    if (yc == 0) {
+      st[ti * TILE + a_col + lane] = s_x;
+      st[g.Kp + ti * TILE + a_col + lane] = q_x;
+    }
+    if (ti == 0 && wc == 0) {
+      if (lane < YT) {
+        st[2 * g.Kp + yc * YT + lane] = s_y;
+        st[2 * g.Kp + g.Mp + yc * YT + lane] = q_y;
+      }
+      if (yc == 0 && lane == 0) {
+        st[2 * g.Kp + 2 * g.Mp + 0] = s_w;
+        st[2 * g.Kp + 2 * g.Mp + 1] = n_z;
+        st[2 * g.Kp + 2 * g.Mp + 2] = neg;
+      }
+    }
+  } else if (do_g && !(diag && wr == 1 && wc < 2)) {
+    T *tp = unit_tiles<T>(a.ws, g, u) + (size_t)it * TILE * TILE;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc] = acc[m * 2 + n][r];
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// finalize kernels
+// ----------------------------------------------------------------------------------
+struct FinArgs {
+  Geom g;
+  int splits;
+  int n_seg;            // segments (folds) in this batch
+  int64_t seg0;         // first fold of the batch (for output addressing)
+  const char *ws;       // unit partials
+  double *fstats;       // per fold of the batch: [muX(K) sdX(K) muY(M) sdY(M) swT pad..]
+  const int64_t *offs;  // device offsets (fold sizes) or nullptr
+  const void *w;        // non-null: weighted
+  const void *G, *H;    // global Gram (fold mode)
+  const double *gstats;
+  void *out_XTX, *out_XTY, *out_muX, *out_sdX, *out_muY, *out_sdY;
+  double *out_fold;
+  double ddof, resolution;
+  unsigned flags;
+  int32_t *neg_flag;
+};
+__host__ __device__ inline size_t fstat_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 4; }
+
+// fit: gstats = ordered sum of the split partials
+template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *gstats) {
+  const Geom &g = a.g;
+  const int total = 2 * g.K + 2 * g.M + 3;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
+    int src;
+    if (c < g.K) src = c;
+    else if (c < 2 * g.K) src = g.Kp + (c - g.K);
+    else if (c < 2 * g.K + g.M) src = 2 * g.Kp + (c - 2 * g.K);
+    else if (c < 2 * g.K + 2 * g.M) src = 2 * g.Kp + g.Mp + (c - 2 * g.K - g.M);
+    else src = 2 * g.Kp + 2 * g.Mp + (c - 2 * g.K - 2 * g.M);
+    double s = 0;
+    for (int p = 0; p < a.splits; ++p) s += unit_stats<T>((char *)a.ws, g, p)[src];
+    if (c < total - 1) gstats[c] = s;
+    else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
+  }
+}
+
+// fold: training-set mean / std of every column; reference operation order
+// (cvmatrix.py:612-620, 709-745, 1043, 1079, 1119-1128)
+template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
+  const Geom &g = a.g;
+  const int f = blockIdx.x;
+  const int K = g.K, M = g.M;
+  const bool weighted = a.w != nullptr;
+  const long u0 = (long)f * a.splits;
+  double swv = 0, nzv = 0;
+  if (weighted) {
+    for (int p = 0; p < a.splits; ++p) {
+      const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
+      swv += st[2 * g.Kp + 2 * g.Mp + 0];
+      nzv += st[2 * g.Kp + 2 * g.Mp + 1];
+    }
+  } else {
+    swv = nzv = (double)(a.offs[a.seg0 + f + 1] - a.offs[a.seg0 + f]);
+  }
+  const double gsw = a.gstats[2 * K + 2 * M], gnz = a.gstats[2 * K + 2 * M + 1];
+  const double swt = gsw - swv, nzt = gnz - nzv;
+  const double divisor = (nzt - a.ddof) * swt / nzt;
+  double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+  if (threadIdx.x == 0) {
+    fs[2 * K + 2 * M] = swt;
+    if (a.out_fold) {
+      double *o = a.out_fold + 4 * (a.seg0 + f);
+      o[0] = swt; o[1] = nzt; o[2] = swv; o[3] = nzv;
+    }
+  }
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const bool rXTY = a.flags & CVM_RET_XTY;
+  const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
+  const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
+  for (int c = threadIdx.x; c < K + M; c += blockDim.x) {
+    const bool isX = c < K;
+    const int cc = isX ? c : c - K;
+    if (isX ? !(want_muX) : !(want_muY)) continue;
+    const int s_src = isX ? cc : 2 * g.Kp + cc;
+    const int q_src = isX ? g.Kp + cc : 2 * g.Kp + g.Mp + cc;
+    double sv = 0, qv = 0;
+    for (int p = 0; p < a.splits; ++p) {
+      const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
+      sv += st[s_src]; qv += st[q_src];
+    }
+    const double gs = isX ? a.gstats[cc] : a.gstats[2 * K + cc];
+    const double gq = isX ? a.gstats[K + cc] : a.gstats[2 * K + M + cc];
+    const double st_ = gs - sv;          // cvmatrix.py:1020
+    const double mu = st_ / swt;         // cvmatrix.py:1043
+    double sd = 1.0;
+    if (isX ? want_sdX : want_sdY) {
+      const double qt = gq - qv;
+      double var = (-2 * mu * st_ + swt * (mu * mu) + qt) / divisor;   // 1119-1123
+      var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
+      sd = sqrt(var);
+      if (sd <= a.resolution) sd = 1.0;  // 1128
+    }
+    fs[isX ? cc : 2 * K + cc] = mu;
+    fs[isX ? K + cc : 2 * K + M + cc] = sd;
+    T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
+    const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
+    if (omu) omu[o] = (T)mu;
+    if (osd && (isX ? want_sdX : want_sdY)) osd[o] = (T)sd;
+  }
+}
+
+// One 128x128 upper tile (or one 128 x M panel of H) of one segment: ordered sum of the
+// split partials, then (fold mode) total - partial, rank-1 centring, outer-std scaling in
+// the reference's order (cvmatrix.py:1001-1010); the XTX tile is mirrored.
+template <typename T, bool FOLD> __global__ __launch_bounds__(NTHREADS) void apply_kernel(const FinArgs a) {
+  const Geom &g = a.g;
+  const int f = blockIdx.y;
+  const int x = blockIdx.x;
+  const int K = g.K, M = g.M;
+  const long u0 = (long)f * a.splits;
+  const double *fs = FOLD ? a.fstats + (size_t)f * fstat_len(K, M) : nullptr;
+  const double swt = FOLD ? fs[2 * K + 2 * M] : 0.0;
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const size_t fo = (size_t)(a.seg0 + f);
+  if (x < g.nTiles) {
+    if (!a.out_XTX) return;
+    int ti, tj;
+    decode_tile(x, g.P, ti, tj);
+    T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
+    const T *Gt = (const T *)a.G;
+    for (int e = threadIdx.x; e < TILE * TILE; e += NTHREADS) {
+      const int ra = e >> 7, cb = e & 127;
+      const int ga = ti * TILE + ra, gb = tj * TILE + cb;
+      if (ga >= K || gb >= K || (ti == tj && ra > cb)) continue;
+      double v = 0;
+      for (int p = 0; p < a.splits; ++p)
+        v += (double)unit_tiles<T>((char *)a.ws, g, u0 + p)[(size_t)x * TILE * TILE + e];
+      if (FOLD) {
+        v = (double)Gt[(size_t)ga * K + gb] - v;
+        if (cX) v -= swt * (fs[ga] * fs[gb]);
+        if (sX) v = v / (fs[K + ga] * fs[K + gb]);
+      }
+      out[(size_t)ga * K + gb] = (T)v;
+      out[(size_t)gb * K + ga] = (T)v;
+    }
+  } else {
+    if (!a.out_XTY || M == 0) return;
+    const int ti = x - g.nTiles;
+    T *out = (T *)a.out_XTY + (FOLD ? fo * (size_t)K * M : 0);
+    const T *Ht = (const T *)a.H;
+    for (int e = threadIdx.x; e < TILE * M; e += NTHREADS) {
+      const int ra = e / M, m = e - ra * M;
+      const int ga = ti * TILE + ra;
+      if (ga >= K) continue;
+      double v = 0;
+      for (int p = 0; p < a.splits; ++p)
+        v += (double)unit_h<T>((char *)a.ws, g, u0 + p)[(size_t)ga * g.Mp + m];
+      if (FOLD) {
+        v = (double)Ht[(size_t)ga * M + m] - v;
+        if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
+        if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + m]);
+        else if (sX) v = v / fs[K + ga];
+        else if (sY) v = v / fs[2 * K + M + m];
+      }
+      out[(size_t)ga * M + m] = (T)v;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, const char *detail = "") {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return code;
+}
+#define HIP_OK(expr)                                                             \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) return fail(CVM_ELAUNCH, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+struct Plan {
+  Geom g;
+  int splits;
+  int64_t folds_per_batch;
+  size_t fstat_bytes_per_fold;
+};
+
+// Row splits per segment.  Model: TARGET_WG workgroups are resident at a time and take
+// equal time, so W = items*splits workgroups cost ceil(W/TARGET_WG) rounds; pick the split
+// count with the best fill, lightly preferring fewer splits (less partial traffic).
+int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g) {
+  const int64_t items = (n_seg > 0 ? n_seg : 1) * g.nT;
+  int64_t cap = max_rows / 64;                       // >= 64 rows per split
+  const int64_t mem_cap = (int64_t)(((size_t)3 << 30) / ((size_t)(n_seg > 0 ? n_seg : 1) * g.unit_bytes));
+  if (cap > mem_cap) cap = mem_cap;
+  if (cap > 64) cap = 64;
+  if (cap < 1) cap = 1;
+  int best = 1;
+  double best_score = -1;
+  for (int64_t s = 1; s <= cap; ++s) {
+    const int64_t W = items * s;
+    const int64_t rounds = (W + TARGET_WG - 1) / TARGET_WG;
+    const double score = (double)W / (double)(rounds * TARGET_WG) - 0.002 * (double)s;
+    if (score > best_score) { best_score = score; best = (int)s; }
+  }
+  return best;
+}
+
+int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsigned flags,
+              size_t ws_bytes, bool fold_mode, Plan &p) {
+  const int esize = dtype == CVM_F64 ? 8 : 4;
+  const int diag_only = fold_mode && !(flags & CVM_RET_XTX);
+  p.g = make_geom(K, M, esize, diag_only);
+  p.splits = choose_splits(n_folds, max_rows, p.g);
+  p.fstat_bytes_per_fold = fold_mode ? align_up(fstat_len(K, M) * 8, 256) : 0;
+  for (;;) {
+    const size_t per_fold = (size_t)p.splits * p.g.unit_bytes + p.fstat_bytes_per_fold;
+    int64_t nb = (int64_t)(ws_bytes / per_fold);
+    if (nb >= 1) { p.folds_per_batch = nb < n_folds ? nb : n_folds; return CVM_OK; }
+    if (p.splits == 1) return CVM_EWORKSPACE;
+    p.splits = (p.splits + 1) / 2;
+  }
+}
+
+template <typename T>
+int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st) {
+  const long per_xcd = (a.n_items + 7) / 8;
+  WgramArgs<T> args = a;
+  args.items_per_xcd = per_xcd;
+  const dim3 grid((unsigned)(per_xcd * 8)), block(NTHREADS);
+  const size_t lds = 2 * BUF_ELEMS * sizeof(T) + 3 * STAGE_ROWS * sizeof(int64_t);
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+#define CVM_LAUNCH(W, GA, AL)                                                              \
+  do {                                                                                     \
+    static unsigned long long attr_done = 0;   /* one bit per device */                   \
+    if (!((attr_done >> (dev & 63)) & 1ull)) {                                             \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram_kernel<T, W, GA, AL>,                 \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+      attr_done |= 1ull << (dev & 63);                                                     \
+    }                                                                                      \
+    hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL>), grid, block, lds, st, args);          \
+  } while (0)
+  if (weighted) {
+    if (gather) { if (aligned) CVM_LAUNCH(true, true, true); else CVM_LAUNCH(true, true, false); }
+    else { if (aligned) CVM_LAUNCH(true, false, true); else CVM_LAUNCH(true, false, false); }
+  } else {
+    if (gather) { if (aligned) CVM_LAUNCH(false, true, true); else CVM_LAUNCH(false, true, false); }
+    else { if (aligned) CVM_LAUNCH(false, false, true); else CVM_LAUNCH(false, false, false); }
+  }
+#undef CVM_LAUNCH
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+
+bool rows_aligned(const void *X, int K, int esize) {
+  return ((uintptr_t)X % 16 == 0) && (((size_t)K * esize) % 16 == 0);
+}
+
+template <typename T>
+int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
+                  void *G, void *H, double *gstats, int32_t *neg_flag, void *ws, size_t ws_bytes,
+                  hipStream_t st) {
+  Plan p;
+  int rc = make_plan(1, N, K, M, dtype, CVM_RET_XTX | CVM_RET_XTY, ws_bytes, false, p);
+  if (rc != CVM_OK) return fail(rc, "cvm_gram_fit: workspace too small%s");
+  WgramArgs<T> a;
+  a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+  a.idx = nullptr; a.offs = nullptr; a.N = N; a.seg0 = 0;
+  a.n_seg = 1; a.splits = p.splits; a.g = p.g;
+  a.n_items = (long)p.splits * p.g.nT; a.items_per_xcd = 0;
+  a.ws = (char *)ws;
+  rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st);
+  if (rc != CVM_OK) return rc;
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = p.g; f.splits = p.splits; f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
+  f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
+  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
+  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles + p.g.P, 1), dim3(NTHREADS), 0, st, f);
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+
+template <typename T>
+int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
+                     const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                     int K, int M, int dtype, unsigned flags, double ddof, double resolution,
+                     const void *G, const void *H, const double *gstats, void *out_XTX,
+                     void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                     double *out_fold, void *ws, size_t ws_bytes, hipStream_t st) {
+  int64_t max_rows = 0;
+  for (int64_t f = 0; f < n_folds; ++f) {
+    const int64_t n = host_offsets[f + 1] - host_offsets[f];
+    if (n < 0) return fail(CVM_EINVAL, "cvm_fold_update: offsets must be non-decreasing%s");
+    if (n > max_rows) max_rows = n;
+  }
+  Plan p;
+  int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
+  if (rc != CVM_OK) return fail(rc, "cvm_fold_update: workspace cannot hold one fold%s");
+  const bool aligned = rows_aligned(X, K, sizeof(T));
+  for (int64_t f0 = 0; f0 < n_folds; f0 += p.folds_per_batch) {
+    const int64_t nb = (n_folds - f0 < p.folds_per_batch) ? n_folds - f0 : p.folds_per_batch;
+    char *units = (char *)ws;
+    double *fstats = (double *)((char *)ws + (size_t)nb * p.splits * p.g.unit_bytes);
+    WgramArgs<T> a;
+    a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+    a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
+    a.n_seg = (int)nb; a.splits = p.splits; a.g = p.g;
+    a.n_items = (long)nb * p.splits * p.g.nT; a.items_per_xcd = 0;
+    a.ws = units;
+    rc = launch_wgram<T>(a, w != nullptr, true, aligned, st);
+    if (rc != CVM_OK) return rc;
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.g = p.g; f.splits = p.splits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = units;
+    f.fstats = (double *)((char *)fstats);
+    f.offs = offsets; f.w = w; f.G = G; f.H = H; f.gstats = gstats;
+    f.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
+    f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
+    f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+    f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+    // fstats rows are fstat_len doubles apart inside the 256-byte aligned slots? keep dense
+    hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, f);
+    if (f.out_XTX || f.out_XTY) {
+      const unsigned gx = p.g.diag_only ? 0 : p.g.nTiles;
+      FinArgs f2 = f;
+      hipLaunchKernelGGL((apply_kernel<T, true>), dim3(p.g.nTiles + p.g.P, (unsigned)nb),
+                         dim3(NTHREADS), 0, st, f2);
+      (void)gx;
+    }
+    HIP_OK(hipGetLastError());
+  }
+  return CVM_OK;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------
+extern "C" {
+
+const char *cvm_version(void) { return "cvmhip 0.1.0 (gfx950)"; }
+const char *cvm_last_error(void) { return g_err; }
+
+size_t cvm_gstats_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 2; }
+
+size_t cvm_fit_workspace_bytes(int64_t N, int K, int M, int dtype) {
+  const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
+  return (size_t)choose_splits(1, N, g) * g.unit_bytes;
+}
+
+int cvm_gram_fit(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
+                 void *G, void *H, double *gstats, int32_t *neg_flag, void *ws, size_t ws_bytes,
+                 void *stream) {
+  if (!X || !G || !gstats || !ws) return fail(CVM_EINVAL, "cvm_gram_fit: null pointer%s");
+  if (N < 0 || K <= 0 || M < 0 || (M > 0 && (!Y || !H)) || (M == 0 && Y))
+    return fail(CVM_EINVAL, "cvm_gram_fit: bad shape%s");
+  if (dtype == CVM_F64)
+    return gram_fit_impl<double>(X, Y, w, N, K, M, dtype, G, H, gstats, neg_flag, ws, ws_bytes,
+                                 (hipStream_t)stream);
+  if (dtype == CVM_F32)
+    return gram_fit_impl<float>(X, Y, w, N, K, M, dtype, G, H, gstats, neg_flag, ws, ws_bytes,
+                                (hipStream_t)stream);
+  return fail(CVM_EINVAL, "cvm_gram_fit: dtype must be CVM_F32 or CVM_F64%s");
+}
+
+size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold_rows, int K, int M,
+                                int dtype, unsigned flags) {
+  (void)n_idx;
+  const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, !(flags & CVM_RET_XTX));
+  const int splits = choose_splits(n_folds, max_fold_rows, g);
+  const size_t per_fold = (size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256);
+  size_t want = per_fold * (size_t)(n_folds > 0 ? n_folds : 1);
+  const size_t cap = (size_t)8 << 30;   // beyond 8 GiB walk the folds in batches
+  if (want > cap) want = (cap / per_fold > 0 ? cap / per_fold : 1) * per_fold;
+  return want;
+}
+
+int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *idx,
+                    const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                    int K, int M, int dtype, unsigned flags, double ddof, double resolution,
+                    const void *G, const void *H, const double *gstats, void *out_XTX,
+                    void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                    double *out_fold, void *ws, size_t ws_bytes, void *stream) {
+  if (!X || !offsets || !host_offsets || !G || !gstats || !ws)
+    return fail(CVM_EINVAL, "cvm_fold_update: null pointer%s");
+  if (n_folds < 0 || N < 0 || K <= 0 || M < 0 || (M > 0 && !Y))
+    return fail(CVM_EINVAL, "cvm_fold_update: bad shape%s");
+  if (!idx && host_offsets[n_folds] > 0) return fail(CVM_EINVAL, "cvm_fold_update: idx is null%s");
+  if ((flags & CVM_RET_XTY) && (M == 0 || !H))
+    return fail(CVM_EINVAL, "cvm_fold_update: CVM_RET_XTY needs Y and H%s");
+  if (n_folds == 0) return CVM_OK;
+  if (dtype == CVM_F64)
+    return fold_update_impl<double>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype,
+                                    flags, ddof, resolution, G, H, gstats, out_XTX, out_XTY, out_muX,
+                                    out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes,
+                                    (hipStream_t)stream);
+  if (dtype == CVM_F32)
+    return fold_update_impl<float>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype,
+                                   flags, ddof, resolution, G, H, gstats, out_XTX, out_XTY, out_muX,
+                                   out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes,
+                                   (hipStream_t)stream);
+  return fail(CVM_EINVAL, "cvm_fold_update: dtype must be CVM_F32 or CVM_F64%s");
+}
+
+int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype, unsigned flags,
+                  size_t ws_bytes, int64_t *info) {
+  if (!info || K <= 0 || M < 0) return fail(CVM_EINVAL, "cvm_plan_fold: bad argument%s");
+  Plan p;
+  const bool fold_mode = (flags & 0x80000000u) == 0;   // bit 31 set: plan the fit stage
+  int rc = make_plan(n_folds, max_fold_rows, K, M, dtype, flags & 0x7fffffffu, ws_bytes, fold_mode, p);
+  if (rc != CVM_OK) return fail(rc, "cvm_plan_fold: workspace too small%s");
+  info[0] = p.splits;
+  info[1] = (int64_t)p.folds_per_batch * p.splits * p.g.nT;
+  info[2] = p.g.P;
+  info[3] = p.g.nT;
+  info[4] = p.folds_per_batch;
+  // MFMA instructions issued per 4 rows of one unit (executed work, incl. padding)
+  int64_t per4 = 0;
+  if (!p.g.diag_only) per4 += (int64_t)(p.g.nTiles - p.g.P) * 64 + (int64_t)p.g.P * 48;
+  if (M > 0) per4 += (int64_t)p.g.P * p.g.Yc * 16;   // two H waves x 8
+  info[5] = per4;
+  return CVM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+"""CVMatrix on MI355X: host-side mirror of the reference class.
+
+Same constructor / ``fit`` / ``training_XTX`` / ``training_XTY`` / ``training_XTX_XTY`` /
+``training_statistics`` surface, return structure, ``None`` pattern, shapes and
+``ValueError`` messages as the reference (cvmatrix/cvmatrix.py:157-167, 207-212, 330-332,
+385-387, 451-453, 519-521), with ``backend="hip"``: the fit stage and the per-fold stage
+each run as one call into libcvmhip.so (include/cvmhip.h) on PyTorch-ROCm device memory.
+Like the reference's ``backend="jax"`` returning ``jax.Array``, results are device arrays
+(``torch.Tensor`` on the GPU); ``.cpu().numpy()`` gives the NumPy view.
+
+New next to the reference API: the ``*_batched`` methods process many folds per launch
+(the shape the reference reaches with ``jax.vmap`` in benchmarks/benchmark.py:144-152),
+taking a ``Partitioner``, a list of index arrays or a prepared ``FoldBatch``.
+
+There is no CPU path in this module: it raises if the extension or a GPU is missing.
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .partitioner import Partitioner
+
+MSG_NEG_W = "Weights must be non-negative."
+MSG_NZ_ZERO = (
+    "The number of non-zero weights in the training set must be greater than zero."
+)
+MSG_NZ_DDOF = (
+    "The number of non-zero weights in the training set must be greater than `ddof`."
+)
+MSG_NEITHER = "At least one of `return_XTX` and `return_XTY` must be True."
+MSG_NO_Y = "Response variables `Y` are not provided."
+
+_TORCH_DT = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}
+
+
+def _resolve_backend(backend: str) -> str:
+    """Counterpart of cvmatrix.py:58-96 for this package: the only backend is "hip"."""
+    if backend == "hip":
+        return backend
+    raise ValueError(
+        f"Invalid backend: {backend!r}. Must be 'hip' (the 'numpy' and 'jax' backends "
+        "live in the reference package)."
+    )
+
+
+class FoldBatch:
+    """Validation indices of many folds, resident on the device in CSR form.
+
+    idx      int64[n]     concatenated row numbers (wrapped to [0,N))
+    offsets  int64[P+1]   fold f owns idx[offsets[f]:offsets[f+1]]
+    Built by ``CVMatrix.prepare_folds``; reusable across ``*_batched`` calls.
+    """
+
+    def __init__(self, idx, offsets, host_offsets, nz_val, labels=None):
+        self.idx, self.offsets = idx, offsets
+        self.host_offsets, self.nz_val, self.labels = host_offsets, nz_val, labels
+
+    @property
+    def n_folds(self) -> int:
+        return int(self.host_offsets.size - 1)
+
+    @property
+    def sizes(self) -> np.ndarray:
+        return np.diff(self.host_offsets)
+
+
+class CVMatrix:
+    """Fast training-set ``XᵀWX`` / ``XᵀWY`` for cross-validation (Engstrøm & Jensen),
+    computed on an MI355X.  Parameters as cvmatrix.py:109-155; ``dtype`` must be
+    float64 or float32; ``backend`` must be ``"hip"``; ``device`` picks the GPU
+    (default: the current torch device)."""
+
+    def __init__(
+        self,
+        center_X: bool = True,
+        center_Y: bool = True,
+        scale_X: bool = True,
+        scale_Y: bool = True,
+        ddof: int = 1,
+        dtype=np.float64,
+        copy: bool = True,
+        backend: str = "hip",
+        device: Union[None, str, int, torch.device] = None,
+    ) -> None:
+        self.center_X, self.center_Y = center_X, center_Y
+        self.scale_X, self.scale_Y = scale_X, scale_Y
+        self.ddof = ddof
+        if isinstance(dtype, torch.dtype):
+            dtype = {torch.float64: np.float64, torch.float32: np.float32}.get(dtype, dtype)
+        self.dtype = dtype.type if isinstance(dtype, np.dtype) else dtype
+        self.copy = copy
+        self.backend = _resolve_backend(backend)
+        try:
+            npdt = np.dtype(self.dtype)
+        except TypeError as e:
+            raise TypeError(f"dtype {dtype!r} is not a floating-point type") from e
+        if npdt not in _TORCH_DT:
+            raise TypeError(
+                f"backend='hip' computes in float64 or float32, not {npdt.name}; "
+                "use the reference package for other dtypes."
+            )
+        self._npdt, self._tdt = npdt, _TORCH_DT[npdt]
+        self._cdt = _lib.CVM_F64 if npdt == np.float64 else _lib.CVM_F32
+        self.resolution = np.finfo(self.dtype).resolution * 10  # cvmatrix.py:187
+        self._device_arg = device
+        self.device: Optional[torch.device] = None
+        self.X = self.Y = self.weights = None
+        self.N = self.K = self.M = None
+        self.XTX = self.XTY = None
+        self.sum_X = self.sum_Y = self.sum_sq_X = self.sum_sq_Y = None
+        self._sum_w = self.num_nonzero_w = None
+        self._gstats = None
+        self._w_host = None
+        self._ws = None
+        self._w_checked = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _pick_device(self) -> torch.device:
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "cvmatrix_amd needs an AMD GPU visible to PyTorch-ROCm; there is no "
+                "CPU fallback."
+            )
+        d = self._device_arg
+        if d is None:
+            return torch.device("cuda", torch.cuda.current_device())
+        d = torch.device(d if not isinstance(d, int) else f"cuda:{d}")
+        return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+
+    def _init_mat(self, mat) -> torch.Tensor:
+        """cvmatrix.py:1131-1151 on the device: cast, copy iff needed, 1-D -> (N,1)."""
+        if isinstance(mat, torch.Tensor):
+            t = mat
+            if t.device != self.device or t.dtype != self._tdt or not t.is_contiguous():
+                t = t.to(device=self.device, dtype=self._tdt).contiguous()
+            elif self.copy:
+                t = t.clone()
+        else:
+            h = np.ascontiguousarray(np.asarray(mat, dtype=self._npdt))
+            t = torch.from_numpy(h).to(self.device)  # the upload is the private copy
+        if t.ndim == 1:
+            t = t.reshape(-1, 1)
+        if t.ndim != 2:
+            raise ValueError("expected a 1-D or 2-D array")
+        return t
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ------------------------------------------------------------------ fit stage
+    def fit(self, X, Y=None, weights=None) -> None:
+        """Store ``X``, ``Y``, ``weights`` on the device and compute the full-data
+        ``XᵀWX``, ``XᵀWY`` and column statistics in one pass (cvmatrix.py:207-328).
+
+        Raises ``ValueError("Weights must be non-negative.")`` like cvmatrix.py:1188-1189.
+        """
+        lib = _lib.load()
+        self.device = self._pick_device()
+        with torch.cuda.device(self.device):
+            self.X = self._init_mat(X)
+            self.N, self.K = self.X.shape
+            if Y is not None:
+                self.Y = self._init_mat(Y)
+                self.M = self.Y.shape[1]
+                if self.Y.shape[0] != self.N:
+                    raise ValueError("X and Y must have the same number of rows")
+            else:
+                self.Y, self.M = None, None
+            if weights is not None:
+                self._check_weights_host(weights)
+                self.weights = self._init_mat(weights)
+                if self.weights.shape != (self.N, 1):
+                    raise ValueError("weights must have shape (N,) or (N, 1)")
+            else:
+                self.weights, self._w_host, self._w_checked = None, None, None
+            M = self.M or 0
+            self.XTX = torch.empty((self.K, self.K), dtype=self._tdt, device=self.device)
+            self.XTY = (torch.empty((self.K, M), dtype=self._tdt, device=self.device)
+                        if self.Y is not None else None)
+            self._gstats = torch.empty(lib.cvm_gstats_len(self.K, M), dtype=torch.float64,
+                                       device=self.device)
+            neg = torch.zeros(1, dtype=torch.int32, device=self.device)
+            ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self.K, M, self._cdt))
+            rc = lib.cvm_gram_fit(
+                self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), self.N, self.K, M,
+                self._cdt, self.XTX.data_ptr(), _lib.ptr(self.XTY), self._gstats.data_ptr(),
+                neg.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(),
+            )
+            _lib.check(rc, "cvm_gram_fit")
+            if self.weights is not None and self._w_host is None:
+                # device-resident weights: one readback for the sign check and for the
+                # host-side fold validity checks (non-zero counts)
+                if int(neg.item()) != 0:
+                    raise ValueError(MSG_NEG_W)
+                self._w_host = self.weights.reshape(-1).cpu().numpy()
+                self._w_checked = self._weights_key(weights)
+            self._publish_stats()
+
+    @staticmethod
+    def _weights_key(w):
+        if isinstance(w, torch.Tensor):
+            return (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+        return None
+
+    def _check_weights_host(self, weights) -> None:
+        """Sign check + host copy of the weights (used for per-fold validity checks)."""
+        if isinstance(weights, torch.Tensor):
+            if weights.device.type == "cpu":
+                h = weights.detach().numpy().reshape(-1)
+            else:
+                key = self._weights_key(weights)
+                if key == self._w_checked and self._w_host is not None:
+                    return  # same unmodified tensor as last fit: already validated
+                self._w_host = None  # validated after the kernel via its sign flag
+                return
+        else:
+            h = np.asarray(weights, dtype=self._npdt).reshape(-1)
+        if bool(np.any(h < 0)):
+            raise ValueError(MSG_NEG_W)
+        self._w_host = np.array(h, dtype=self._npdt, copy=True)
+        self._w_checked = None
+
+    def _publish_stats(self) -> None:
+        """Expose the reference's attributes under the reference's flag conditions
+        (cvmatrix.py:1223-1243).  ``sum_w`` / ``num_nonzero_w`` are host scalars."""
+        K, M = self.K, self.M or 0
+        g = self._gstats
+        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
+        anyflag = cX or cY or sX or sY
+        hasY = self.Y is not None
+        cast = lambda t: t.to(self._tdt).reshape(1, -1)  # noqa: E731
+        self.sum_X = cast(g[0:K]) if (cX or cY or sX) else None
+        self.sum_sq_X = cast(g[K : 2 * K]) if sX else None
+        self.sum_Y = cast(g[2 * K : 2 * K + M]) if ((cX or cY or sY) and hasY) else None
+        self.sum_sq_Y = cast(g[2 * K + M : 2 * K + 2 * M]) if (sY and hasY) else None
+        self._sum_w = None
+        if anyflag:
+            if self.weights is None:
+                self._sum_w = self.num_nonzero_w = self.N
+            else:
+                self.num_nonzero_w = int(np.count_nonzero(self._w_host))
+                self._sum_w = "device"  # read from the device on first access
+        else:
+            self.num_nonzero_w = None
+
+    @property
+    def sum_w(self):
+        """Sum of the weights (cvmatrix.py:1225/1228); ``None`` without centre/scale flags."""
+        if isinstance(self._sum_w, str):
+            K, M = self.K, self.M or 0
+            self._sum_w = self.dtype(self._gstats[2 * K + 2 * M].item())
+        return self._sum_w
+
+    # ------------------------------------------------------------------ fold batches
+    def _wrap_indices(self, v) -> np.ndarray:
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        if v.dtype == bool:
+            v = np.flatnonzero(v)
+        if v.size == 0:
+            return np.zeros(0, dtype=np.int64)
+        if v.dtype.kind not in "iu":
+            raise IndexError("validation indices must be integers")
+        v = v.astype(np.int64, copy=False).reshape(-1)
+        if v.min() < -self.N or v.max() >= self.N:
+            raise IndexError(f"validation index out of bounds for {self.N} samples")
+        return np.where(v < 0, v + self.N, v) if v.min() < 0 else v
+
+    def prepare_folds(self, folds) -> FoldBatch:
+        """Upload validation indices of many folds once (CSR) and pre-compute the per-fold
+        non-zero weight counts on the host.  ``folds``: a ``Partitioner``, or a sequence of
+        index arrays."""
+        if self.X is None:
+            raise RuntimeError("call fit() first")
+        if isinstance(folds, FoldBatch):
+            return folds
+        labels = None
+        if isinstance(folds, Partitioner):
+            labels = list(folds.folds_dict)
+            folds = list(folds.folds_dict.values())
+        parts = [self._wrap_indices(v) for v in folds]
+        sizes = np.array([p.size for p in parts], dtype=np.int64)
+        host_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=host_offsets[1:])
+        idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+        if self._w_host is not None:
+            nzmask = (self._w_host != 0).astype(np.int64)
+            csum = np.concatenate([[0], np.cumsum(nzmask[idx])])
+            nz_val = csum[host_offsets[1:]] - csum[host_offsets[:-1]]
+        else:
+            nz_val = sizes.copy()
+        with torch.cuda.device(self.device):
+            d_idx = torch.from_numpy(idx).to(self.device)
+            d_off = torch.from_numpy(host_offsets).to(self.device)
+        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels)
+
+    def _validate(self, batch: FoldBatch, need_stats: bool, need_std: bool) -> None:
+        """The reference's data-dependent raises, in its order (zero check first, weighted
+        only: cvmatrix.py:612-630; then ddof: 1074-1078), decided on exact host counts."""
+        if not need_stats:
+            return
+        if self.weights is not None:
+            nz_total = self.num_nonzero_w
+            nz_train = nz_total - batch.nz_val
+            if np.any(nz_train == 0):
+                raise ValueError(MSG_NZ_ZERO)
+        else:
+            nz_train = self.N - batch.sizes
+        if need_std and np.any(nz_train <= self.ddof):
+            raise ValueError(MSG_NZ_DDOF)
+
+    def _run(self, batch: FoldBatch, rXTX: bool, rXTY: bool, stat_flags=None,
+             stats_only: bool = False):
+        """One cvm_fold_update call over ``batch``.  Returns raw stacked device tensors.
+        ``stats_only``: keep the return flags (they select which statistics the kernel
+        derives, cvmatrix.py:828-831) but produce no matrices."""
+        lib = _lib.load()
+        K, M, P = self.K, self.M or 0, batch.n_folds
+        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
+        if stat_flags is not None:
+            cX, cY, sX, sY = stat_flags
+        flags = ((_lib.RET_XTX if rXTX else 0) | (_lib.RET_XTY if rXTY else 0)
+                 | (_lib.CENTER_X if cX else 0) | (_lib.CENTER_Y if cY else 0)
+                 | (_lib.SCALE_X if sX else 0) | (_lib.SCALE_Y if sY else 0))
+        dev, dt = self.device, self._tdt
+        with torch.cuda.device(dev):
+            mats = not stats_only
+            out_XTX = torch.empty((P, K, K), dtype=dt, device=dev) if (rXTX and mats) else None
+            out_XTY = torch.empty((P, K, M), dtype=dt, device=dev) if (rXTY and mats) else None
+            muX = torch.empty((P, 1, K), dtype=dt, device=dev)
+            sdX = torch.empty((P, 1, K), dtype=dt, device=dev)
+            muY = torch.empty((P, 1, M), dtype=dt, device=dev) if M else None
+            sdY = torch.empty((P, 1, M), dtype=dt, device=dev) if M else None
+            out_fold = torch.empty((P, 4), dtype=torch.float64, device=dev)
+            sizes = batch.sizes
+            want = lib.cvm_fold_workspace_bytes(P, int(batch.host_offsets[-1]),
+                                                int(sizes.max()) if P else 0, K, M,
+                                                self._cdt, flags)
+            ws = self._workspace(want)
+            rc = lib.cvm_fold_update(
+                self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights),
+                batch.idx.data_ptr(), batch.offsets.data_ptr(),
+                batch.host_offsets.ctypes.data, P, self.N, K, M, self._cdt, flags,
+                float(self.ddof), float(self.resolution), self.XTX.data_ptr(),
+                _lib.ptr(self.XTY), self._gstats.data_ptr(), _lib.ptr(out_XTX),
+                _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(), _lib.ptr(muY),
+                _lib.ptr(sdY), out_fold.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(),
+            )
+            _lib.check(rc, "cvm_fold_update")
+        return out_XTX, out_XTY, (muX, sdX, muY, sdY), out_fold
+
+    def _training_matrices_batched(self, rXTX: bool, rXTY: bool, folds):
+        """Batched counterpart of cvmatrix.py:754-896.  Leading axis = fold."""
+        if not rXTX and not rXTY:
+            raise ValueError(MSG_NEITHER)
+        if self.X is None:
+            raise RuntimeError("call fit() first")
+        if rXTY and self.Y is None:
+            raise ValueError(MSG_NO_Y)
+        batch = self.prepare_folds(folds)
+        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
+        r_muX = cX or (rXTY and cY)                 # cvmatrix.py:828-831
+        r_muY = rXTY and (cX or cY)
+        r_sdX = sX
+        r_sdY = rXTY and sY
+        self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY)
+        xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY)
+        stats = (muX if r_muX else None, sdX if r_sdX else None,
+                 muY if r_muY else None, sdY if r_sdY else None)
+        if rXTX and rXTY:
+            return (xtx, xty), stats
+        return (xtx if rXTX else xty), stats
+
+    # ------------------------------------------------------------------ public API
+    def training_XTX_batched(self, folds):
+        """``training_XTX`` for many folds: (XTX[P,K,K], (muX[P,1,K]|None, sdX|None, None, None))."""
+        return self._training_matrices_batched(True, False, folds)
+
+    def training_XTY_batched(self, folds):
+        return self._training_matrices_batched(False, True, folds)
+
+    def training_XTX_XTY_batched(self, folds):
+        """``training_XTX_XTY`` for many folds in one launch sequence:
+        ((XTX[P,K,K], XTY[P,K,M]), (muX[P,1,K], sdX[P,1,K], muY[P,1,M], sdY[P,1,M]))
+        with ``None`` for statistics the flags do not ask for."""
+        return self._training_matrices_batched(True, True, folds)
+
+    @staticmethod
+    def _first(res):
+        """Strip the fold axis of a one-fold batched result."""
+        mats, stats = res
+        if isinstance(mats, tuple):
+            mats = tuple(m[0] for m in mats)
+        else:
+            mats = mats[0]
+        return mats, tuple(None if s is None else s[0] for s in stats)
+
+    def _training_matrices(self, return_XTX: bool, return_XTY: bool, val_indices):
+        """cvmatrix.py:754-896 for one fold."""
+        if not return_XTX and not return_XTY:
+            raise ValueError(MSG_NEITHER)
+        if self.X is not None and return_XTY and self.Y is None:
+            raise ValueError(MSG_NO_Y)
+        return self._first(
+            self._training_matrices_batched(return_XTX, return_XTY, [val_indices]))
+
+    def training_XTX(self, validation_indices):
+        """Training-set ``XᵀWX`` for every sample except ``validation_indices`` and
+        (mean_X, std_X, None, None); cvmatrix.py:330-383."""
+        return self._training_matrices(True, False, validation_indices)
+
+    def training_XTY(self, validation_indices):
+        """Training-set ``XᵀWY`` and the four statistics; cvmatrix.py:385-449."""
+        return self._training_matrices(False, True, validation_indices)
+
+    def training_XTX_XTY(self, validation_indices):
+        """Training-set ``XᵀWX`` and ``XᵀWY`` and the four statistics; cvmatrix.py:451-517."""
+        return self._training_matrices(True, True, validation_indices)
+
+    def training_statistics_batched(self, folds):
+        """Batched ``training_statistics`` (cvmatrix.py:519-574, flag map 570-573)."""
+        if self.X is None:
+            raise RuntimeError("call fit() first")
+        batch = self.prepare_folds(folds)
+        hasY = self.Y is not None
+        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
+        r_muX, r_sdX = (cX or sX), sX
+        r_muY, r_sdY = ((cY or sY) and hasY), (sY and hasY)
+        if not (r_muX or r_sdX or r_muY or r_sdY):
+            return None, None, None, None
+        self._validate(batch, True, r_sdX or r_sdY)
+        # the kernel derives "what to compute" from (return flags, centre/scale flags)
+        # exactly like cvmatrix.py:828-831; pass a flag set whose derived wants cover
+        # this method's own map (cvmatrix.py:570-573); surplus statistics are dropped
+        _, _, (muX, sdX, muY, sdY), _ = self._run(
+            batch, False, hasY, stat_flags=(r_muX, r_muY, r_sdX, r_sdY), stats_only=True)
+        return (muX if r_muX else None, sdX if r_sdX else None,
+                muY if r_muY else None, sdY if r_sdY else None)
+
+    def training_statistics(self, validation_indices):
+        """(mean_X, std_X, mean_Y, std_Y) of the training set; cvmatrix.py:519-574."""
+        st = self.training_statistics_batched([validation_indices])
+        return tuple(None if s is None else s[0] for s in st)

@@ -1,0 +1,68 @@
+"""Partitioner: fold label -> validation index array.
+
+Host-side mirror of the reference's ``Partitioner`` (cvmatrix/partitioner.py:22-107):
+same constructor, ``folds_dict`` (keys in first-seen order, ascending int index arrays)
+and ``get_validation_indices`` incl. its ``ValueError("Fold ... not found.")``.  Added for
+the batched device path: ``csr()`` exports all folds as one concatenated index array plus
+offsets, the layout ``cvm_fold_update`` (include/cvmhip.h) consumes."""
+
+from __future__ import annotations
+
+from collections.abc import Hashable
+from typing import Iterable, Tuple
+
+import numpy as np
+import numpy.typing as npt
+
+
+class Partitioner:
+    """Groups sample positions by fold label (Algorithm 1 of Engstrøm & Jensen, as in
+    cvmatrix/partitioner.py:89-107).
+
+    Parameters
+    ----------
+    folds : Iterable of Hashable with N elements
+        One label per sample; equal labels form a fold.
+    """
+
+    def __init__(self, folds: Iterable[Hashable]) -> None:
+        self.folds_dict: dict[Hashable, npt.NDArray[np.int_]] = {}
+        self._init_folds_dict(folds)
+
+    def get_validation_indices(self, fold: Hashable) -> npt.NDArray[np.int_]:
+        """Index array of the samples labelled ``fold`` (partitioner.py:61-87)."""
+        try:
+            return self.folds_dict[fold]
+        except KeyError as e:
+            raise ValueError(f"Fold {fold} not found.") from e
+
+    def _init_folds_dict(self, folds: Iterable[Hashable]) -> None:
+        arr = folds if isinstance(folds, np.ndarray) else None
+        if arr is not None and arr.ndim == 1 and arr.dtype.kind in "iub" and arr.size > 0:
+            # vectorised grouping for the common integer-label case (N up to 1e6+):
+            # a stable sort keeps positions ascending inside each fold; folds are then
+            # ordered by first appearance like the reference's dict insertion order.
+            order = np.argsort(arr, kind="stable")
+            sorted_labels = arr[order]
+            starts = np.flatnonzero(np.r_[True, sorted_labels[1:] != sorted_labels[:-1]])
+            ends = np.r_[starts[1:], arr.size]
+            first_pos = order[starts]
+            out: dict = {}
+            for g in np.argsort(first_pos, kind="stable"):
+                out[arr[first_pos[g]]] = order[starts[g] : ends[g]].astype(int, copy=False)
+            self.folds_dict = out
+            return
+        buckets: dict = {}
+        for pos, label in enumerate(folds):
+            buckets.setdefault(label, []).append(pos)
+        self.folds_dict = {k: np.asarray(v, dtype=int) for k, v in buckets.items()}
+
+    def csr(self) -> Tuple[np.ndarray, np.ndarray]:
+        """All folds in ``folds_dict`` order as (indices int64[n], offsets int64[P+1])."""
+        parts = list(self.folds_dict.values())
+        sizes = np.fromiter((p.size for p in parts), dtype=np.int64, count=len(parts))
+        offsets = np.zeros(len(parts) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=offsets[1:])
+        idx = (np.concatenate(parts).astype(np.int64, copy=False) if parts
+               else np.zeros(0, dtype=np.int64))
+        return idx, offsets

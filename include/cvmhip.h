@@ -1,0 +1,119 @@
+/*
+ * cvmhip.h -- C ABI of libcvmhip.so: the MI355X (gfx950) implementation of the cvmatrix
+ * per-fold training-matrix hot path.
+ *
+ * The reference (sm00thix/cvmatrix v3.2.1) has no FFI of its own: its seam is the array
+ * namespace chosen by `_resolve_backend` (cvmatrix/cvmatrix.py:58-96) and used through
+ * `self.xp` by the private methods of `CVMatrix`.  The two entry points below replace,
+ * for a backend literal "hip", exactly the two fused stages behind that seam:
+ *
+ *   cvm_gram_fit     <- CVMatrix.fit(): _init_weighted_mats, _init_matrix_products,
+ *                       _init_stats                      (cvmatrix.py:1193-1243)
+ *   cvm_fold_update  <- CVMatrix._training_matrices / training_statistics for a BATCH of
+ *                       folds: _get_val_matrices, _compute_training_stats,
+ *                       _training_kernel_matrix          (cvmatrix.py:589-1129)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch-ROCm storage) unless it is
+ *     named host_*; row-major, contiguous, no strides;
+ *   - the library never allocates or frees device memory and keeps no pointer after a
+ *     call returns; scratch comes from the caller's workspace `ws`;
+ *   - calls enqueue work on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) and return without synchronising;
+ *   - return value: CVM_OK or a CVM_E* code; cvm_last_error() gives the text for the
+ *     calling thread;
+ *   - dtype: CVM_F64 or CVM_F32 (the reference accepts any NumPy float; f16/f128 are not
+ *     offered on the device).  Column statistics are always kept in float64.
+ *   - results are deterministic: no floating-point atomics, fixed-order reductions.
+ */
+#ifndef CVMHIP_H
+#define CVMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVM_OK 0
+#define CVM_EINVAL 1   /* bad argument */
+#define CVM_EWORKSPACE 2 /* workspace too small */
+#define CVM_ELAUNCH 3  /* HIP launch / runtime error */
+
+#define CVM_F32 0
+#define CVM_F64 1
+
+/* flags for cvm_fold_update (cvmatrix.py:157-163 constructor flags + what to return) */
+#define CVM_RET_XTX 0x01u
+#define CVM_RET_XTY 0x02u
+#define CVM_CENTER_X 0x04u
+#define CVM_CENTER_Y 0x08u
+#define CVM_SCALE_X 0x10u
+#define CVM_SCALE_Y 0x20u
+
+const char *cvm_version(void);
+const char *cvm_last_error(void);
+
+/* Number of float64 entries of the global statistics vector written by cvm_gram_fit and
+ * read by cvm_fold_update:  [ sX(K) | qX(K) | sY(M) | qY(M) | sw | nz ]
+ *   sX = sum_i w_i x_i   (cvmatrix.py:1231)      qX = sum_i w_i x_i^2   (1235-1236)
+ *   sY = sum_i w_i y_i   (1233)                  qY = sum_i w_i y_i^2   (1240-1241)
+ *   sw = sum_i w_i       (1225 / 1228)           nz = #{w_i != 0}       (1226 / 1229)
+ * With w == NULL: w_i = 1, sw = nz = N. */
+size_t cvm_gstats_len(int K, int M);
+
+/* Workspace (bytes) that lets cvm_gram_fit run N rows in one launch sequence. */
+size_t cvm_fit_workspace_bytes(int64_t N, int K, int M, int dtype);
+
+/* Full-data Gram and column statistics (replaces cvmatrix.py:1193-1243).
+ *   X [N,K], Y [N,M] or NULL (then M must be 0), w [N] or NULL (unweighted)
+ *   G [K,K]  = X^T diag(w) X   (exactly symmetric)
+ *   H [K,M]  = X^T diag(w) Y   (untouched if Y == NULL)
+ *   gstats   float64[cvm_gstats_len(K,M)] as laid out above
+ *   neg_flag int32[1], set to 1 if any w_i < 0 (cvmatrix.py:1188), else 0; may be NULL */
+int cvm_gram_fit(const void *X, const void *Y, const void *w, int64_t N, int K, int M,
+                 int dtype, void *G, void *H, double *gstats, int32_t *neg_flag,
+                 void *ws, size_t ws_bytes, void *stream);
+
+/* Workspace (bytes) recommended for a cvm_fold_update call: with it all folds are
+ * processed in one batch.  A smaller workspace is legal as long as it holds one fold;
+ * the call then walks the folds in several batches. */
+size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold_rows,
+                                int K, int M, int dtype, unsigned flags);
+
+/* Training-set matrices for a batch of folds (replaces, per fold, cvmatrix.py:754-896).
+ *   idx      int64[n_idx]      validation row numbers of all folds, concatenated
+ *                              (each in [0,N); duplicates are subtracted twice, as
+ *                              NumPy fancy indexing would)
+ *   offsets  int64[n_folds+1]  DEVICE: fold f owns idx[offsets[f] .. offsets[f+1])
+ *   host_offsets               the same array in HOST memory (sizes the launch)
+ *   G,H,gstats                 outputs of cvm_gram_fit (replicated on every GPU)
+ *   ddof, resolution           cvmatrix.py:172, 187
+ * outputs (any may be NULL if not wanted; *_XTX needs CVM_RET_XTX etc.):
+ *   out_XTX [n_folds,K,K], out_XTY [n_folds,K,M]           dtype
+ *   out_muX,out_sdX [n_folds,K], out_muY,out_sdY [n_folds,M]  dtype
+ *   out_fold float64[n_folds,4] = { sw_train, nz_train, sw_val, nz_val }
+ * The kernels never raise: the caller turns nz_train == 0 / nz_train <= ddof into the
+ * reference's ValueErrors (cvmatrix.py:625-629, 1074-1078).  Statistics are computed
+ * whenever a centre/scale flag asks for them (same conditions as cvmatrix.py:828-831);
+ * un-requested statistic outputs are left untouched. */
+int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *idx,
+                    const int64_t *offsets, const int64_t *host_offsets,
+                    int64_t n_folds, int64_t N, int K, int M, int dtype, unsigned flags,
+                    double ddof, double resolution, const void *G, const void *H,
+                    const double *gstats, void *out_XTX, void *out_XTY, void *out_muX,
+                    void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
+                    void *ws, size_t ws_bytes, void *stream);
+
+/* Introspection for benchmarks/profiles: geometry chosen for a problem.
+ * info[0]=splits, [1]=workgroups of the gram kernel, [2]=panels, [3]=tiles per unit,
+ * [4]=folds per batch, [5]=executed MFMA flops of the gram kernel (as double bits in
+ * info64[0]).  Same decision procedure as the real calls. */
+int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype,
+                  unsigned flags, size_t ws_bytes, int64_t *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVMHIP_H */

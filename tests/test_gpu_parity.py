@@ -1,0 +1,349 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI of libcvmhip.so, against
+(1) the golden vectors produced by the reference, (2) the CPU oracle on the same seeded
+inputs, and (3) size-independent properties at BASELINE.json's full shapes.
+
+Tolerance: fp64 norm-wise 1e-10 (max|d| <= 1e-10 max|ref| and
+Frobenius), statistics element-wise rtol 1e-10.  fp32: compared with the fp64 reference;
+error must not exceed 2x the reference's own float32 error (stored with the digests)."""
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from conftest import assert_normwise, assert_stats, load_json, load_npz, to_np
+from oracle.cvmatrix_oracle import (
+    OracleCVMatrix,
+    OraclePartitioner,
+    benchmark_inputs,
+    complement_indices,
+    naive_training_matrices,
+)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def amd(hip_device):
+    import cvmatrix_amd
+
+    from cvmatrix_amd import _lib
+
+    _lib.load()  # fails loudly if the extension is missing
+    return cvmatrix_amd
+
+
+def make_factory(amd):
+    def make(flags, ddof, dtype=np.float64):
+        return amd.CVMatrix(*flags, ddof=ddof, dtype=dtype)
+
+    return make
+
+
+# ---------------------------------------------------------------- golden vectors (G1-G7)
+def test_g1_inline_fixtures(amd):
+    pc.run_g1(make_factory(amd), amd.Partitioner, TOL)
+
+
+def test_g2_readme_quickstart(amd):
+    pc.run_g2(make_factory(amd), amd.Partitioner, TOL)
+
+
+@pytest.mark.parametrize("name", pc.g3_cases())
+def test_g3_flag_sweep(amd, name):
+    pc.run_g3_case(name, make_factory(amd), amd.Partitioner, TOL)
+
+
+def test_g4_example_zero_weight_and_str_label(amd):
+    pc.run_g4(make_factory(amd), amd.Partitioner, TOL)
+
+
+def test_g5_error_messages(amd):
+    pc.run_g5(amd.CVMatrix, amd.Partitioner)
+
+
+def test_g7_none_pattern(amd):
+    pc.run_g7(amd.CVMatrix)
+
+
+# ---------------------------------------------------------------- digests at full shapes
+@pytest.mark.parametrize("name", ["c2", "c3", "c4s"])
+def test_g6_digest_fp64(amd, name):
+    z = load_npz("g6_digest.npz")
+    meta = load_json("g6_digest_meta.json")[name]
+    X, Y, w, folds = benchmark_inputs(meta["N"], meta["K"], meta["M"], meta["P"])
+    m = amd.CVMatrix(*meta["flags"], ddof=1)
+    m.fit(X, Y, w if meta["weighted"] else None)
+    p = amd.Partitioner(folds)
+    labels = [int(f) for f in z[f"{name}/fold_labels"]]
+    # single-fold calls
+    for f in labels[:2]:
+        (xtx, xty), st = m.training_XTX_XTY(p.get_validation_indices(f))
+        pc.check_digest(z, name, f, xtx, xty, st, TOL)
+    # one batched call over all folds
+    (bx, by), bst = m.training_XTX_XTY_batched(p)
+    keys = list(p.folds_dict)
+    for f in labels:
+        i = keys.index(f)
+        st = tuple(None if s is None else s[i] for s in bst)
+        pc.check_digest(z, name, f, bx[i], by[i], st, TOL)
+    # the result is exactly symmetric (the kernel mirrors the upper triangle)
+    assert bool((bx[0] == bx[0].T).all())
+
+
+def test_g6_digest_fp32_c5_scaled(amd):
+    """C5 shape (K=4096, M=1, fp32), N scaled to 8000: fp32 result vs the fp64 reference
+    must be no worse than 2x the reference's own fp32 error (min 1e-5 slack)."""
+    name = "c5s"
+    z = load_npz("g6_digest.npz")
+    meta = load_json("g6_digest_meta.json")[name]
+    X, Y, w, folds = benchmark_inputs(meta["N"], meta["K"], meta["M"], meta["P"],
+                                      dtype=np.float32)
+    m = amd.CVMatrix(dtype=np.float32)
+    m.fit(X, Y, w)
+    p = amd.Partitioner(folds)
+    (bx, by), bst = m.training_XTX_XTY_batched(p)
+    assert bx.dtype.is_floating_point and bx.element_size() == 4
+    keys = list(p.folds_dict)
+    sx, sy = z[f"{name}/samp_x"], z[f"{name}/samp_y"]
+    for f in [int(f) for f in z[f"{name}/fold_labels"]]:
+        i = keys.index(f)
+        k = f"{name}/fold{f}"
+        x64 = to_np(bx[i]).astype(np.float64)
+        y64 = to_np(by[i]).astype(np.float64)
+        bound_x = max(2 * float(z[f"{k}/ref32_XTX_relfro"]), 1e-5)
+        bound_y = max(2 * float(z[f"{k}/ref32_XTY_relfro"]), 1e-5)
+        # sampled entries and row sums stand in for the full matrix
+        ex = np.abs(x64[sx[:, 0], sx[:, 1]] - z[f"{k}/XTX_samp"]).max() / z[f"{k}/XTX_max"]
+        ey = np.abs(y64[sy[:, 0], sy[:, 1]] - z[f"{k}/XTY_samp"]).max() / z[f"{k}/XTY_max"]
+        assert ex <= bound_x * 8 and ey <= bound_y * 8, (f, ex, ey, bound_x, bound_y)
+        assert abs(np.linalg.norm(x64) - z[f"{k}/XTX_fro"]) <= bound_x * z[f"{k}/XTX_fro"]
+        assert abs(np.linalg.norm(y64) - z[f"{k}/XTY_fro"]) <= bound_y * z[f"{k}/XTY_fro"]
+        for n_, g_ in zip(("muX", "sdX", "muY", "sdY"), bst):
+            np.testing.assert_allclose(to_np(g_[i]), z[f"{k}/{n_}"], rtol=2e-5)
+
+
+# ---------------------------------------------------------------- oracle on seeded inputs
+def _compare_with_oracle(amd, X, Y, w, fold_lists, flags, ddof=1, tol=TOL, dtype=np.float64):
+    m = amd.CVMatrix(*flags, ddof=ddof, dtype=dtype)
+    o = OracleCVMatrix(*flags, ddof=ddof)
+    m.fit(X, Y, w)
+    o.fit(X, Y, w)
+    if Y is not None:
+        (bx, by), bst = m.training_XTX_XTY_batched(fold_lists)
+    else:
+        bx, bst = m.training_XTX_batched(fold_lists)
+        by = None
+    for i, v in enumerate(fold_lists):
+        if Y is not None:
+            (rx, ry), rst = o.training_XTX_XTY(np.asarray(v))
+            assert_normwise(by[i], ry, tol, f"fold{i} XTY")
+        else:
+            rx, rst = o.training_XTX(np.asarray(v))
+        assert_normwise(bx[i], rx, tol, f"fold{i} XTX")
+        assert_stats(tuple(None if s is None else s[i] for s in bst), rst, tol, f"fold{i}")
+    return m, o
+
+
+@pytest.mark.parametrize("K,M", [(1, 1), (7, 3), (129, 33), (130, 16), (257, 70), (384, 0)])
+def test_shapes_ragged_empty_and_unaligned(amd, K, M):
+    """Odd K (unaligned row starts -> scalar-load variant), K/M just past a tile edge,
+    M > 32 (several Y chunks), Y absent; ragged folds incl. an empty one and one with a
+    single row; all against the oracle."""
+    rng = np.random.default_rng(100 + K)
+    N = 700
+    X = rng.standard_normal((N, K)) + 0.5
+    Y = rng.random((N, M)) if M else None
+    w = rng.random(N)
+    w[rng.choice(N, 50, replace=False)] = 0
+    perm = rng.permutation(N)
+    folds = [perm[:300], perm[300:301], np.zeros(0, dtype=int), perm[301:650], perm[650:]]
+    for flags in [(True,) * 4, (False,) * 4, (True, False, True, False)]:
+        _compare_with_oracle(amd, X, Y, w, folds, flags)
+    _compare_with_oracle(amd, X, Y, None, folds, (True,) * 4)
+
+
+def test_duplicates_and_negative_indices(amd):
+    """NumPy fancy-index semantics: duplicates count twice, negatives wrap."""
+    rng = np.random.default_rng(5)
+    X, Y, w = rng.random((50, 6)), rng.random((50, 2)), rng.random(50)
+    v = np.array([3, 3, -1, 10, -50])
+    _compare_with_oracle(amd, X, Y, w, [v], (True,) * 4)
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    with pytest.raises(IndexError):
+        m.training_XTX(np.array([50]))
+
+
+def test_one_dimensional_inputs_and_y_none(amd):
+    """tests/test_cvmatrix.py:1083-1145."""
+    X = np.array([1, 2, 3, 4, 5])
+    Y = np.array([5, 4, 3, 2, 1])
+    w = np.array([2, 4, 6, 8, 10])
+    m, _ = _compare_with_oracle(amd, X, Y, w, [np.array([0, 1]), np.array([4])], (True,) * 4)
+    assert m.X.shape == (5, 1) and m.Y.shape == (5, 1)
+    xtx, st = m.training_XTX(np.array([2, 3]))
+    assert xtx.shape == (1, 1) and st[0].shape == (1, 1) and st[2] is None
+    _compare_with_oracle(amd, X, None, w, [np.array([0, 1])], (True,) * 4)
+
+
+def test_constant_column_is_exact(amd):
+    """A constant-one column must get variance exactly 0 -> std replaced by 1
+    (cvmatrix.py:1128), also WITH weights: the kernel reduces w, w*x and w*x*x in the same
+    order (SURVEY 7 'hard parts' 4; the reference itself only guarantees this unweighted,
+    tests/test_cvmatrix.py:1045-1081)."""
+    rng = np.random.default_rng(11)
+    N, K = 5000, 40
+    X = rng.random((N, K))
+    X[:, 7] = 1.0
+    Y = rng.random((N, 3))
+    Y[:, 1] = 1.0
+    w = rng.random(N)
+    folds = [np.arange(i, N, 7) for i in range(7)]
+    for weights in (None, w):
+        m = amd.CVMatrix()
+        m.fit(X, Y, weights)
+        (_, _), (muX, sdX, muY, sdY) = m.training_XTX_XTY_batched(folds)
+        assert bool((sdX[:, 0, 7] == 1.0).all()) and bool((sdY[:, 0, 1] == 1.0).all())
+        assert bool((muX[:, 0, 7] == 1.0).all())
+
+
+def test_ones_weights_equal_unweighted(amd):
+    """tests/test_cvmatrix.py:978-1018."""
+    rng = np.random.default_rng(3)
+    X, Y = rng.random((400, 20)), rng.random((400, 4))
+    folds = [np.arange(i, 400, 4) for i in range(4)]
+    a = amd.CVMatrix()
+    a.fit(X, Y, np.ones(400))
+    b = amd.CVMatrix()
+    b.fit(X, Y, None)
+    (ax, ay), ast = a.training_XTX_XTY_batched(folds)
+    (bx, by), bst = b.training_XTX_XTY_batched(folds)
+    assert_normwise(ax, to_np(bx), 1e-13)
+    assert_normwise(ay, to_np(by), 1e-13)
+    for s, t in zip(ast, bst):
+        np.testing.assert_allclose(to_np(s), to_np(t), rtol=1e-13)
+
+
+def test_refit_switches_matrices(amd):
+    """tests/test_cvmatrix.py:1020-1043: fit again with X and Y swapped."""
+    rng = np.random.default_rng(9)
+    X, Y, w = rng.random((300, 5)), rng.random((300, 9)), rng.random(300)
+    folds = [np.arange(0, 100), np.arange(100, 300)]
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    m.training_XTX_XTY_batched(folds)
+    m.fit(Y, X, None)
+    o = OracleCVMatrix()
+    o.fit(Y, X, None)
+    (bx, by), _ = m.training_XTX_XTY_batched(folds)
+    for i, v in enumerate(folds):
+        (rx, ry), _ = o.training_XTX_XTY(v)
+        assert_normwise(bx[i], rx, TOL)
+        assert_normwise(by[i], ry, TOL)
+
+
+def test_dtype_preserved_and_copy_semantics(amd, hip_device):
+    """tests/test_cvmatrix.py:1147-1250 on the device: outputs carry the constructor dtype;
+    copy=False aliases a matching device tensor, copy=True does not."""
+    import torch
+
+    rng = np.random.default_rng(2)
+    X = rng.random((64, 4))
+    for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        m = amd.CVMatrix(dtype=dt)
+        m.fit(X, X[:, :2], np.ones(64))
+        (xtx, xty), st = m.training_XTX_XTY(np.arange(8))
+        assert xtx.dtype == tdt and xty.dtype == tdt and all(s.dtype == tdt for s in st)
+    Xd = torch.from_numpy(X).to(hip_device)
+    m = amd.CVMatrix(copy=False)
+    m.fit(Xd)
+    assert m.X.data_ptr() == Xd.data_ptr()
+    m = amd.CVMatrix(copy=True)
+    m.fit(Xd)
+    assert m.X.data_ptr() != Xd.data_ptr()
+    with pytest.raises(TypeError):
+        amd.CVMatrix(dtype=np.float16)
+    with pytest.raises(ValueError, match="Invalid backend"):
+        amd.CVMatrix(backend="tpu")
+
+
+def test_deterministic_and_batch_invariant(amd):
+    """Fixed-order reductions: the same call twice is bit-identical; a fold computed alone
+    or inside a batch agrees to rounding (the row split differs)."""
+    rng = np.random.default_rng(21)
+    X, Y, w = rng.random((20000, 256)), rng.random((20000, 8)), rng.random(20000)
+    folds = [np.arange(i, 20000, 5) for i in range(5)]
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    g1 = m.XTX.clone()
+    (a, b), sa = m.training_XTX_XTY_batched(folds)
+    (c, d), sc = m.training_XTX_XTY_batched(folds)
+    assert bool((a == c).all()) and bool((b == d).all())
+    assert all(bool((s == t).all()) for s, t in zip(sa, sc))
+    m.fit(X, Y, w)
+    assert bool((g1 == m.XTX).all())
+    (e, f), _ = m.training_XTX_XTY(folds[2])
+    assert_normwise(e, to_np(a[2]), 1e-12)
+    assert_normwise(f, to_np(b[2]), 1e-12)
+
+
+def test_small_workspace_walks_folds_in_batches(amd):
+    """cvm_fold_update with a workspace that holds only part of the folds."""
+    rng = np.random.default_rng(8)
+    X, Y, w = rng.random((3000, 140)), rng.random((3000, 4)), rng.random(3000)
+    folds = [np.arange(i, 3000, 12) for i in range(12)]
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    (a, b), _ = m.training_XTX_XTY_batched(folds)
+    import torch
+
+    from cvmatrix_amd import _lib
+
+    lib = _lib.load()
+    full = lib.cvm_fold_workspace_bytes(12, 3000, 250, 140, 4, _lib.CVM_F64, 0x3F)
+    m._ws = torch.empty(full // 5, dtype=torch.uint8, device=m.device)
+    m._workspace = lambda n: m._ws  # keep the undersized workspace
+    (c, d), _ = m.training_XTX_XTY_batched(folds)
+    assert_normwise(c, to_np(a), 1e-12)
+    assert_normwise(d, to_np(b), 1e-12)
+
+
+# ---------------------------------------------------------------- properties at full size
+def test_full_size_partition_linearity_c2(amd):
+    """C2 (N=1e5,K=512,M=16,P=10, no weights, no preprocessing): the folds partition the
+    rows, so sum_f (G - G_train_f) = G and sum_f (H - H_train_f) = H."""
+    X, Y, w, folds = benchmark_inputs(100000, 512, 16, 10)
+    m = amd.CVMatrix(False, False, False, False)
+    m.fit(X, Y, None)
+    p = amd.Partitioner(folds)
+    (bx, by), st = m.training_XTX_XTY_batched(p)
+    assert st == (None, None, None, None)
+    G, H = m.XTX.double(), m.XTY.double()
+    sx = (G[None] - bx.double()).sum(0)
+    sy = (H[None] - by.double()).sum(0)
+    assert_normwise(sx, to_np(G), 1e-12, "sum of validation Grams")
+    assert_normwise(sy, to_np(H), 1e-12)
+    # and the fit-stage Gram itself against a float64 matmul on the device
+    import torch
+
+    Xd = m.X
+    assert_normwise(G, to_np(Xd.T @ Xd), 1e-12, "fit Gram")
+    assert_normwise(H, to_np(Xd.T @ m.Y), 1e-12, "fit XTY")
+
+
+def test_full_size_c3_naive_crosscheck_one_fold(amd):
+    """C3: one fold against the direct training-set computation (the reference's own
+    equivalence test, tests/test_cvmatrix.py:420-537, atol 1e-8) -- independent of the
+    subtract-and-correct algebra."""
+    X, Y, w, folds = benchmark_inputs(100000, 512, 16, 10)
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    p = amd.Partitioner(folds)
+    (xtx, xty), st = m.training_XTX_XTY(p.get_validation_indices(3))
+    op = OraclePartitioner(folds)
+    (nx, ny), nst = naive_training_matrices(X, Y, w, complement_indices(op, 3),
+                                            True, True, True, True, 1)
+    np.testing.assert_allclose(to_np(xtx), nx, atol=1e-8, rtol=1e-7)
+    np.testing.assert_allclose(to_np(xty), ny, atol=1e-8, rtol=1e-7)
+    assert_stats(st, nst, 1e-9, "c3 naive")
