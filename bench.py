@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- folds/sec of the cvmatrix hot path on MI355X.
+
+One "step" = one full cross-validation pass over device-resident inputs, the quantity the
+reference's benchmark times (benchmarks/benchmark.py:101-158): CVMatrix.fit() (full-data
+Gram + column statistics) followed by training_XTX_XTY for every fold (one batched call).
+Workload = BASELINE.json configs[2] ("C3"): N=100000, K=512, M=16, 10 folds
+(folds = arange(N) % P), weighted, center+scale X and Y, float64, inputs from
+default_rng(42).random exactly as benchmarks/benchmark.py:223-233.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): weak scaling.  Every rank
+owns its own N rows and the P folds made of them; the fit stage runs on the local rows and
+ONE RCCL all-reduce of [G | H | column stats] (2.2 MB) makes the full-data matrices of the
+world*N-row data set; the fold stage then needs no communication.  value = folds of all
+ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings)."""
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N, K, M, P, weighted, flags, dtype)
+    "C2": (100000, 512, 16, 10, False, (False,) * 4, np.float64),
+    "C3": (100000, 512, 16, 10, True, (True,) * 4, np.float64),
+    "C4": (1000000, 1024, 32, 64, True, (True,) * 4, np.float64),
+    "C5": (200000, 4096, 1, 20, True, (True,) * 4, np.float32),
+}
+PEAK_TFLOPS = {np.float64: 78.6, np.float32: 157.3}  # MI355X_MICROARCH.md (MFMA = vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def synth(N, K, M, dtype, seed):
+    """benchmarks/benchmark.py:223-233 (draw order X, Y, weights)."""
+    rng = np.random.default_rng(seed=seed)
+    X = rng.random((N, K), dtype=dtype)
+    Y = rng.random((N, M), dtype=dtype)
+    w = rng.random((N,), dtype=dtype)
+    return X, Y, w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows", type=int, default=0, help="override N per GPU (debug)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                     "(one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cvmatrix_amd import Partitioner, _lib
+    from cvmatrix_amd.distributed import ShardedCVMatrix
+
+    lib = _lib.load()
+    N, K, M, P, weighted, flags, dtype = WORKLOADS[args.workload]
+    if args.rows:
+        N = args.rows
+    tdt = torch.float64 if dtype is np.float64 else torch.float32
+
+    X, Y, w = synth(N, K, M, dtype, 42 + rank)
+    folds = np.arange(N) % P
+    Xd = torch.from_numpy(X).to(dev)
+    Yd = torch.from_numpy(Y).to(dev)
+    wd = torch.from_numpy(w).to(dev) if weighted else None
+
+    model = ShardedCVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev,
+                            mode="row_sharded")
+    model.fit(Xd, Yd, wd)
+    batch = model.prepare_folds(Partitioner(folds))
+
+    def step():
+        model.fit(Xd, Yd, wd)
+        return model.training_XTX_XTY_batched(batch)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    lib.cvm_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    t1 = time.perf_counter()
+    ms_fit, ms_fold = C.c_double(), C.c_double()
+    n_fit, n_fold = C.c_int64(), C.c_int64()
+    lib.cvm_timing_read(C.byref(ms_fit), C.byref(n_fit), C.byref(ms_fold), C.byref(n_fold))
+    lib.cvm_timing_enable(0)
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # split timers (outside the timed region): fit alone, fold stage alone
+    def timed(fn, reps=10):
+        fence()
+        a = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - a) / reps * 1e3
+
+    fit_ms = timed(lambda: model.fit(Xd, Yd, wd))
+    fold_ms = timed(lambda: model.training_XTX_XTY_batched(batch))
+
+    result = None
+    if rank == 0:
+        total_folds = P * world * args.steps
+        value = total_folds / elapsed
+        n_val = np.diff(batch.host_offsets).astype(np.float64)
+        # algorithmic flops of one fold-stage Gram launch.  SURVEY.md 8(d) gives two
+        # conventions; `achieved` uses the smaller, symmetric one (what has to be computed:
+        # upper triangle of XTX + XTY), the dense one (what the reference's dgemm executes,
+        # F = 2 n K (K+M)) is reported next to it.
+        f_tri = float((n_val * (K * (K + 1) + 2.0 * K * M)).sum())
+        f_dense = float((2.0 * n_val * K * (K + M)).sum())
+        es = np.dtype(dtype).itemsize
+        b_alg = float((es * n_val * (K + M + 1) + 8 * n_val).sum() + 2.0 * es * K * (K + M) * P)
+        gram_ms = ms_fold.value / max(n_fold.value, 1)
+        fit_gram_ms = ms_fit.value / max(n_fit.value, 1)
+        peak = PEAK_TFLOPS[dtype]
+        achieved = f_tri / (gram_ms * 1e-3) / 1e12
+        info = (C.c_int64 * 8)()
+        fl = 0x3F
+        lib.cvm_plan_fold(P, int(n_val.max()), K, M, _lib.CVM_F64 if es == 8 else _lib.CVM_F32,
+                          fl, C.c_size_t(1 << 40), info)
+        executed = float(info[5]) * 2048.0 * float(np.ceil(n_val / 4.0).sum())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.workload, {}).get("fold_gram_bytes_per_launch")
+        roofline = {
+            "kernel": "wgram_kernel (fold stage: gather + weighted Gram of all folds, 1 launch/step)",
+            "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "flops_per_launch": f_tri, "flops_convention": "n*K*(K+1) + 2*n*K*M per fold (symmetric)",
+            "achieved_dense_convention": round(f_dense / (gram_ms * 1e-3) / 1e12, 3),
+            "mfma_executed_tflops": round(executed / (gram_ms * 1e-3) / 1e12, 3),
+            "avg_launch_ms": round(gram_ms, 4), "launches_timed": int(n_fold.value),
+            "fit_gram_avg_launch_ms": round(fit_gram_ms, 4),
+            "fit_gram_achieved": round((N * (K * (K + 1) + 2.0 * K * M)) / (fit_gram_ms * 1e-3) / 1e12, 3),
+            "algorithmic_hbm_bytes_per_launch": b_alg,
+            "hbm_frac_if_bytes_bound": round(b_alg / (gram_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+        }
+        # parity gate in the same run (C2/C3 only: digests of the reference at these inputs)
+        parity = "not checked"
+        if world == 1 and not args.rows and args.workload in ("C2", "C3"):
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import parity_cases as pc
+                from conftest import load_npz
+
+                z = load_npz("g6_digest.npz")
+                (bx, by), bst = out
+                for f in (0, 4, 9):
+                    st = tuple(None if s is None else s[f] for s in bst)
+                    pc.check_digest(z, args.workload.lower(), f, bx[f], by[f], st, 1e-10)
+                parity = "ok: folds 0,4,9 within 1e-10 norm-wise of the reference digests"
+            except AssertionError as e:  # pragma: no cover
+                parity = f"FAILED: {e}"
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.cvmatrix_oracle import run_cv
+
+            try:
+                from threadpoolctl import threadpool_info
+
+                thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+            except Exception:  # noqa: BLE001
+                thr = os.cpu_count()
+            a = time.perf_counter()
+            run_cv(X, Y, w if weighted else None, folds, *flags, ddof=1, dtype=dtype)
+            cpu_s = time.perf_counter() - a
+            cpu = {"value": round(P / cpu_s, 3), "unit": "folds/s", "cores": int(thr),
+                   "kind": "port",
+                   "sample": f"the full {args.workload} workload once (ctor+Partitioner+fit+{P} folds, "
+                             f"{cpu_s:.1f} s), NumPy oracle (oracle/cvmatrix_oracle.py) on the host, "
+                             f"BLAS threads={thr}, host cores={os.cpu_count()}"}
+        result = {
+            "metric": "folds/sec (training_XTX_XTY, center+scale) at N=1e5,K=512",
+            "value": round(value, 2), "unit": "folds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if es == 8 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: N={N} rows/GPU, K={K}, M={M}, {P} folds/GPU "
+                                   f"(arange(N)%P), {'weighted' if weighted else 'unweighted'}, "
+                                   f"center/scale X,Y={flags[0]}, fit + batched training_XTX_XTY per step",
+                       "parallelism": f"folds+rows sharded over {world} GPU(s); one all-reduce of [G|H|stats]"},
+            "fit_ms": round(fit_ms, 4), "fold_stage_ms": round(fold_ms, 4),
+            "update_only_folds_per_s": round(P / (fold_ms * 1e-3), 1),
+            "parity": parity, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

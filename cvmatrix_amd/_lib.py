@@ -22,6 +22,7 @@ CENTER_X, CENTER_Y, SCALE_X, SCALE_Y = 0x04, 0x08, 0x10, 0x20
 EXPORTS = (
     "cvm_version", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
     "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_plan_fold",
+    "cvm_timing_enable", "cvm_timing_read",
 )
 
 _lib = None
@@ -55,6 +56,10 @@ def load():
     lib.cvm_fold_update.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int,
                                     C.c_int, u32, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp,
                                     vp, vp, vp, sz, vp]
+    lib.cvm_timing_enable.restype = C.c_int
+    lib.cvm_timing_enable.argtypes = [C.c_int]
+    lib.cvm_timing_read.restype = C.c_int
+    lib.cvm_timing_read.argtypes = [vp, vp, vp, vp]
     lib.cvm_plan_fold.restype = C.c_int
     lib.cvm_plan_fold.argtypes = [i64, i64, C.c_int, C.c_int, C.c_int, u32, sz, vp]
     _lib = lib

@@ -581,6 +581,13 @@ int fail(int code, const char *fmt, const char *detail = "") {
     if (e_ != hipSuccess) return fail(CVM_ELAUNCH, #expr ": %s", hipGetErrorString(e_)); \
   } while (0)
 
+// ---- optional per-launch timing of the Gram kernel (bench.py's roofline figure) --------
+struct TimedLaunch { hipEvent_t a, b; int kind; };
+bool g_timing = false;
+TimedLaunch g_timed[8192];
+int g_ntimed = 0;
+int g_timing_kind = 0;   // 0: fit stage, 1: fold stage
+
 struct Plan {
   Geom g;
   int splits;
@@ -644,6 +651,13 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     }                                                                                      \
     hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL>), grid, block, lds, st, args);          \
   } while (0)
+  TimedLaunch *tl = nullptr;
+  if (g_timing && g_ntimed < 8192) {
+    tl = &g_timed[g_ntimed];
+    if (!tl->a) { HIP_OK(hipEventCreate(&tl->a)); HIP_OK(hipEventCreate(&tl->b)); }
+    tl->kind = g_timing_kind;
+    HIP_OK(hipEventRecord(tl->a, st));
+  }
   if (weighted) {
     if (gather) { if (aligned) CVM_LAUNCH(true, true, true); else CVM_LAUNCH(true, true, false); }
     else { if (aligned) CVM_LAUNCH(true, false, true); else CVM_LAUNCH(true, false, false); }
@@ -652,6 +666,7 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     else { if (aligned) CVM_LAUNCH(false, false, true); else CVM_LAUNCH(false, false, false); }
   }
 #undef CVM_LAUNCH
+  if (tl) { HIP_OK(hipEventRecord(tl->b, st)); ++g_ntimed; }
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
@@ -673,6 +688,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   a.n_seg = 1; a.splits = p.splits; a.g = p.g;
   a.n_items = (long)p.splits * p.g.nT; a.items_per_xcd = 0;
   a.ws = (char *)ws;
+  g_timing_kind = 0;
   rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st);
   if (rc != CVM_OK) return rc;
   FinArgs f;
@@ -712,6 +728,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     a.n_seg = (int)nb; a.splits = p.splits; a.g = p.g;
     a.n_items = (long)nb * p.splits * p.g.nT; a.items_per_xcd = 0;
     a.ws = units;
+    g_timing_kind = 1;
     rc = launch_wgram<T>(a, w != nullptr, true, aligned, st);
     if (rc != CVM_OK) return rc;
     FinArgs f;
@@ -806,6 +823,30 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
                                    out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes,
                                    (hipStream_t)stream);
   return fail(CVM_EINVAL, "cvm_fold_update: dtype must be CVM_F32 or CVM_F64%s");
+}
+
+int cvm_timing_enable(int on) {
+  g_timing = on != 0;
+  g_ntimed = 0;
+  return CVM_OK;
+}
+
+int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold) {
+  double ms[2] = {0, 0};
+  int64_t n[2] = {0, 0};
+  for (int i = 0; i < g_ntimed; ++i) {
+    HIP_OK(hipEventSynchronize(g_timed[i].b));
+    float t = 0;
+    HIP_OK(hipEventElapsedTime(&t, g_timed[i].a, g_timed[i].b));
+    ms[g_timed[i].kind] += t;
+    ++n[g_timed[i].kind];
+  }
+  g_ntimed = 0;
+  if (ms_fit) *ms_fit = ms[0];
+  if (n_fit) *n_fit = n[0];
+  if (ms_fold) *ms_fold = ms[1];
+  if (n_fold) *n_fold = n[1];
+  return CVM_OK;
 }
 
 int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype, unsigned flags,

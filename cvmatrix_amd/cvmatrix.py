@@ -112,8 +112,8 @@ class CVMatrix:
         self.X = self.Y = self.weights = None
         self.N = self.K = self.M = None
         self.XTX = self.XTY = None
-        self.sum_X = self.sum_Y = self.sum_sq_X = self.sum_sq_Y = None
-        self._sum_w = self.num_nonzero_w = None
+        self._sum_w = None
+        self._n_total = self._nz_total = None
         self._gstats = None
         self._w_host = None
         self._ws = None
@@ -231,32 +231,60 @@ class CVMatrix:
         self._w_checked = None
 
     def _publish_stats(self) -> None:
-        """Expose the reference's attributes under the reference's flag conditions
-        (cvmatrix.py:1223-1243).  ``sum_w`` / ``num_nonzero_w`` are host scalars."""
-        K, M = self.K, self.M or 0
-        g = self._gstats
-        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
-        anyflag = cX or cY or sX or sY
-        hasY = self.Y is not None
-        cast = lambda t: t.to(self._tdt).reshape(1, -1)  # noqa: E731
-        self.sum_X = cast(g[0:K]) if (cX or cY or sX) else None
-        self.sum_sq_X = cast(g[K : 2 * K]) if sX else None
-        self.sum_Y = cast(g[2 * K : 2 * K + M]) if ((cX or cY or sY) and hasY) else None
-        self.sum_sq_Y = cast(g[2 * K + M : 2 * K + 2 * M]) if (sY and hasY) else None
+        """Host-side totals used by the per-fold validity checks.  ``_n_total`` /
+        ``_nz_total`` are the sample count and non-zero weight count of the WHOLE data set
+        (a row-sharded multi-GPU fit overrides them with the all-reduced values)."""
         self._sum_w = None
-        if anyflag:
-            if self.weights is None:
-                self._sum_w = self.num_nonzero_w = self.N
-            else:
-                self.num_nonzero_w = int(np.count_nonzero(self._w_host))
-                self._sum_w = "device"  # read from the device on first access
-        else:
-            self.num_nonzero_w = None
+        self._n_total = self.N
+        self._nz_total = (self.N if self.weights is None
+                          else int(np.count_nonzero(self._w_host)))
+
+    def _gslice(self, lo: int, hi: int, cond: bool):
+        if not cond or self._gstats is None:
+            return None
+        return self._gstats[lo:hi].to(self._tdt).reshape(1, -1)
+
+    # The reference's global statistics attributes, present under the reference's flag
+    # conditions (cvmatrix.py:1223-1243), materialised from the float64 device vector on
+    # access.
+    @property
+    def _anyflag(self) -> bool:
+        return bool(self.center_X or self.center_Y or self.scale_X or self.scale_Y)
+
+    @property
+    def sum_X(self):
+        return self._gslice(0, self.K, self.center_X or self.center_Y or self.scale_X)
+
+    @property
+    def sum_sq_X(self):
+        return self._gslice(self.K, 2 * self.K, self.scale_X)
+
+    @property
+    def sum_Y(self):
+        M = self.M or 0
+        return self._gslice(2 * self.K, 2 * self.K + M,
+                            (self.center_X or self.center_Y or self.scale_Y)
+                            and self.Y is not None)
+
+    @property
+    def sum_sq_Y(self):
+        M = self.M or 0
+        return self._gslice(2 * self.K + M, 2 * self.K + 2 * M,
+                            self.scale_Y and self.Y is not None)
+
+    @property
+    def num_nonzero_w(self):
+        """cvmatrix.py:1226/1229; ``None`` without centre/scale flags."""
+        return self._nz_total if (self._anyflag and self.X is not None) else None
 
     @property
     def sum_w(self):
         """Sum of the weights (cvmatrix.py:1225/1228); ``None`` without centre/scale flags."""
-        if isinstance(self._sum_w, str):
+        if not self._anyflag or self.X is None:
+            return None
+        if self.weights is None:
+            return self._n_total
+        if self._sum_w is None:
             K, M = self.K, self.M or 0
             self._sum_w = self.dtype(self._gstats[2 * K + 2 * M].item())
         return self._sum_w
@@ -311,12 +339,11 @@ class CVMatrix:
         if not need_stats:
             return
         if self.weights is not None:
-            nz_total = self.num_nonzero_w
-            nz_train = nz_total - batch.nz_val
+            nz_train = self._nz_total - batch.nz_val
             if np.any(nz_train == 0):
                 raise ValueError(MSG_NZ_ZERO)
         else:
-            nz_train = self.N - batch.sizes
+            nz_train = self._n_total - batch.sizes
         if need_std and np.any(nz_train <= self.ddof):
             raise ValueError(MSG_NZ_DDOF)
 

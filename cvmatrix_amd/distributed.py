@@ -1,0 +1,158 @@
+"""Multi-GPU: one process per GPU, folds sharded across ranks, RCCL over xGMI for the one
+exchange the path has (replicating the full-data Gram and column statistics).
+
+The reference has no distributed code at all; its only parallel structure
+is that folds are independent given the full-data matrices (cvmatrix.py:1001-1010 reads
+nothing else).  Two ways to get those matrices onto every rank:
+
+  row-sharded  (default) every rank owns a block of rows -- and therefore the folds made of
+               those rows -- runs the fit-stage kernel on its own rows only and the partial
+               [G | H | gstats] are summed with ONE all-reduce.  Fit work scales 1/world.
+  replicated   every rank holds all rows; rank `src` runs the fit stage and broadcasts
+               [G | H | gstats]; folds are dealt round-robin (fold f -> rank f mod world).
+
+After that exchange the per-fold update needs no communication.  The collectives below
+are written against torch.distributed only, so the same code runs on RCCL ("nccl" backend
+on ROCm) and, for the CPU tests, on gloo."""
+
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .cvmatrix import CVMatrix
+
+
+def assign_folds(sizes: Sequence[int], world: int) -> List[List[int]]:
+    """Deal folds to ranks: longest-processing-time first on the fold row counts (ties by
+    fold number), so ragged folds balance; equal folds reduce to a round-robin deal.
+    Returns, per rank, the fold numbers it owns in ascending order."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    order = sorted(range(len(sizes)), key=lambda f: (-int(sizes[f]), f))
+    load = [0] * world
+    owned: List[List[int]] = [[] for _ in range(world)]
+    for f in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owned[r].append(f)
+        load[r] += int(sizes[f]) if sizes[f] > 0 else 1
+    return [sorted(o) for o in owned]
+
+
+def pack_globals(G: torch.Tensor, H: Optional[torch.Tensor], gstats: torch.Tensor) -> torch.Tensor:
+    """One float64 buffer [G | H | gstats] so the exchange is a single collective
+    (K(K+M)+2(K+M)+2 values: 2.2 MB at K=512,M=16; 67 MB at K=4096)."""
+    parts = [G.reshape(-1).double()]
+    if H is not None:
+        parts.append(H.reshape(-1).double())
+    parts.append(gstats.reshape(-1).double())
+    return torch.cat(parts)
+
+
+def unpack_globals(buf: torch.Tensor, G: torch.Tensor, H: Optional[torch.Tensor],
+                   gstats: torch.Tensor) -> None:
+    o = 0
+    for t in (G, H, gstats):
+        if t is None:
+            continue
+        n = t.numel()
+        t.copy_(buf[o : o + n].reshape(t.shape).to(t.dtype))
+        o += n
+
+
+def allreduce_globals(G, H, gstats, group=None) -> None:
+    """Sum the per-rank partial [G | H | gstats] in place on every rank."""
+    buf = pack_globals(G, H, gstats)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    unpack_globals(buf, G, H, gstats)
+
+
+def broadcast_globals(G, H, gstats, src: int = 0, group=None) -> None:
+    """Replicate rank `src`'s [G | H | gstats] on every rank."""
+    buf = pack_globals(G, H, gstats)
+    dist.broadcast(buf, src=src, group=group)
+    unpack_globals(buf, G, H, gstats)
+
+
+class ShardedCVMatrix(CVMatrix):
+    """CVMatrix over the GPUs of one node, one process per GPU.
+
+    mode="row_sharded": ``fit`` receives THIS RANK'S rows; fold indices passed to
+    ``training_*`` are local row numbers of this rank.  mode="replicated": ``fit`` receives
+    all rows on every rank; use ``my_folds`` to pick this rank's share of the folds."""
+
+    def __init__(self, *args, mode: str = "row_sharded", group=None, src: int = 0, **kw):
+        super().__init__(*args, **kw)
+        if mode not in ("row_sharded", "replicated"):
+            raise ValueError("mode must be 'row_sharded' or 'replicated'")
+        self.mode, self.group, self.src = mode, group, src
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def my_folds(self, sizes: Sequence[int]) -> List[int]:
+        return assign_folds(sizes, self.world)[self.rank]
+
+    def fit(self, X, Y=None, weights=None) -> None:
+        if self.world == 1:
+            return super().fit(X, Y, weights)
+        if self.mode == "row_sharded":
+            super().fit(X, Y, weights)
+            allreduce_globals(self.XTX, self.XTY, self._gstats, self.group)
+            self._sync_totals()
+        else:
+            if self.rank == self.src:
+                super().fit(X, Y, weights)
+            else:
+                self._fit_without_gram(X, Y, weights)
+            broadcast_globals(self.XTX, self.XTY, self._gstats, self.src, self.group)
+
+    def _sync_totals(self) -> None:
+        """Global sample / non-zero-weight counts for the host-side validity checks
+        (cvmatrix.py:612-630, 1074-1078): they ride in the all-reduced gstats."""
+        K, M = self.K, self.M or 0
+        tail = self._gstats[2 * K + 2 * M : 2 * K + 2 * M + 2].cpu()
+        self._nz_total = int(round(float(tail[1])))
+        if self.weights is None:
+            self._n_total = int(round(float(tail[0])))
+        else:
+            cnt = torch.tensor([self.N], dtype=torch.int64, device=self._gstats.device)
+            dist.all_reduce(cnt, group=self.group)
+            self._n_total = int(cnt.item())
+        self._sum_w = None
+
+    def _fit_without_gram(self, X, Y, weights) -> None:
+        """Non-source rank of the replicated mode: upload the data, allocate the globals,
+        skip the fit-stage kernel (the broadcast fills them)."""
+        from . import _lib
+
+        lib = _lib.load()
+        self.device = self._pick_device()
+        with torch.cuda.device(self.device):
+            self.X = self._init_mat(X)
+            self.N, self.K = self.X.shape
+            self.Y = self._init_mat(Y) if Y is not None else None
+            self.M = self.Y.shape[1] if Y is not None else None
+            if weights is not None:
+                self._check_weights_host(weights)
+                self.weights = self._init_mat(weights)
+                if self._w_host is None:
+                    self._w_host = self.weights.reshape(-1).cpu().numpy()
+                    if bool(np.any(self._w_host < 0)):
+                        raise ValueError("Weights must be non-negative.")
+            else:
+                self.weights, self._w_host = None, None
+            M = self.M or 0
+            self.XTX = torch.empty((self.K, self.K), dtype=self._tdt, device=self.device)
+            self.XTY = (torch.empty((self.K, M), dtype=self._tdt, device=self.device)
+                        if Y is not None else None)
+            self._gstats = torch.empty(lib.cvm_gstats_len(self.K, M), dtype=torch.float64,
+                                       device=self.device)
+        self._publish_stats()

@@ -106,10 +106,19 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
                     void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
                     void *ws, size_t ws_bytes, void *stream);
 
+/* Benchmark support: when enabled, a hipEvent pair is recorded on the launch stream around
+ * every launch of the Gram kernel (at most 8192 pairs between reads).  cvm_timing_read
+ * waits for the recorded events, returns the summed kernel milliseconds and launch counts
+ * of the fit stage and of the fold stage since the last read, and resets the list.
+ * Not thread-safe; meant for bench.py only. */
+int cvm_timing_enable(int on);
+int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold);
+
 /* Introspection for benchmarks/profiles: geometry chosen for a problem.
- * info[0]=splits, [1]=workgroups of the gram kernel, [2]=panels, [3]=tiles per unit,
- * [4]=folds per batch, [5]=executed MFMA flops of the gram kernel (as double bits in
- * info64[0]).  Same decision procedure as the real calls. */
+ * info[0]=row splits per fold, [1]=workgroups of the Gram kernel per batch, [2]=column
+ * panels, [3]=work items per (fold, split), [4]=folds per batch, [5]=MFMA instructions the
+ * kernel issues per 4 rows of one fold (executed work, 2048 flop each).  Bit 31 of `flags`
+ * set: plan the fit stage instead.  Same decision procedure as the real calls. */
 int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype,
                   unsigned flags, size_t ws_bytes, int64_t *info);
 
