@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/cvmhip.h"
@@ -103,6 +104,8 @@ template <typename T> struct WgramArgs {
   Geom g;
   long n_items, items_per_xcd;
   char *ws;             // unit u at ws + u*unit_bytes
+  int dbg;              // diagnostic ablations (env CVM_DEBUG): 1 no global loads after the
+                        // first stage, 2 no MFMA, 4 no VALU column sums; results are wrong
 };
 
 template <typename T> __device__ __forceinline__ T *unit_tiles(char *ws, const Geom &g, long u) {
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   const int wr = wave >> 2, wc = wave & 3;
   const bool h_wave = diag && wr == 1 && wc < 2;
   const bool do_g = !g.diag_only && yc == 0;       // the G tile of this item is wanted
-  const bool mfma_wave = h_wave ? (g.M > 0) : do_g;
+  const bool mfma_wave = h_wave || do_g;   // H waves also carry the column sums
 
   int64_t seg_begin, seg_rows;
   if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   acc_t acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = (acc_t){0, 0, 0, 0};
-  double s_x = 0, q_x = 0, s_y = 0, q_y = 0, s_w = 0, n_z = 0, neg = 0;
+  double s_x[4] = {0, 0, 0, 0}, q_x[4] = {0, 0, 0, 0}, s_y[2] = {0, 0}, q_y[2] = {0, 0};
+  double s_w = 0, n_z = 0, neg = 0;
 
   // wave -> operand blocks inside the LDS stage buffer
   const int lk = lane >> 4, lc = lane & 15;
@@ -297,12 +301,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
 #pragma unroll 1
   for (int s = 0; s < nstages; ++s) {
     const bool more = (s + 1 < nstages);
-    if (more) issue_loads(s + 1);
-    const int64_t ring_next = ring_load(s + 3);
+    if (more && !(a.dbg & 1)) issue_loads(s + 1);
+    const int64_t ring_next = (a.dbg & 1) ? -1 : ring_load(s + 3);
     const T *buf = smem + (s & 1) * BUF_ELEMS;
     const T *wb = buf + 2 * PANEL_ELEMS;
 
-    if (mfma_wave) {
+    if (mfma_wave && !(a.dbg & 2)) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int r = 4 * ks + lk;
@@ -311,8 +315,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
         for (int m = 0; m < 4; ++m) af[m] = buf[a_off + r * PITCH + 16 * m];
 #pragma unroll
         for (int n = 0; n < 2; ++n) bf[n] = buf[b_off + r * b_pitch + 16 * n];
+        const T wv = wb[r];   // 0 on rows past the end of the split, 1 if unweighted
+        if (h_wave && !(a.dbg & 4)) {
+          // Column sums on the VALU, in the shadow of this k-step's MFMAs, from the
+          // fragments already in registers: lane (lk,lc) owns rows = lk (mod 4) of column
+          // lc of each 16-column group.  p = w*x is rounded like the MFMA A operand;
+          // s += p, q += p*x.  sw, sX, sY use the same row classes and the same final
+          // combine, so a column of ones gets s == q == sw bit for bit (variance 0).
+          if (yc == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              if (sizeof(T) == 8) {
+                const T pv = WEIGHTED ? (T)(af[m] * wv) : af[m];
+                s_x[m] += (double)pv; q_x[m] += (double)(pv * af[m]);
+              } else {
+                const double pv = (double)wv * (double)af[m];
+                s_x[m] += pv; q_x[m] += pv * (double)af[m];
+              }
+            }
+          }
+          if (ti == 0 && wc == 0) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              if (sizeof(T) == 8) {
+                const T pv = WEIGHTED ? (T)(bf[n] * wv) : bf[n];
+                s_y[n] += (double)pv; q_y[n] += (double)(pv * bf[n]);
+              } else {
+                const double pv = (double)wv * (double)bf[n];
+                s_y[n] += pv; q_y[n] += pv * (double)bf[n];
+              }
+            }
+            s_w += (double)wv;
+            n_z += (wv != (T)0) ? 1.0 : 0.0;
+            neg += (wv < (T)0) ? 1.0 : 0.0;
+          }
+        }
         if (WEIGHTED) {
-          const T wv = wb[r];
 #pragma unroll
           for (int m = 0; m < 4; ++m) af[m] *= wv;
         }
@@ -320,41 +358,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n) acc[m * 2 + n] = MF<T>::mfma(af[m], bf[n], acc[m * 2 + n]);
-      }
-    }
-    if (h_wave) {
-      // VALU column sums, sequential over rows: p = w*x rounded like the MFMA A operand,
-      // s += p, q += p*x.  For x == 1 the three sums sw, s, q are the same sequence of
-      // additions, so a constant-one column gets variance exactly 0.
-      if (yc == 0) {
-#pragma unroll
-        for (int r = 0; r < STAGE_ROWS; ++r) {
-          const T x = buf[r * PITCH + a_col + lane];
-          if (sizeof(T) == 8) {
-            const T p = WEIGHTED ? (T)(wb[r] * x) : x;
-            s_x += (double)p; q_x += (double)(p * x);
-          } else {
-            const double p = (WEIGHTED ? (double)wb[r] : 1.0) * (double)x;
-            s_x += p; q_x += p * (double)x;
-          }
-        }
-      }
-      if (ti == 0 && wc == 0) {
-#pragma unroll
-        for (int r = 0; r < STAGE_ROWS; ++r) {
-          const double wv = (double)wb[r];
-          const T yv = (lane < YT) ? buf[PANEL_ELEMS + r * YPITCH + lane] : (T)0;
-          if (sizeof(T) == 8) {
-            const T p = WEIGHTED ? (T)(wb[r] * yv) : yv;
-            s_y += (double)p; q_y += (double)(p * yv);
-          } else {
-            const double p = wv * (double)yv;
-            s_y += p; q_y += p * (double)yv;
-          }
-          s_w += wv;                       // padded rows carry w = 0
-          n_z += (wv != 0.0) ? 1.0 : 0.0;
-          neg += (wv < 0.0) ? 1.0 : 0.0;
-        }
       }
     }
     if (more) write_lds((s + 1) & 1);
@@ -374,20 +377,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
           for (int r = 0; r < 4; ++r)
             hp[(size_t)(a_col + 16 * m + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] = acc[m * 2 + n][r];
     }
+    // combine the four row classes (lanes lc, lc+16, lc+32, lc+48) in class order
+    auto comb = [&](double v) -> double {
+      const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
+      return ((v + v1) + v2) + v3;   // meaningful in lanes 0..15
+    };
     double *st = unit_stats<T>(a.ws, g, u);
     if (yc == 0) {
-      st[ti * TILE + a_col + lane] = s_x;
-      st[g.Kp + ti * TILE + a_col + lane] = q_x;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double sv = comb(s_x[m]), qv = comb(q_x[m]);
+        if (lk == 0) {
+          st[ti * TILE + a_col + 16 * m + lc] = sv;
+          st[g.Kp + ti * TILE + a_col + 16 * m + lc] = qv;
+        }
+      }
     }
     if (ti == 0 && wc == 0) {
-      if (lane < YT) {
-        st[2 * g.Kp + yc * YT + lane] = s_y;
-        st[2 * g.Kp + g.Mp + yc * YT + lane] = q_y;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const double sv = comb(s_y[n]), qv = comb(q_y[n]);
+        if (lk == 0) {
+          st[2 * g.Kp + yc * YT + 16 * n + lc] = sv;
+          st[2 * g.Kp + g.Mp + yc * YT + 16 * n + lc] = qv;
+        }
       }
+      const double swv = comb(s_w), nzv = comb(n_z), ngv = comb(neg);
       if (yc == 0 && lane == 0) {
-        st[2 * g.Kp + 2 * g.Mp + 0] = s_w;
-        st[2 * g.Kp + 2 * g.Mp + 1] = n_z;
-        st[2 * g.Kp + 2 * g.Mp + 2] = neg;
+        st[2 * g.Kp + 2 * g.Mp + 0] = swv;
+        st[2 * g.Kp + 2 * g.Mp + 1] = nzv;
+        st[2 * g.Kp + 2 * g.Mp + 2] = ngv;
       }
     }
   } else if (do_g && !(diag && wr == 1 && wc < 2)) {
@@ -508,10 +527,13 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
   }
 }
 
-// One 128x128 upper tile (or one 128 x M panel of H) of one segment: ordered sum of the
-// split partials, then (fold mode) total - partial, rank-1 centring, outer-std scaling in
-// the reference's order (cvmatrix.py:1001-1010); the XTX tile is mirrored.
-template <typename T, bool FOLD> __global__ __launch_bounds__(NTHREADS) void apply_kernel(const FinArgs a) {
+// A 16-row slab of one 128x128 upper tile (or one 128 x M panel of H) of one segment:
+// ordered sum of the split partials, then (fold mode) total - partial, rank-1 centring,
+// outer-std scaling in the reference's order (cvmatrix.py:1001-1010); the XTX tile is
+// mirrored into the lower triangle.
+constexpr int APPLY_THREADS = 256;
+constexpr int APPLY_SUB = 8;   // slabs per tile
+template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) void apply_kernel(const FinArgs a) {
   const Geom &g = a.g;
   const int f = blockIdx.y;
   const int x = blockIdx.x;
@@ -522,19 +544,21 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(NTHREADS) void app
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
   const size_t fo = (size_t)(a.seg0 + f);
-  if (x < g.nTiles) {
+  if (x < g.nTiles * APPLY_SUB) {
     if (!a.out_XTX) return;
+    const int t = x / APPLY_SUB, sub = x - t * APPLY_SUB;
     int ti, tj;
-    decode_tile(x, g.P, ti, tj);
+    decode_tile(t, g.P, ti, tj);
     T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
     const T *Gt = (const T *)a.G;
-    for (int e = threadIdx.x; e < TILE * TILE; e += NTHREADS) {
-      const int ra = e >> 7, cb = e & 127;
+    constexpr int ROWS = TILE / APPLY_SUB;
+    for (int e = threadIdx.x; e < ROWS * TILE; e += APPLY_THREADS) {
+      const int ra = sub * ROWS + (e >> 7), cb = e & 127;
       const int ga = ti * TILE + ra, gb = tj * TILE + cb;
       if (ga >= K || gb >= K || (ti == tj && ra > cb)) continue;
+      const size_t off = (size_t)t * TILE * TILE + (size_t)ra * TILE + cb;
       double v = 0;
-      for (int p = 0; p < a.splits; ++p)
-        v += (double)unit_tiles<T>((char *)a.ws, g, u0 + p)[(size_t)x * TILE * TILE + e];
+      for (int p = 0; p < a.splits; ++p) v += (double)unit_tiles<T>((char *)a.ws, g, u0 + p)[off];
       if (FOLD) {
         v = (double)Gt[(size_t)ga * K + gb] - v;
         if (cX) v -= swt * (fs[ga] * fs[gb]);
@@ -545,10 +569,10 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(NTHREADS) void app
     }
   } else {
     if (!a.out_XTY || M == 0) return;
-    const int ti = x - g.nTiles;
+    const int ti = x - g.nTiles * APPLY_SUB;
     T *out = (T *)a.out_XTY + (FOLD ? fo * (size_t)K * M : 0);
     const T *Ht = (const T *)a.H;
-    for (int e = threadIdx.x; e < TILE * M; e += NTHREADS) {
+    for (int e = threadIdx.x; e < TILE * M; e += APPLY_THREADS) {
       const int ra = e / M, m = e - ra * M;
       const int ga = ti * TILE + ra;
       if (ga >= K) continue;
@@ -637,6 +661,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   const long per_xcd = (a.n_items + 7) / 8;
   WgramArgs<T> args = a;
   args.items_per_xcd = per_xcd;
+  static const int dbg_env = getenv("CVM_DEBUG") ? atoi(getenv("CVM_DEBUG")) : 0;
+  args.dbg = dbg_env;
   const dim3 grid((unsigned)(per_xcd * 8)), block(NTHREADS);
   const size_t lds = 2 * BUF_ELEMS * sizeof(T) + 3 * STAGE_ROWS * sizeof(int64_t);
   int dev = 0;
@@ -696,7 +722,8 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   f.g = p.g; f.splits = p.splits; f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
   hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
-  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles + p.g.P, 1), dim3(NTHREADS), 0, st, f);
+  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
+                     dim3(APPLY_THREADS), 0, st, f);
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
@@ -743,11 +770,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     // fstats rows are fstat_len doubles apart inside the 256-byte aligned slots? keep dense
     hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, f);
     if (f.out_XTX || f.out_XTY) {
-      const unsigned gx = p.g.diag_only ? 0 : p.g.nTiles;
-      FinArgs f2 = f;
-      hipLaunchKernelGGL((apply_kernel<T, true>), dim3(p.g.nTiles + p.g.P, (unsigned)nb),
-                         dim3(NTHREADS), 0, st, f2);
-      (void)gx;
+      hipLaunchKernelGGL((apply_kernel<T, true>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, (unsigned)nb),
+                         dim3(APPLY_THREADS), 0, st, f);
     }
     HIP_OK(hipGetLastError());
   }
