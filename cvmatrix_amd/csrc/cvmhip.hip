@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/cvmhip.h"
 
@@ -35,7 +36,8 @@ constexpr int YPITCH = 48;    // LDS row pitch of the Y tile, in elements
 constexpr int NTHREADS = 512; // 8 waves, two per SIMD
 constexpr int PANEL_ELEMS = STAGE_ROWS * PITCH;             // 2304
 constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + STAGE_ROWS;     // A panel, B panel | Y tile, w
-constexpr int TARGET_WG = 256;  // resident workgroups: one per CU (raised if two fit)
+constexpr int TARGET_WG_1 = 256;  // resident workgroups, register-staged kernel: one per CU
+constexpr int TARGET_WG_2 = 256;  // DMA kernel (<= 128 VGPRs): two per CU
 // LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
 // f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
 // the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
@@ -154,8 +156,23 @@ __device__ __forceinline__ void split_range(int64_t n, int splits, int sp, int64
 // barrier per stage).  Row numbers come from a 3-slot LDS ring filled three stages ahead,
 // so no global load in the loop depends on another one.
 // ----------------------------------------------------------------------------------
-template <typename T, bool WEIGHTED, bool GATHER, bool ALIGNED>
+//
+// DMA variant (float64, 16-byte aligned rows): the X panels go global -> LDS directly
+// (global_load_lds_dwordx4: one wave instruction = one 1 KiB panel row, per-lane source
+// address = gather by row number, rows past the end / columns past K read a zero line).
+// No staging registers and no ds_write pass, and the kernel fits 128 VGPRs so that TWO
+// workgroups share a CU: while one waits at its stage barrier the other keeps the MFMA
+// pipe busy.
+__device__ double g_zero_line[32];   // zero-initialised at code-object load
+#ifdef CVM_STAMPS
+// diagnostic build only: per (workgroup, wave) cycle sums of the three phases of a stage
+__device__ unsigned long long g_stamps[1024 * 8 * 4];
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+
+template <typename T, bool WEIGHTED, bool GATHER, bool ALIGNED, bool DMA>
 __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a) {
+  static_assert(!DMA || (ALIGNED && sizeof(T) == 8), "DMA path: aligned float64 only");
   typedef typename MF<T>::acc_t acc_t;
   constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte chunk
   constexpr int CPR = TILE / VEC;                   // chunks per panel row
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   const int wr = wave >> 2, wc = wave & 3;
   const bool h_wave = diag && wr == 1 && wc < 2;
   const bool do_g = !g.diag_only && yc == 0;       // the G tile of this item is wanted
-  const bool mfma_wave = h_wave || do_g;   // H waves also carry the column sums
+  const bool mfma_wave = h_wave ? (g.M > 0 || yc == 0) : do_g;   // H waves also feed the X column sums
 
   int64_t seg_begin, seg_rows;
   if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
@@ -219,11 +236,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   auto ring_store = [&](int s, int64_t row) {
     if (tid < STAGE_ROWS) ring[(s % 3) * STAGE_ROWS + tid] = row;
   };
-  auto load_panel = [&](vec_t *dst, int col0, int s) {
+  auto load_panel = [&](vec_t *dst, int col0, int s, int region, int only_j) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
+      if (only_j >= 0 && j != only_j) continue;
       const int64_t row = ring[(s % 3) * STAGE_ROWS + st_row0 + j * ST_ROW_STEP];
       const int col = col0 + st_col;
+      if (DMA) {
+        // st_row0 == wave for float64: the LDS row address is wave-uniform
+        const T *src = (row >= 0 && col < g.K) ? a.X + row * (int64_t)g.K + col
+                                               : reinterpret_cast<const T *>(g_zero_line);
+        char *dst_row = smem_raw + ((size_t)((s & 1) * BUF_ELEMS + region * PANEL_ELEMS +
+                                             (wave + j * ST_ROW_STEP) * PITCH)) * sizeof(T);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)src,
+            (__attribute__((address_space(3))) void *)dst_row, 16, 0, 0);
+        continue;
+      }
       vec_t v;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[e] = 0;
@@ -239,10 +268,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
       dst[j] = v;
     }
   };
-  auto issue_loads = [&](int s) {
-    load_panel(ra, colA0, s);
-    if (!diag) load_panel(rb, colB0, s);
-    else {
+  // DMA path: the panel loads are issued one "piece" (one 1 KiB LDS-DMA per wave) per MFMA
+  // k-step, in the shadow of that k-step's MFMAs.  pieces 0,1: panel A rows wave, wave+8;
+  // pieces 2,3: panel B (off-diagonal tiles only).
+  auto issue_piece = [&](int s, int piece) {
+    if (piece < 2) load_panel(ra, colA0, s, 0, piece);
+    else if (!diag) load_panel(rb, colB0, s, 1, piece - 2);
+  };
+  auto issue_loads = [&](int s, bool panels) {
+    if (panels) {
+      load_panel(ra, colA0, s, 0, -1);
+      if (!diag) load_panel(rb, colB0, s, 1, -1);
+    }
+    if (diag) {
       const int64_t row = ring[(s % 3) * STAGE_ROWS + y_row];
       T v = 0;
       if (row >= 0 && y_col < g.M) v = a.Y[row * (int64_t)g.M + y_col];
@@ -257,13 +295,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   };
   auto write_lds = [&](int buf) {
     T *base = smem + buf * BUF_ELEMS;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-      *reinterpret_cast<vec_t *>(base + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = ra[j];
-    if (!diag) {
+    if (!DMA) {
 #pragma unroll
       for (int j = 0; j < NCH; ++j)
-        *reinterpret_cast<vec_t *>(base + PANEL_ELEMS + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = rb[j];
+        *reinterpret_cast<vec_t *>(base + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = ra[j];
+    }
+    if (!diag) {
+      if (!DMA) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+          *reinterpret_cast<vec_t *>(base + PANEL_ELEMS + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = rb[j];
+      }
     } else {
       base[PANEL_ELEMS + y_row * YPITCH + y_m] = ry;
     }
@@ -274,8 +316,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   acc_t acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = (acc_t){0, 0, 0, 0};
-  double s_x[4] = {0, 0, 0, 0}, q_x[4] = {0, 0, 0, 0}, s_y[2] = {0, 0}, q_y[2] = {0, 0};
-  double s_w = 0, n_z = 0, neg = 0;
+  // column-sum accumulators; meaning depends on the wave's role (see the k-step loop)
+  double st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};
+  const int stat_role = (h_wave && yc == 0) ? 1 : ((diag && ti == 0 && wave == 0) ? 2 : 0);
 
   // wave -> operand blocks inside the LDS stage buffer
   const int lk = lane >> 4, lc = lane & 15;
@@ -293,79 +336,172 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
     ring_store(1, ring_load(1));
     ring_store(2, ring_load(2));
     __syncthreads();
-    issue_loads(0);
+    issue_loads(0, true);
     write_lds(0);
     __syncthreads();
   }
+  // the second-dispatched half of the workgroup loses issue arbitration to the older
+  // half on every k-step (MI355X_MICROARCH "Two waves per SIMD" item 4): static priority
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-#pragma unroll 1
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = (s + 1 < nstages);
-    if (more && !(a.dbg & 1)) issue_loads(s + 1);
-    const int64_t ring_next = (a.dbg & 1) ? -1 : ring_load(s + 3);
+#ifdef CVM_STAMPS
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
+#endif
+
+  // One pipeline stage, specialised at compile time on the wave's role so that the body is
+  // straight-line code (branches inside it make hipcc drain lgkmcnt at every block edge):
+  //   MFM   the wave issues MFMAs;  ROLE 0 none / 1 X column sums / 2 Y column sums
+  //   LD    a next stage exists (loads for it are issued here)
+  auto stage = [&](auto MFMc, auto ROLEc, auto LDc, int s) {
+    constexpr bool MFM = decltype(MFMc)::value;
+    constexpr int ROLE = decltype(ROLEc)::value;
+    constexpr bool LD = decltype(LDc)::value;
+#ifdef CVM_STAMPS
+    STAMP(t0);
+#endif
+    if (LD) issue_loads(s + 1, !DMA);
+    const int64_t ring_next = ring_load(s + 3);
     const T *buf = smem + (s & 1) * BUF_ELEMS;
     const T *wb = buf + 2 * PANEL_ELEMS;
-
-    if (mfma_wave && !(a.dbg & 2)) {
+#ifdef CVM_STAMPS
+    STAMP(t1);
+#endif
+    if (MFM || ROLE != 0) {
+      // fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks issue
+      T af[2][4], bf[2][2], yf[2][2], wv[2];
+      auto read_frags = [&](int ks, int slot) {
+        const int r = 4 * ks + lk;
+        if (MFM || ROLE == 1) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) af[slot][m] = buf[a_off + r * PITCH + 16 * m];
+        }
+        if (MFM) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) bf[slot][n] = buf[b_off + r * b_pitch + 16 * n];
+        }
+        if (ROLE == 2) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) yf[slot][n] = buf[PANEL_ELEMS + r * YPITCH + 16 * n + lc];
+        }
+        wv[slot] = wb[r];   // 0 on rows past the end of the split, 1 if unweighted
+      };
+      read_frags(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int r = 4 * ks + lk;
-        T af[4], bf[2];
+        const int c = ks & 1;
+        if (ks < 3) read_frags(ks + 1, c ^ 1);
+        // Column sums on the VALU, in the shadow of this k-step's MFMAs, from fragments
+        // in registers: lane (lk,lc) owns rows = lk (mod 4) of column lc of each 16-column
+        // group.  p = w*x is rounded like the MFMA A operand; s += p, q += p*x.  sw, sX,
+        // sY use the same row classes and the same final combine, so a column of ones
+        // gets s == q == sw bit for bit (variance exactly 0).
+        if (ROLE == 1) {          // H wave: its 64 X columns
 #pragma unroll
-        for (int m = 0; m < 4; ++m) af[m] = buf[a_off + r * PITCH + 16 * m];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bf[n] = buf[b_off + r * b_pitch + 16 * n];
-        const T wv = wb[r];   // 0 on rows past the end of the split, 1 if unweighted
-        if (h_wave && !(a.dbg & 4)) {
-          // Column sums on the VALU, in the shadow of this k-step's MFMAs, from the
-          // fragments already in registers: lane (lk,lc) owns rows = lk (mod 4) of column
-          // lc of each 16-column group.  p = w*x is rounded like the MFMA A operand;
-          // s += p, q += p*x.  sw, sX, sY use the same row classes and the same final
-          // combine, so a column of ones gets s == q == sw bit for bit (variance 0).
-          if (yc == 0) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              if (sizeof(T) == 8) {
-                const T pv = WEIGHTED ? (T)(af[m] * wv) : af[m];
-                s_x[m] += (double)pv; q_x[m] += (double)(pv * af[m]);
-              } else {
-                const double pv = (double)wv * (double)af[m];
-                s_x[m] += pv; q_x[m] += pv * (double)af[m];
-              }
+          for (int m = 0; m < 4; ++m) {
+            if (sizeof(T) == 8) {
+              const T pv = WEIGHTED ? (T)(af[c][m] * wv[c]) : af[c][m];
+              st_s[m] += (double)pv; st_q[m] += (double)(pv * af[c][m]);
+            } else {
+              const double pv = (double)wv[c] * (double)af[c][m];
+              st_s[m] += pv; st_q[m] += pv * (double)af[c][m];
             }
           }
-          if (ti == 0 && wc == 0) {
+        } else if (ROLE == 2) {   // wave 0 of panel 0: Y columns, sw, nz
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-              if (sizeof(T) == 8) {
-                const T pv = WEIGHTED ? (T)(bf[n] * wv) : bf[n];
-                s_y[n] += (double)pv; q_y[n] += (double)(pv * bf[n]);
-              } else {
-                const double pv = (double)wv * (double)bf[n];
-                s_y[n] += pv; q_y[n] += pv * (double)bf[n];
-              }
+          for (int n = 0; n < 2; ++n) {
+            const T yv = yf[c][n];
+            if (sizeof(T) == 8) {
+              const T pv = WEIGHTED ? (T)(yv * wv[c]) : yv;
+              st_s[n] += (double)pv; st_q[n] += (double)(pv * yv);
+            } else {
+              const double pv = (double)wv[c] * (double)yv;
+              st_s[n] += pv; st_q[n] += pv * (double)yv;
             }
-            s_w += (double)wv;
-            n_z += (wv != (T)0) ? 1.0 : 0.0;
-            neg += (wv < (T)0) ? 1.0 : 0.0;
           }
+          st_s[2] += (double)wv[c];                         // sw
+          st_s[3] += (wv[c] != (T)0) ? 1.0 : 0.0;           // nz
+          st_q[3] += (wv[c] < (T)0) ? 1.0 : 0.0;            // any negative weight
         }
-        if (WEIGHTED) {
+        if (MFM) {
+          if (WEIGHTED) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) af[m] *= wv;
+            for (int m = 0; m < 4; ++m) af[c][m] *= wv[c];
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              acc[m * 2 + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * 2 + n]);
         }
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m * 2 + n] = MF<T>::mfma(af[m], bf[n], acc[m * 2 + n]);
+        if (DMA && LD) issue_piece(s + 1, ks);
       }
+    } else if (DMA && LD) {
+#pragma unroll
+      for (int piece = 0; piece < 4; ++piece) issue_piece(s + 1, piece);
     }
-    if (more) write_lds((s + 1) & 1);
+#ifdef CVM_STAMPS
+    STAMP(t2);
+#endif
+    if (LD) write_lds((s + 1) & 1);
     ring_store(s + 3, ring_next);   // slot (s%3) was last read for stage s, one barrier ago
     __syncthreads();
+#ifdef CVM_STAMPS
+    STAMP(t3);
+    t_a += t1 - t0; t_b += t2 - t1; t_c += t3 - t2;
+#endif
+  };
+  auto run = [&](auto MFMc, auto ROLEc) {
+#pragma unroll 1
+    for (int s = 0; s + 1 < nstages; ++s) stage(MFMc, ROLEc, std::true_type{}, s);
+    if (nstages > 0) stage(MFMc, ROLEc, std::false_type{}, nstages - 1);
+  };
+  typedef std::integral_constant<int, 0> R0;
+  typedef std::integral_constant<int, 1> R1;
+  typedef std::integral_constant<int, 2> R2;
+  if (!diag) run(std::true_type{}, R0{});
+  else if (h_wave) { if (yc == 0) run(std::true_type{}, R1{}); else run(std::true_type{}, R0{}); }
+  else if (stat_role == 2) { if (do_g) run(std::true_type{}, R2{}); else run(std::false_type{}, R2{}); }
+  else { if (do_g) run(std::true_type{}, R0{}); else run(std::false_type{}, R0{}); }
+#ifdef CVM_STAMPS
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+    o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = (unsigned long long)nstages;
   }
+#endif
 
   // ---- store partials -------------------------------------------------------------------
+  // combine the four row classes (lanes lc, lc+16, lc+32, lc+48) in class order
+  auto comb = [&](double v) -> double {
+    const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
+    return ((v + v1) + v2) + v3;   // meaningful in lanes 0..15
+  };
+  if (stat_role == 1) {
+    double *st = unit_stats<T>(a.ws, g, u);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double sv = comb(st_s[m]), qv = comb(st_q[m]);
+      if (lk == 0) {
+        st[ti * TILE + a_col + 16 * m + lc] = sv;
+        st[g.Kp + ti * TILE + a_col + 16 * m + lc] = qv;
+      }
+    }
+  } else if (stat_role == 2) {
+    double *st = unit_stats<T>(a.ws, g, u);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const double sv = comb(st_s[n]), qv = comb(st_q[n]);
+      if (lk == 0) {
+        st[2 * g.Kp + yc * YT + 16 * n + lc] = sv;
+        st[2 * g.Kp + g.Mp + yc * YT + 16 * n + lc] = qv;
+      }
+    }
+    const double swv = comb(st_s[2]), nzv = comb(st_s[3]), ngv = comb(st_q[3]);
+    if (yc == 0 && lane == 0) {
+      st[2 * g.Kp + 2 * g.Mp + 0] = swv;
+      st[2 * g.Kp + 2 * g.Mp + 1] = nzv;
+      st[2 * g.Kp + 2 * g.Mp + 2] = ngv;
+    }
+  }
   if (h_wave) {
     if (g.M > 0) {
       T *hp = unit_h<T>(a.ws, g, u) + (size_t)ti * TILE * g.Mp + yc * YT;
@@ -377,39 +513,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
           for (int r = 0; r < 4; ++r)
             hp[(size_t)(a_col + 16 * m + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] = acc[m * 2 + n][r];
     }
-    // combine the four row classes (lanes lc, lc+16, lc+32, lc+48) in class order
-    auto comb = [&](double v) -> double {
-      const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
-      return ((v + v1) + v2) + v3;   // meaningful in lanes 0..15
-    };
-    double *st = unit_stats<T>(a.ws, g, u);
-    if (yc == 0) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const double sv = comb(s_x[m]), qv = comb(q_x[m]);
-        if (lk == 0) {
-          st[ti * TILE + a_col + 16 * m + lc] = sv;
-          st[g.Kp + ti * TILE + a_col + 16 * m + lc] = qv;
-        }
-      }
-    }
-    if (ti == 0 && wc == 0) {
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const double sv = comb(s_y[n]), qv = comb(q_y[n]);
-        if (lk == 0) {
-          st[2 * g.Kp + yc * YT + 16 * n + lc] = sv;
-          st[2 * g.Kp + g.Mp + yc * YT + 16 * n + lc] = qv;
-        }
-      }
-      const double swv = comb(s_w), nzv = comb(n_z), ngv = comb(neg);
-      if (yc == 0 && lane == 0) {
-        st[2 * g.Kp + 2 * g.Mp + 0] = swv;
-        st[2 * g.Kp + 2 * g.Mp + 1] = nzv;
-        st[2 * g.Kp + 2 * g.Mp + 2] = ngv;
-      }
-    }
-  } else if (do_g && !(diag && wr == 1 && wc < 2)) {
+  } else if (do_g) {
     T *tp = unit_tiles<T>(a.ws, g, u) + (size_t)it * TILE * TILE;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -622,7 +726,7 @@ struct Plan {
 // Row splits per segment.  Model: TARGET_WG workgroups are resident at a time and take
 // equal time, so W = items*splits workgroups cost ceil(W/TARGET_WG) rounds; pick the split
 // count with the best fill, lightly preferring fewer splits (less partial traffic).
-int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g) {
+int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g, int TARGET_WG) {
   const int64_t items = (n_seg > 0 ? n_seg : 1) * g.nT;
   int64_t cap = max_rows / 64;                       // >= 64 rows per split
   const int64_t mem_cap = (int64_t)(((size_t)3 << 30) / ((size_t)(n_seg > 0 ? n_seg : 1) * g.unit_bytes));
@@ -640,12 +744,18 @@ int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g) {
   return best;
 }
 
+// which Gram kernel variant a problem gets (pointers from torch are 256-byte aligned; a
+// misaligned X falls back to the register path at launch, only the split heuristic differs)
+int target_wg(int K, int esize) {
+  return (esize == 8 && ((size_t)K * esize) % 16 == 0) ? TARGET_WG_2 : TARGET_WG_1;
+}
+
 int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsigned flags,
               size_t ws_bytes, bool fold_mode, Plan &p) {
   const int esize = dtype == CVM_F64 ? 8 : 4;
   const int diag_only = fold_mode && !(flags & CVM_RET_XTX);
   p.g = make_geom(K, M, esize, diag_only);
-  p.splits = choose_splits(n_folds, max_rows, p.g);
+  p.splits = choose_splits(n_folds, max_rows, p.g, target_wg(K, esize));
   p.fstat_bytes_per_fold = fold_mode ? align_up(fstat_len(K, M) * 8, 256) : 0;
   for (;;) {
     const size_t per_fold = (size_t)p.splits * p.g.unit_bytes + p.fstat_bytes_per_fold;
@@ -667,15 +777,15 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   const size_t lds = 2 * BUF_ELEMS * sizeof(T) + 3 * STAGE_ROWS * sizeof(int64_t);
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
-#define CVM_LAUNCH(W, GA, AL)                                                              \
+#define CVM_LAUNCH(W, GA, AL, DM)                                                             \
   do {                                                                                     \
     static unsigned long long attr_done = 0;   /* one bit per device */                   \
     if (!((attr_done >> (dev & 63)) & 1ull)) {                                             \
-      HIP_OK(hipFuncSetAttribute((const void *)wgram_kernel<T, W, GA, AL>,                 \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram_kernel<T, W, GA, AL, DM>,             \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
       attr_done |= 1ull << (dev & 63);                                                     \
     }                                                                                      \
-    hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL>), grid, block, lds, st, args);          \
+    hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL, DM>), grid, block, lds, st, args);      \
   } while (0)
   TimedLaunch *tl = nullptr;
   if (g_timing && g_ntimed < 8192) {
@@ -684,12 +794,19 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     tl->kind = g_timing_kind;
     HIP_OK(hipEventRecord(tl->a, st));
   }
-  if (weighted) {
-    if (gather) { if (aligned) CVM_LAUNCH(true, true, true); else CVM_LAUNCH(true, true, false); }
-    else { if (aligned) CVM_LAUNCH(true, false, true); else CVM_LAUNCH(true, false, false); }
+  constexpr bool CAN_DMA = sizeof(T) == 8;
+  const bool dma = CAN_DMA && aligned && !(dbg_env & 16);
+  if (dma) {
+    if constexpr (CAN_DMA) {
+      if (weighted) { if (gather) CVM_LAUNCH(true, true, true, true); else CVM_LAUNCH(true, false, true, true); }
+      else { if (gather) CVM_LAUNCH(false, true, true, true); else CVM_LAUNCH(false, false, true, true); }
+    }
+  } else if (weighted) {
+    if (gather) { if (aligned) CVM_LAUNCH(true, true, true, false); else CVM_LAUNCH(true, true, false, false); }
+    else { if (aligned) CVM_LAUNCH(true, false, true, false); else CVM_LAUNCH(true, false, false, false); }
   } else {
-    if (gather) { if (aligned) CVM_LAUNCH(false, true, true); else CVM_LAUNCH(false, true, false); }
-    else { if (aligned) CVM_LAUNCH(false, false, true); else CVM_LAUNCH(false, false, false); }
+    if (gather) { if (aligned) CVM_LAUNCH(false, true, true, false); else CVM_LAUNCH(false, true, false, false); }
+    else { if (aligned) CVM_LAUNCH(false, false, true, false); else CVM_LAUNCH(false, false, false, false); }
   }
 #undef CVM_LAUNCH
   if (tl) { HIP_OK(hipEventRecord(tl->b, st)); ++g_ntimed; }
@@ -785,14 +902,14 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
 // ----------------------------------------------------------------------------------
 extern "C" {
 
-const char *cvm_version(void) { return "cvmhip 0.1.0 (gfx950)"; }
+const char *cvm_version(void) { return "cvmhip 0.1.0 (gfx950) built " __DATE__ " " __TIME__; }
 const char *cvm_last_error(void) { return g_err; }
 
 size_t cvm_gstats_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 2; }
 
 size_t cvm_fit_workspace_bytes(int64_t N, int K, int M, int dtype) {
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
-  return (size_t)choose_splits(1, N, g) * g.unit_bytes;
+  return (size_t)choose_splits(1, N, g, target_wg(K, dtype == CVM_F64 ? 8 : 4)) * g.unit_bytes;
 }
 
 int cvm_gram_fit(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
@@ -814,7 +931,7 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
                                 int dtype, unsigned flags) {
   (void)n_idx;
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, !(flags & CVM_RET_XTX));
-  const int splits = choose_splits(n_folds, max_fold_rows, g);
+  const int splits = choose_splits(n_folds, max_fold_rows, g, target_wg(K, dtype == CVM_F64 ? 8 : 4));
   const size_t per_fold = (size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256);
   size_t want = per_fold * (size_t)(n_folds > 0 ? n_folds : 1);
   const size_t cap = (size_t)8 << 30;   // beyond 8 GiB walk the folds in batches
@@ -848,6 +965,14 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
                                    (hipStream_t)stream);
   return fail(CVM_EINVAL, "cvm_fold_update: dtype must be CVM_F32 or CVM_F64%s");
 }
+
+#ifdef CVM_STAMPS
+int cvm_debug_stamps(unsigned long long *host_out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024 * 8 * 4));
+  return CVM_OK;
+}
+#endif
 
 int cvm_timing_enable(int on) {
   g_timing = on != 0;
