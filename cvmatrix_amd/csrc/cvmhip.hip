@@ -37,7 +37,7 @@ constexpr int NTHREADS = 512; // 8 waves, two per SIMD
 constexpr int PANEL_ELEMS = STAGE_ROWS * PITCH;             // 2304
 constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + STAGE_ROWS;     // A panel, B panel | Y tile, w
 constexpr int TARGET_WG_1 = 256;  // resident workgroups, register-staged kernel: one per CU
-constexpr int TARGET_WG_2 = 256;  // DMA kernel (<= 128 VGPRs): two per CU
+constexpr int TARGET_WG_2 = 512;  // DMA kernel (<= 128 VGPRs): two per CU
 // LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
 // f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
 // the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
@@ -119,6 +119,32 @@ template <typename T> __device__ __forceinline__ T *unit_h(char *ws, const Geom 
 template <typename T> __device__ __forceinline__ double *unit_stats(char *ws, const Geom &g, long u) {
   return (double *)(ws + (size_t)u * g.unit_bytes + ((g.tile_elems * sizeof(T) + 255) / 256 * 256) +
                     ((g.h_elems * sizeof(T) + 255) / 256 * 256));
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename P> __device__ __forceinline__ P *unip(P *p) { return (P *)uni64((long long)p); }
+// by-value copy of the launch arguments with every field forced into scalar registers; a
+// body function that reads them through the caller's reference reloads them with flat
+// loads (and a full vmcnt wait) at every use
+template <typename T> __device__ __forceinline__ WgramArgs<T> scalarize(const WgramArgs<T> &r) {
+  WgramArgs<T> a;
+  a.X = unip(r.X); a.Y = unip(r.Y); a.w = unip(r.w); a.idx = unip(r.idx); a.offs = unip(r.offs);
+  a.N = uni64(r.N); a.seg0 = uni64(r.seg0); a.n_seg = uni(r.n_seg); a.splits = uni(r.splits);
+  a.g.K = uni(r.g.K); a.g.M = uni(r.g.M); a.g.P = uni(r.g.P); a.g.Kp = uni(r.g.Kp);
+  a.g.Yc = uni(r.g.Yc); a.g.Mp = uni(r.g.Mp); a.g.nTiles = uni(r.g.nTiles); a.g.nT = uni(r.g.nT);
+  a.g.diag_only = uni(r.g.diag_only);
+  a.g.tile_elems = (size_t)uni64((long long)r.g.tile_elems);
+  a.g.h_elems = (size_t)uni64((long long)r.g.h_elems);
+  a.g.stat_len = (size_t)uni64((long long)r.g.stat_len);
+  a.g.unit_bytes = (size_t)uni64((long long)r.g.unit_bytes);
+  a.n_items = uni64(r.n_items); a.items_per_xcd = uni64(r.items_per_xcd);
+  a.ws = unip(r.ws); a.dbg = uni(r.dbg);
+  return a;
 }
 
 __device__ __forceinline__ void decode_tile(int t, int P, int &ti, int &tj) {
@@ -526,6 +552,338 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
 }
 
 // ----------------------------------------------------------------------------------
+// wgram4_kernel: the fast path (float64, 16-byte aligned rows, even M).
+//
+// Same work decomposition, LDS image and partial layout as wgram_kernel, but a workgroup is
+// FOUR waves (one per SIMD) and TWO workgroups share a CU: the two waves of a SIMD belong to
+// different workgroups with independent barriers, so one keeps the MFMA pipe busy while the
+// other sits at its stage barrier or issues loads.  Wave (wr,wc) owns the 64x64 block
+// (wr,wc) of the tile: 4x4 MFMA tiles, 16 accumulators (128 VGPRs), 16 MFMAs per 8 LDS
+// fragment reads.  On a diagonal tile the strictly-lower block (1,0) is not computed and
+// its wave (the "H wave") computes panel_i^T W Y[:, 32c..32c+32) (8x2 MFMA tiles) plus the
+// X column sums of the whole panel; wave 0 of panel 0 adds the Y column sums, sw and nz.
+// X panels arrive by LDS-DMA (global_load_lds_dwordx4, one 1 KiB panel row per wave
+// instruction, gathered by row number), issued two per k-step behind that k-step's MFMAs.
+// ----------------------------------------------------------------------------------
+constexpr int NT4 = 256;
+// The body is instantiated once per wave role and kept out of line: inlined together, the
+// register allocator has to give all roles one common assignment of the 128 accumulator
+// registers and spills hundreds of values; as separate functions every role fits.
+template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER>
+__device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
+  typedef double T;
+  const WgramArgs<double> a = scalarize(a_ref);
+  typedef MF<double>::acc_t acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  int64_t *ring = reinterpret_cast<int64_t *>(smem_raw + 2 * BUF_ELEMS * sizeof(T));
+
+  const Geom &g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const long b = blockIdx.x;
+  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
+  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+  const long u = item / g.nT;
+  const int it = (int)(item - u * g.nT);
+  const int seg = (int)(u / a.splits);
+  const int sp = (int)(u - (long)seg * a.splits);
+  int ti, tj, yc;
+  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
+  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
+  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  const bool diag = (ti == tj);
+  const int wr = wave >> 1, wc = wave & 1;
+  const bool h_wave = diag && wave == 2;
+  const bool do_g = !g.diag_only && yc == 0;
+  // column-sum roles on a diagonal tile: waves 0 and 3 (blocks (0,0), (1,1)) sum the X
+  // columns of their own A fragments (64 columns each), wave 1 sums the Y columns, sw and
+  // nz (panel 0 only); the H wave has no spare registers for sums
+  const int stat_role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
+
+  int64_t seg_begin, seg_rows;
+  if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
+  else { seg_begin = 0; seg_rows = a.N; }
+  int64_t r0, r1;
+  split_range(seg_rows, a.splits, sp, r0, r1);
+  const int nstages = (int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS);
+
+  const int colA0 = ti * TILE, colB0 = tj * TILE;
+  const int dcol = lane * 2;                         // this lane's 2 columns of a panel row
+  const int y_row = tid >> 5, y_m = tid & 31;        // Y tile: rows y_row, y_row + 8
+  const int y_col = yc * YT + y_m;
+  T ry[2] = {0, 0}, rw = 0;
+
+  auto ring_load = [&](int s) -> int64_t {
+    int64_t row = -1;
+    if (tid < STAGE_ROWS) {
+      int64_t r = r0 + (int64_t)s * STAGE_ROWS + tid;
+      if (r < r1) row = GATHER ? a.idx[seg_begin + r] : seg_begin + r;
+    }
+    return row;
+  };
+  auto ring_store = [&](int s, int64_t row) {
+    if (tid < STAGE_ROWS) ring[(s % 3) * STAGE_ROWS + tid] = row;
+  };
+  // piece p of stage s: panel (p & 1 ? B : A) row wave + 4*(p >> 1); diagonal tiles have no
+  // B panel (pieces 0..3 = A rows wave, wave+4, wave+8, wave+12)
+  // all LDS-DMA pieces of stage s: panel A (and B off the diagonal) rows wave + 4j.  The
+  // four row numbers are read from the ring first (one LDS round trip), are the same in
+  // every lane and live in SGPRs; then the loads issue back to back.
+  auto issue_panels = [&](int s) {
+    int64_t row[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row[j] = ring[(s % 3) * STAGE_ROWS + wave + 4 * j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row[j] = uni64(row[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lrow = wave + 4 * j;
+#pragma unroll
+      for (int region = 0; region < 2; ++region) {
+        if (region == 1 && diag) continue;
+        const int col = (region ? colB0 : colA0) + dcol;
+        const T *src = (row[j] >= 0 && col < g.K) ? a.X + row[j] * (int64_t)g.K + col
+                                                  : reinterpret_cast<const T *>(g_zero_line);
+        char *dst = smem_raw + ((size_t)((s & 1) * BUF_ELEMS + region * PANEL_ELEMS + lrow * PITCH)) * sizeof(T);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+      }
+    }
+  };
+  auto issue_small = [&](int s) {   // Y tile elements and weights, through registers
+    if (diag) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t row = ring[(s % 3) * STAGE_ROWS + y_row + 8 * j];
+        T v = 0;
+        if (row >= 0 && y_col < g.M) v = a.Y[row * (int64_t)g.M + y_col];
+        ry[j] = v;
+      }
+    }
+    if (tid < STAGE_ROWS) {
+      const int64_t row = ring[(s % 3) * STAGE_ROWS + tid];
+      T v = 0;
+      if (row >= 0) v = WEIGHTED ? a.w[row] : (T)1;
+      rw = v;
+    }
+  };
+  auto write_small = [&](int buf) {
+    T *base = smem + buf * BUF_ELEMS;
+    if (diag) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) base[PANEL_ELEMS + (y_row + 8 * j) * YPITCH + y_m] = ry[j];
+    }
+    if (tid < STAGE_ROWS) base[2 * PANEL_ELEMS + tid] = rw;
+  };
+
+  acc_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (acc_t){0, 0, 0, 0};
+  double st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};
+
+  const int lk = lane >> 4, lc = lane & 15;
+  const int a_col = h_wave ? 0 : 64 * wr;
+  const int b_col = h_wave ? 0 : 64 * wc;
+  const int a_off = a_col + lc;
+  const int b_off = h_wave ? PANEL_ELEMS + lc : (diag ? 0 : PANEL_ELEMS) + b_col + lc;
+
+  if (nstages > 0) {
+    ring_store(0, ring_load(0));
+    ring_store(1, ring_load(1));
+    ring_store(2, ring_load(2));
+    __syncthreads();
+    issue_small(0);
+    issue_panels(0);
+    write_small(0);
+    __syncthreads();
+  }
+
+#ifdef CVM_STAMPS
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
+#endif
+  // HW: this wave is the H wave (8x2 tiles against the Y tile) instead of a G wave (4x4);
+  // MFM: it issues MFMAs at all; ROLE: column sums (0 none, 1 X, 2 Y); LD: next stage exists
+  auto stage = [&](auto HWc, auto MFMc, auto ROLEc, auto LDc, int s) {
+    constexpr bool HW = decltype(HWc)::value;
+    constexpr bool MFM = decltype(MFMc)::value;
+    constexpr int ROLE = decltype(ROLEc)::value;
+    constexpr bool LD = decltype(LDc)::value;
+    constexpr int NA = HW ? 8 : 4, NB = HW ? 2 : 4;
+#ifdef CVM_STAMPS
+    STAMP(t0);
+#endif
+    if (LD) {
+      // every LDS-DMA of the next stage is issued before this stage's first MFMA: the
+      // data has the whole stage (several microseconds) to land before the barrier
+      issue_small(s + 1);
+      issue_panels(s + 1);
+    }
+    const int64_t ring_next = ring_load(s + 3);
+    const T *buf = smem + (s & 1) * BUF_ELEMS;
+    const T *wb = buf + 2 * PANEL_ELEMS;
+#ifdef CVM_STAMPS
+    STAMP(t1);
+#endif
+    if (MFM || ROLE != 0) {
+      T af[2][NA], bf[2][NB], yf[2][2], wv[2];
+      auto read_frags = [&](int ks, int slot) {
+        const int r = 4 * ks + lk;
+        if (MFM || ROLE == 1) {
+#pragma unroll
+          for (int m = 0; m < NA; ++m) af[slot][m] = buf[a_off + r * PITCH + 16 * m];
+        }
+        if (MFM) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n) bf[slot][n] = buf[b_off + r * (HW ? YPITCH : PITCH) + 16 * n];
+        }
+        if (ROLE == 2) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) yf[slot][n] = buf[PANEL_ELEMS + r * YPITCH + 16 * n + lc];
+        }
+        wv[slot] = wb[r];
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        if (ks < 3) read_frags(ks + 1, c ^ 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep exactly one k-step of fragments in flight
+        // column sums: see wgram_kernel (same row classes, same combine order)
+        if (ROLE == 1) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const T pv = WEIGHTED ? (T)(af[c][m] * wv[c]) : af[c][m];
+            st_s[m] += pv; st_q[m] += (T)(pv * af[c][m]);
+          }
+        } else if (ROLE == 2) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const T yv = yf[c][n];
+            const T pv = WEIGHTED ? (T)(yv * wv[c]) : yv;
+            st_s[n] += pv; st_q[n] += (T)(pv * yv);
+          }
+          st_s[2] += wv[c];
+          st_s[3] += (wv[c] != (T)0) ? 1.0 : 0.0;
+          st_q[3] += (wv[c] < (T)0) ? 1.0 : 0.0;
+        }
+        if (MFM) {
+          if (WEIGHTED) {
+#pragma unroll
+            for (int m = 0; m < NA; ++m) af[c][m] *= wv[c];
+          }
+#pragma unroll
+          for (int m = 0; m < NA; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef CVM_STAMPS
+    STAMP(t2);
+#endif
+    if (LD) write_small((s + 1) & 1);
+    ring_store(s + 3, ring_next);
+    __syncthreads();
+#ifdef CVM_STAMPS
+    STAMP(t3);
+    t_a += t1 - t0; t_b += t2 - t1; t_c += t3 - t2;
+#endif
+  };
+  auto run = [&](auto HWc, auto MFMc, auto ROLEc) {
+#pragma unroll 1
+    for (int s = 0; s + 1 < nstages; ++s) stage(HWc, MFMc, ROLEc, std::true_type{}, s);
+    if (nstages > 0) stage(HWc, MFMc, ROLEc, std::false_type{}, nstages - 1);
+  };
+  run(std::bool_constant<HWR>{}, std::bool_constant<MFMR>{}, std::integral_constant<int, ROLER>{});
+#ifdef CVM_STAMPS
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+    o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = (unsigned long long)nstages;
+  }
+#endif
+
+  auto comb = [&](double v) -> double {
+    const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
+    return ((v + v1) + v2) + v3;
+  };
+  if (stat_role == 1) {
+    double *st = unit_stats<T>(a.ws, g, u);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double sv = comb(st_s[m]), qv = comb(st_q[m]);
+      if (lk == 0) {
+        st[ti * TILE + a_col + 16 * m + lc] = sv;
+        st[g.Kp + ti * TILE + a_col + 16 * m + lc] = qv;
+      }
+    }
+  } else if (stat_role == 2) {
+    double *st = unit_stats<T>(a.ws, g, u);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const double sv = comb(st_s[n]), qv = comb(st_q[n]);
+      if (lk == 0) {
+        st[2 * g.Kp + yc * YT + 16 * n + lc] = sv;
+        st[2 * g.Kp + g.Mp + yc * YT + 16 * n + lc] = qv;
+      }
+    }
+    const double swv = comb(st_s[2]), nzv = comb(st_s[3]), ngv = comb(st_q[3]);
+    if (yc == 0 && lane == 0) {
+      st[2 * g.Kp + 2 * g.Mp + 0] = swv;
+      st[2 * g.Kp + 2 * g.Mp + 1] = nzv;
+      st[2 * g.Kp + 2 * g.Mp + 2] = ngv;
+    }
+  }
+  if (h_wave) {
+    if (g.M > 0) {
+      T *hp = unit_h<T>(a.ws, g, u) + (size_t)ti * TILE * g.Mp + yc * YT;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            hp[(size_t)(16 * m + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] = acc[m * 2 + n][r];
+    }
+  } else if (do_g) {
+    T *tp = unit_tiles<T>(a.ws, g, u) + (size_t)it * TILE * TILE;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc] = acc[m * 4 + n][r];
+  }
+}
+
+template <bool WEIGHTED, bool GATHER>
+__global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> a) {
+  // role of this wave (same decode as in the body)
+  const Geom &g = a.g;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long b = blockIdx.x;
+  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
+  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+  const int it = (int)(item % g.nT);
+  int ti, tj, yc;
+  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
+  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
+  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  const bool diag = (ti == tj);
+  const bool do_g = !g.diag_only && yc == 0;
+  const int role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
+  if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0>(a);
+  else if (role == 1) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 1>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 1>(a); }
+  else if (role == 2) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 2>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 2>(a); }
+  else { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 0>(a); }
+}
+
+// ----------------------------------------------------------------------------------
 // finalize kernels
 // ----------------------------------------------------------------------------------
 struct FinArgs {
@@ -746,8 +1104,8 @@ int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g, int TARGET_WG)
 
 // which Gram kernel variant a problem gets (pointers from torch are 256-byte aligned; a
 // misaligned X falls back to the register path at launch, only the split heuristic differs)
-int target_wg(int K, int esize) {
-  return (esize == 8 && ((size_t)K * esize) % 16 == 0) ? TARGET_WG_2 : TARGET_WG_1;
+int target_wg(int K, int M, int esize) {
+  return (esize == 8 && ((size_t)K * esize) % 16 == 0 && M % 2 == 0) ? TARGET_WG_2 : TARGET_WG_1;
 }
 
 int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsigned flags,
@@ -755,7 +1113,7 @@ int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsign
   const int esize = dtype == CVM_F64 ? 8 : 4;
   const int diag_only = fold_mode && !(flags & CVM_RET_XTX);
   p.g = make_geom(K, M, esize, diag_only);
-  p.splits = choose_splits(n_folds, max_rows, p.g, target_wg(K, esize));
+  p.splits = choose_splits(n_folds, max_rows, p.g, target_wg(K, M, esize));
   p.fstat_bytes_per_fold = fold_mode ? align_up(fstat_len(K, M) * 8, 256) : 0;
   for (;;) {
     const size_t per_fold = (size_t)p.splits * p.g.unit_bytes + p.fstat_bytes_per_fold;
@@ -795,11 +1153,23 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     HIP_OK(hipEventRecord(tl->a, st));
   }
   constexpr bool CAN_DMA = sizeof(T) == 8;
-  const bool dma = CAN_DMA && aligned && !(dbg_env & 16);
-  if (dma) {
+  const bool fast = CAN_DMA && aligned && (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) && !(dbg_env & 16);
+  if (fast) {
     if constexpr (CAN_DMA) {
-      if (weighted) { if (gather) CVM_LAUNCH(true, true, true, true); else CVM_LAUNCH(true, false, true, true); }
-      else { if (gather) CVM_LAUNCH(false, true, true, true); else CVM_LAUNCH(false, false, true, true); }
+      const dim3 block4(NT4);
+#define CVM_LAUNCH4(W, GA)                                                                  \
+  do {                                                                                      \
+    static unsigned long long attr_done = 0;                                                \
+    if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<W, GA>,                        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+      attr_done |= 1ull << (dev & 63);                                                      \
+    }                                                                                       \
+    hipLaunchKernelGGL((wgram4_kernel<W, GA>), grid, block4, lds, st, args);                \
+  } while (0)
+      if (weighted) { if (gather) CVM_LAUNCH4(true, true); else CVM_LAUNCH4(true, false); }
+      else { if (gather) CVM_LAUNCH4(false, true); else CVM_LAUNCH4(false, false); }
+#undef CVM_LAUNCH4
     }
   } else if (weighted) {
     if (gather) { if (aligned) CVM_LAUNCH(true, true, true, false); else CVM_LAUNCH(true, true, false, false); }
@@ -909,7 +1279,7 @@ size_t cvm_gstats_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 2; 
 
 size_t cvm_fit_workspace_bytes(int64_t N, int K, int M, int dtype) {
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
-  return (size_t)choose_splits(1, N, g, target_wg(K, dtype == CVM_F64 ? 8 : 4)) * g.unit_bytes;
+  return (size_t)choose_splits(1, N, g, target_wg(K, M, dtype == CVM_F64 ? 8 : 4)) * g.unit_bytes;
 }
 
 int cvm_gram_fit(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
@@ -931,7 +1301,7 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
                                 int dtype, unsigned flags) {
   (void)n_idx;
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, !(flags & CVM_RET_XTX));
-  const int splits = choose_splits(n_folds, max_fold_rows, g, target_wg(K, dtype == CVM_F64 ? 8 : 4));
+  const int splits = choose_splits(n_folds, max_fold_rows, g, target_wg(K, M, dtype == CVM_F64 ? 8 : 4));
   const size_t per_fold = (size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256);
   size_t want = per_fold * (size_t)(n_folds > 0 ? n_folds : 1);
   const size_t cap = (size_t)8 << 30;   // beyond 8 GiB walk the folds in batches

@@ -14,7 +14,7 @@ lib = L.load(); print(lib.cvm_version().decode())
 buf = (C.c_ulonglong * (1024 * 8 * 4))()
 lib.cvm_debug_stamps(buf)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8, 4).astype(np.float64)
-a = a[a[:, 0, 3] > 0]
+a = a[a[:, 0, 3] > 0]; nw = 4 if a[:, 4:, 3].sum() == 0 else 8; a = a[:, :nw]
 st = a[:, :, 3]
 print("workgroups", a.shape[0], "stages/WG", st.mean())
 for name, i in (("issue(top)", 0), ("compute", 1), ("tail(write+barrier)", 2)):
