@@ -37,7 +37,7 @@ constexpr int NTHREADS = 512; // 8 waves, two per SIMD
 constexpr int PANEL_ELEMS = STAGE_ROWS * PITCH;             // 2304
 constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + STAGE_ROWS;     // A panel, B panel | Y tile, w
 constexpr int TARGET_WG_1 = 256;  // resident workgroups, register-staged kernel: one per CU
-constexpr int TARGET_WG_2 = 512;  // DMA kernel (<= 128 VGPRs): two per CU
+constexpr int TARGET_WG_2 = 256;  // DMA kernel (<= 128 VGPRs): two per CU
 // LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
 // f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
 // the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
 // X panels arrive by LDS-DMA (global_load_lds_dwordx4, one 1 KiB panel row per wave
 // instruction, gathered by row number), issued two per k-step behind that k-step's MFMAs.
 // ----------------------------------------------------------------------------------
-constexpr int NT4 = 256;
+constexpr int NT4 = 512;   // waves 0-3 compute (one per SIMD), waves 4-7 only load
 // The body is instantiated once per wave role and kept out of line: inlined together, the
 // register allocator has to give all roles one common assignment of the 128 accumulator
 // registers and spills hundreds of values; as separate functions every role fits.
@@ -581,7 +581,9 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   const Geom &g = a.g;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all & 3;            // compute wave id, or the loader's row slot
+  const int ltid = tid & 255;               // thread id inside the loader / compute group
 
   const long b = blockIdx.x;
   const long item = (b & 7) * a.items_per_xcd + (b >> 3);
@@ -612,20 +614,20 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 
   const int colA0 = ti * TILE, colB0 = tj * TILE;
   const int dcol = lane * 2;                         // this lane's 2 columns of a panel row
-  const int y_row = tid >> 5, y_m = tid & 31;        // Y tile: rows y_row, y_row + 8
+  const int y_row = ltid >> 5, y_m = ltid & 31;      // Y tile: rows y_row, y_row + 8
   const int y_col = yc * YT + y_m;
   T ry[2] = {0, 0}, rw = 0;
 
   auto ring_load = [&](int s) -> int64_t {
     int64_t row = -1;
-    if (tid < STAGE_ROWS) {
-      int64_t r = r0 + (int64_t)s * STAGE_ROWS + tid;
+    if (ltid < STAGE_ROWS) {
+      int64_t r = r0 + (int64_t)s * STAGE_ROWS + ltid;
       if (r < r1) row = GATHER ? a.idx[seg_begin + r] : seg_begin + r;
     }
     return row;
   };
   auto ring_store = [&](int s, int64_t row) {
-    if (tid < STAGE_ROWS) ring[(s % 3) * STAGE_ROWS + tid] = row;
+    if (ltid < STAGE_ROWS) ring[(s % 3) * STAGE_ROWS + ltid] = row;
   };
   // piece p of stage s: panel (p & 1 ? B : A) row wave + 4*(p >> 1); diagonal tiles have no
   // B panel (pieces 0..3 = A rows wave, wave+4, wave+8, wave+12)
@@ -663,8 +665,8 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
         ry[j] = v;
       }
     }
-    if (tid < STAGE_ROWS) {
-      const int64_t row = ring[(s % 3) * STAGE_ROWS + tid];
+    if (ltid < STAGE_ROWS) {
+      const int64_t row = ring[(s % 3) * STAGE_ROWS + ltid];
       T v = 0;
       if (row >= 0) v = WEIGHTED ? a.w[row] : (T)1;
       rw = v;
@@ -676,8 +678,34 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) base[PANEL_ELEMS + (y_row + 8 * j) * YPITCH + y_m] = ry[j];
     }
-    if (tid < STAGE_ROWS) base[2 * PANEL_ELEMS + tid] = rw;
+    if (ltid < STAGE_ROWS) base[2 * PANEL_ELEMS + ltid] = rw;
   };
+
+  if (ROLER == 3) {
+    // ---- loader wave: everything that touches global memory -----------------------------
+    if (nstages > 0) {
+      ring_store(0, ring_load(0));
+      ring_store(1, ring_load(1));
+      ring_store(2, ring_load(2));
+    }
+    __syncthreads();
+    if (nstages > 0) {
+      issue_small(0);
+      issue_panels(0);
+      write_small(0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < nstages; ++s) {
+      const bool more = s + 1 < nstages;
+      if (more) { issue_small(s + 1); issue_panels(s + 1); }
+      const int64_t ring_next = ring_load(s + 3);
+      if (more) write_small((s + 1) & 1);
+      ring_store(s + 3, ring_next);
+      __syncthreads();
+    }
+    return;
+  }
 
   acc_t acc[16];
 #pragma unroll
@@ -690,16 +718,8 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   const int a_off = a_col + lc;
   const int b_off = h_wave ? PANEL_ELEMS + lc : (diag ? 0 : PANEL_ELEMS) + b_col + lc;
 
-  if (nstages > 0) {
-    ring_store(0, ring_load(0));
-    ring_store(1, ring_load(1));
-    ring_store(2, ring_load(2));
-    __syncthreads();
-    issue_small(0);
-    issue_panels(0);
-    write_small(0);
-    __syncthreads();
-  }
+  __syncthreads();   // the loader waves fill the ring and stage 0 (two barriers)
+  __syncthreads();
 
 #ifdef CVM_STAMPS
   unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
@@ -715,13 +735,6 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #ifdef CVM_STAMPS
     STAMP(t0);
 #endif
-    if (LD) {
-      // every LDS-DMA of the next stage is issued before this stage's first MFMA: the
-      // data has the whole stage (several microseconds) to land before the barrier
-      issue_small(s + 1);
-      issue_panels(s + 1);
-    }
-    const int64_t ring_next = ring_load(s + 3);
     const T *buf = smem + (s & 1) * BUF_ELEMS;
     const T *wb = buf + 2 * PANEL_ELEMS;
 #ifdef CVM_STAMPS
@@ -786,8 +799,6 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #ifdef CVM_STAMPS
     STAMP(t2);
 #endif
-    if (LD) write_small((s + 1) & 1);
-    ring_store(s + 3, ring_next);
     __syncthreads();
 #ifdef CVM_STAMPS
     STAMP(t3);
@@ -865,10 +876,12 @@ template <bool WEIGHTED, bool GATHER>
 __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> a) {
   // role of this wave (same decode as in the body)
   const Geom &g = a.g;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave_all & 3;
   const long b = blockIdx.x;
   const long item = (b & 7) * a.items_per_xcd + (b >> 3);
   if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3>(a); return; }
   const int it = (int)(item % g.nT);
   int ti, tj, yc;
   if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
