@@ -189,7 +189,8 @@ __device__ __forceinline__ void split_range(int64_t n, int splits, int sp, int64
 // No staging registers and no ds_write pass, and the kernel fits 128 VGPRs so that TWO
 // workgroups share a CU: while one waits at its stage barrier the other keeps the MFMA
 // pipe busy.
-__device__ double g_zero_line[32];   // zero-initialised at code-object load
+__device__ double g_zero_line[128];  // zero-initialised at code-object load
+__device__ double g_one_line[2] = {1.0, 1.0};
 #ifdef CVM_STAMPS
 // diagnostic build only: per (workgroup, wave) cycle sums of the three phases of a stage
 __device__ unsigned long long g_stamps[1024 * 8 * 4];
@@ -554,36 +555,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
 // ----------------------------------------------------------------------------------
 // wgram4_kernel: the fast path (float64, 16-byte aligned rows, even M).
 //
-// Same work decomposition, LDS image and partial layout as wgram_kernel, but a workgroup is
-// FOUR waves (one per SIMD) and TWO workgroups share a CU: the two waves of a SIMD belong to
-// different workgroups with independent barriers, so one keeps the MFMA pipe busy while the
-// other sits at its stage barrier or issues loads.  Wave (wr,wc) owns the 64x64 block
-// (wr,wc) of the tile: 4x4 MFMA tiles, 16 accumulators (128 VGPRs), 16 MFMAs per 8 LDS
-// fragment reads.  On a diagonal tile the strictly-lower block (1,0) is not computed and
-// its wave (the "H wave") computes panel_i^T W Y[:, 32c..32c+32) (8x2 MFMA tiles) plus the
-// X column sums of the whole panel; wave 0 of panel 0 adds the Y column sums, sw and nz.
-// X panels arrive by LDS-DMA (global_load_lds_dwordx4, one 1 KiB panel row per wave
-// instruction, gathered by row number), issued two per k-step behind that k-step's MFMAs.
+// Same work decomposition, LDS stage image and partial layout as wgram_kernel, but the
+// eight waves of a workgroup (one workgroup per CU) are specialised:
+//   waves 0-3  COMPUTE, one per SIMD.  Wave (wr,wc) owns the 64x64 block (wr,wc) of the
+//              128x128 tile: 4x4 MFMA tiles, 16 accumulators (128 VGPRs), 16 MFMAs per 8
+//              LDS fragment reads.  They never touch global memory inside the loop, so no
+//              vector-memory instruction ever blocks their issue (a 1 KiB load costs its
+//              wave 200-450 cycles of issue on a busy CU: tools/dma_issue.hip).
+//              On a diagonal tile the strictly-lower block (1,0) is not computed; its wave
+//              (the "H wave") computes panel_i^T W Y[:, 32c..32c+32) (8x2 MFMA tiles).
+//              Waves 0 and 3 also sum the X columns of their A fragments, wave 1 (panel 0)
+//              the Y columns, sw and nz -- on the VALU, in the shadow of their MFMAs.
+//   waves 4-6  DMA LOADERS.  X panel rows go global -> LDS by LDS-DMA
+//              (global_load_lds_dwordx4: one wave instruction = one 1 KiB panel row,
+//              gathered by row number; rows past the end / columns past K read a zero
+//              line).  They run THREE stages ahead of the compute waves through a ring of
+//              four LDS stage buffers, with a hand-counted s_waitcnt vmcnt(2 stages).
+//   wave 7     SMALL LOADER: row numbers (ring), weights and the Y tile, through registers,
+//              two stages ahead.
+// One s_barrier per 16-row stage joins all eight waves.
 // ----------------------------------------------------------------------------------
-constexpr int NT4 = 512;   // waves 0-3 compute (one per SIMD), waves 4-7 only load
+constexpr int NT4 = 512;
+constexpr int NBUF4 = 4;        // LDS stage buffers
+constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;
+
 // The body is instantiated once per wave role and kept out of line: inlined together, the
 // register allocator has to give all roles one common assignment of the 128 accumulator
 // registers and spills hundreds of values; as separate functions every role fits.
+//   ROLER 0/1/2: compute wave without sums / with X column sums / with Y column sums
+//   ROLER 3: DMA loader, ROLER 4: small loader
 template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER>
 __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   typedef double T;
-  const WgramArgs<double> a = scalarize(a_ref);
   typedef MF<double>::acc_t acc_t;
+  const WgramArgs<double> a = scalarize(a_ref);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
-  int64_t *ring = reinterpret_cast<int64_t *>(smem_raw + 2 * BUF_ELEMS * sizeof(T));
-
   const Geom &g = a.g;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = wave_all & 3;            // compute wave id, or the loader's row slot
-  const int ltid = tid & 255;               // thread id inside the loader / compute group
+  const int wave = wave_all & 3;
 
   const long b = blockIdx.x;
   const long item = (b & 7) * a.items_per_xcd + (b >> 3);
@@ -600,113 +612,163 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   const int wr = wave >> 1, wc = wave & 1;
   const bool h_wave = diag && wave == 2;
   const bool do_g = !g.diag_only && yc == 0;
-  // column-sum roles on a diagonal tile: waves 0 and 3 (blocks (0,0), (1,1)) sum the X
-  // columns of their own A fragments (64 columns each), wave 1 sums the Y columns, sw and
-  // nz (panel 0 only); the H wave has no spare registers for sums
-  const int stat_role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
 
   int64_t seg_begin, seg_rows;
   if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
   else { seg_begin = 0; seg_rows = a.N; }
   int64_t r0, r1;
   split_range(seg_rows, a.splits, sp, r0, r1);
-  const int nstages = (int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS);
-
-  const int colA0 = ti * TILE, colB0 = tj * TILE;
-  const int dcol = lane * 2;                         // this lane's 2 columns of a panel row
-  const int y_row = ltid >> 5, y_m = ltid & 31;      // Y tile: rows y_row, y_row + 8
-  const int y_col = yc * YT + y_m;
-  T ry[2] = {0, 0}, rw = 0;
-
-  auto ring_load = [&](int s) -> int64_t {
-    int64_t row = -1;
-    if (ltid < STAGE_ROWS) {
-      int64_t r = r0 + (int64_t)s * STAGE_ROWS + ltid;
-      if (r < r1) row = GATHER ? a.idx[seg_begin + r] : seg_begin + r;
-    }
-    return row;
-  };
-  auto ring_store = [&](int s, int64_t row) {
-    if (ltid < STAGE_ROWS) ring[(s % 3) * STAGE_ROWS + ltid] = row;
-  };
-  // piece p of stage s: panel (p & 1 ? B : A) row wave + 4*(p >> 1); diagonal tiles have no
-  // B panel (pieces 0..3 = A rows wave, wave+4, wave+8, wave+12)
-  // all LDS-DMA pieces of stage s: panel A (and B off the diagonal) rows wave + 4j.  The
-  // four row numbers are read from the ring first (one LDS round trip), are the same in
-  // every lane and live in SGPRs; then the loads issue back to back.
-  auto issue_panels = [&](int s) {
-    int64_t row[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) row[j] = ring[(s % 3) * STAGE_ROWS + wave + 4 * j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) row[j] = uni64(row[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int lrow = wave + 4 * j;
-#pragma unroll
-      for (int region = 0; region < 2; ++region) {
-        if (region == 1 && diag) continue;
-        const int col = (region ? colB0 : colA0) + dcol;
-        const T *src = (row[j] >= 0 && col < g.K) ? a.X + row[j] * (int64_t)g.K + col
-                                                  : reinterpret_cast<const T *>(g_zero_line);
-        char *dst = smem_raw + ((size_t)((s & 1) * BUF_ELEMS + region * PANEL_ELEMS + lrow * PITCH)) * sizeof(T);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-      }
-    }
-  };
-  auto issue_small = [&](int s) {   // Y tile elements and weights, through registers
-    if (diag) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t row = ring[(s % 3) * STAGE_ROWS + y_row + 8 * j];
-        T v = 0;
-        if (row >= 0 && y_col < g.M) v = a.Y[row * (int64_t)g.M + y_col];
-        ry[j] = v;
-      }
-    }
-    if (ltid < STAGE_ROWS) {
-      const int64_t row = ring[(s % 3) * STAGE_ROWS + ltid];
-      T v = 0;
-      if (row >= 0) v = WEIGHTED ? a.w[row] : (T)1;
-      rw = v;
-    }
-  };
-  auto write_small = [&](int buf) {
-    T *base = smem + buf * BUF_ELEMS;
-    if (diag) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) base[PANEL_ELEMS + (y_row + 8 * j) * YPITCH + y_m] = ry[j];
-    }
-    if (ltid < STAGE_ROWS) base[2 * PANEL_ELEMS + ltid] = rw;
-  };
+  // wave-uniform by construction; the 64-bit division above runs on the VALU, so say so
+  r0 = uni64(r0); r1 = uni64(r1); seg_begin = uni64(seg_begin);
+  const int nstages = uni((int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS));
+  const int colA0 = uni(ti * TILE), colB0 = uni(tj * TILE);
 
   if (ROLER == 3) {
-    // ---- loader wave: everything that touches global memory -----------------------------
-    if (nstages > 0) {
-      ring_store(0, ring_load(0));
-      ring_store(1, ring_load(1));
-      ring_store(2, ring_load(2));
+    // ---- loader waves 4..7 ----------------------------------------------------------------
+    // Loader d owns stage rows d, d+4, d+8, d+12 and issues, per row, three LDS-DMA
+    // instructions: the X panel A row (1 KiB), the X panel B row (off-diagonal tile) or the
+    // Y tile row (diagonal tile, 16 lanes), and the row's weight (2 lanes x 4 B): exactly 12
+    // per stage, whatever the tile.  Everything per piece is SCALAR (row number by s_load,
+    // row base by SALU, LDS address in M0) plus a loop-invariant per-lane VGPR offset: while
+    // the compute wave of the same SIMD streams f64 MFMAs a VALU instruction of another
+    // wave waits up to a whole MFMA (64 cycles) for an issue slot (measured: 580 cycles per
+    // piece with ~8 VALU instructions in it, 180 without the MFMAs running).  The loads are
+    // inline asm (saddr form) so that no vector instruction and no compiler-chosen wait
+    // enters the loop and the vmcnt count below is exact.
+    // Columns past K (or M) are clamped to the last valid pair: they only feed output
+    // columns >= K that nothing reads.  Rows past the end read a zero line.
+    const int d = wave_all - 4;
+    const char *zero_src = reinterpret_cast<const char *>(unip(g_zero_line));
+    const char *one_src = reinterpret_cast<const char *>(unip(g_one_line));
+    int oa = 2 * lane, ob = 2 * lane, oy = 2 * (lane & 15);
+    if (colA0 + oa > g.K - 2) oa = g.K - 2 - colA0;
+    if (colB0 + ob > g.K - 2) ob = g.K - 2 - colB0;
+    if (oa < 0) oa = 0;
+    if (ob < 0) ob = 0;
+    const int ycol0 = yc * YT;
+    if (g.M > 0) { if (ycol0 + oy > g.M - 2) oy = g.M - 2 - ycol0; if (oy < 0) oy = 0; } else oy = 0;
+    const unsigned va = 8u * (unsigned)oa, vb = 8u * (unsigned)ob, vy = 8u * (unsigned)oy, vw = 4u * (unsigned)lane;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem_raw);
+    auto dma16_all = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma16_lo16 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep; unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma4_lo2 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep; unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dword %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    // wave-uniform row numbers of stage t, row slots d + 4j.  Gathered ones come by four
+    // scalar loads in ONE asm statement that also waits for them (an asm load's destination
+    // counts as written when the statement ends; a later, separate wait would let the
+    // compiler copy the registers before the data has landed).
+    // (32-bit row positions: a 64-bit compare would be a VALU instruction, and a VALU
+    //  instruction of this wave waits ~700 cycles for a slot between the other wave's MFMAs:
+    //  tools/dma_vs_mfma.hip)
+    const int r0i = uni((int)r0), r1i = uni((int)r1);
+    auto row_numbers = [&](int t, int64_t (&rn)[4], bool (&ok)[4]) {
+      int rr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rr[j] = r0i + t * STAGE_ROWS + d + 4 * j;
+        ok[j] = rr[j] < r1i;
+      }
+      if (!GATHER) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rn[j] = seg_begin + rr[j];
+        return;
+      }
+      const int64_t *p0 = a.idx + seg_begin + (ok[0] ? rr[0] : 0);
+      const int64_t *p1 = a.idx + seg_begin + (ok[1] ? rr[1] : 0);
+      const int64_t *p2 = a.idx + seg_begin + (ok[2] ? rr[2] : 0);
+      const int64_t *p3 = a.idx + seg_begin + (ok[3] ? rr[3] : 0);
+      int64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+      if (r1i > 0) {   // (segment not empty: the clamped addresses are valid)
+        asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\t"
+                     "s_load_dwordx2 %2, %6, 0x0\n\ts_load_dwordx2 %3, %7, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                     : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
+      }
+      rn[0] = v0; rn[1] = v1; rn[2] = v2; rn[3] = v3;
+    };
+    auto issue_stage = [&](int t, const int64_t (&rn)[4], const bool (&ok)[4]) {
+      const unsigned bufb = lds0 + (unsigned)((t % NBUF4) * BUF_ELEMS) * 8u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lrow = d + 4 * j;
+        const bool valid = ok[j];
+        const char *xrow = reinterpret_cast<const char *>(a.X + rn[j] * (int64_t)g.K);
+        dma16_all(valid ? xrow + 8 * (int64_t)colA0 : zero_src, va, bufb + (unsigned)(lrow * PITCH) * 8u);
+        if (!diag) {
+          dma16_all(valid ? xrow + 8 * (int64_t)colB0 : zero_src, vb,
+                    bufb + (unsigned)(PANEL_ELEMS + lrow * PITCH) * 8u);
+        } else {
+          const char *yrow = (valid && g.M > 0)
+              ? reinterpret_cast<const char *>(a.Y + rn[j] * (int64_t)g.M + ycol0) : zero_src;
+          dma16_lo16(yrow, vy, bufb + (unsigned)(PANEL_ELEMS + lrow * YPITCH) * 8u);
+        }
+        const char *wsrc = valid ? (WEIGHTED ? reinterpret_cast<const char *>(a.w + rn[j]) : one_src) : zero_src;
+        dma4_lo2(wsrc, vw, bufb + (unsigned)(2 * PANEL_ELEMS + lrow) * 8u);
+      }
+    };
+    // 12 LDS-DMA instructions per stage; two stages may stay in flight across a barrier
+    auto wait_two_stages_in_flight = [&]() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); };
+    int64_t rn[4];
+    bool ok[4];
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      row_numbers(t, rn, ok);
+      issue_stage(t, rn, ok);
     }
-    __syncthreads();
-    if (nstages > 0) {
-      issue_small(0);
-      issue_panels(0);
-      write_small(0);
-    }
-    __syncthreads();
+    wait_two_stages_in_flight();                      // stage 0 has landed
+    __builtin_amdgcn_s_barrier();                     // B_a (two barriers in every role's prologue)
+    __builtin_amdgcn_s_barrier();                     // B_-1
+#ifdef CVM_STAMPS
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
+#endif
 #pragma unroll 1
     for (int s = 0; s < nstages; ++s) {
-      const bool more = s + 1 < nstages;
-      if (more) { issue_small(s + 1); issue_panels(s + 1); }
-      const int64_t ring_next = ring_load(s + 3);
-      if (more) write_small((s + 1) & 1);
-      ring_store(s + 3, ring_next);
-      __syncthreads();
+#ifdef CVM_STAMPS
+      STAMP(t0);
+#endif
+      row_numbers(s + 3, rn, ok);
+      issue_stage(s + 3, rn, ok);                     // buffer (s+3)%4 was last read in stage s-1
+#ifdef CVM_STAMPS
+      STAMP(t1);
+#endif
+      wait_two_stages_in_flight();                    // stage s+1 has landed
+#ifdef CVM_STAMPS
+      STAMP(t2);
+#endif
+      __builtin_amdgcn_s_barrier();                   // B_s
+#ifdef CVM_STAMPS
+      STAMP(t3);
+      t_a += t1 - t0; t_b += t2 - t1; t_c += t3 - t2;
+#endif
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing in flight at wave exit
+#ifdef CVM_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave_all) * 4;
+      o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = (unsigned long long)nstages;
+    }
+#endif
     return;
   }
 
+  // ---- compute waves ----------------------------------------------------------------------
+  const int stat_role = ROLER;
   acc_t acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = (acc_t){0, 0, 0, 0};
@@ -718,27 +780,25 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   const int a_off = a_col + lc;
   const int b_off = h_wave ? PANEL_ELEMS + lc : (diag ? 0 : PANEL_ELEMS) + b_col + lc;
 
-  __syncthreads();   // the loader waves fill the ring and stage 0 (two barriers)
-  __syncthreads();
+  __syncthreads();   // B_a
+  __syncthreads();   // B_-1: stage 0 is in buffer 0
 
 #ifdef CVM_STAMPS
   unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
 #endif
-  // HW: this wave is the H wave (8x2 tiles against the Y tile) instead of a G wave (4x4);
-  // MFM: it issues MFMAs at all; ROLE: column sums (0 none, 1 X, 2 Y); LD: next stage exists
-  auto stage = [&](auto HWc, auto MFMc, auto ROLEc, auto LDc, int s) {
-    constexpr bool HW = decltype(HWc)::value;
-    constexpr bool MFM = decltype(MFMc)::value;
-    constexpr int ROLE = decltype(ROLEc)::value;
-    constexpr bool LD = decltype(LDc)::value;
-    constexpr int NA = HW ? 8 : 4, NB = HW ? 2 : 4;
+  constexpr bool HW = HWR, MFM = MFMR;
+  constexpr int ROLE = ROLER;
+  constexpr int NA = HW ? 8 : 4, NB = HW ? 2 : 4;
+#pragma unroll 1
+  for (int s = 0; s < nstages; ++s) {
 #ifdef CVM_STAMPS
     STAMP(t0);
+    STAMP(t1);
 #endif
-    const T *buf = smem + (s & 1) * BUF_ELEMS;
+    const T *buf = smem + (s % NBUF4) * BUF_ELEMS;
     const T *wb = buf + 2 * PANEL_ELEMS;
 #ifdef CVM_STAMPS
-    STAMP(t1);
+    if (a.dbg & 2) { __syncthreads(); continue; }   // diagnostic: loaders alone
 #endif
     if (MFM || ROLE != 0) {
       T af[2][NA], bf[2][NB], yf[2][2], wv[2];
@@ -758,10 +818,17 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
         }
         wv[slot] = wb[r];
       };
+#ifdef CVM_STAMPS
+      const bool no_reads = (a.dbg & 8) && s > 0, no_mfma = a.dbg & 32;
+      if (!no_reads)
+#endif
       read_frags(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int c = ks & 1;
+#ifdef CVM_STAMPS
+        if (!no_reads)
+#endif
         if (ks < 3) read_frags(ks + 1, c ^ 1);
         __builtin_amdgcn_sched_barrier(0);   // keep exactly one k-step of fragments in flight
         // column sums: see wgram_kernel (same row classes, same combine order)
@@ -782,6 +849,9 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
           st_s[3] += (wv[c] != (T)0) ? 1.0 : 0.0;
           st_q[3] += (wv[c] < (T)0) ? 1.0 : 0.0;
         }
+#ifdef CVM_STAMPS
+        if (!no_mfma)
+#endif
         if (MFM) {
           if (WEIGHTED) {
 #pragma unroll
@@ -799,18 +869,12 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #ifdef CVM_STAMPS
     STAMP(t2);
 #endif
-    __syncthreads();
+    __syncthreads();   // B_s
 #ifdef CVM_STAMPS
     STAMP(t3);
     t_a += t1 - t0; t_b += t2 - t1; t_c += t3 - t2;
 #endif
-  };
-  auto run = [&](auto HWc, auto MFMc, auto ROLEc) {
-#pragma unroll 1
-    for (int s = 0; s + 1 < nstages; ++s) stage(HWc, MFMc, ROLEc, std::true_type{}, s);
-    if (nstages > 0) stage(HWc, MFMc, ROLEc, std::false_type{}, nstages - 1);
-  };
-  run(std::bool_constant<HWR>{}, std::bool_constant<MFMR>{}, std::integral_constant<int, ROLER>{});
+  }
 #ifdef CVM_STAMPS
   if (lane == 0 && blockIdx.x < 1024) {
     unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
@@ -1175,10 +1239,10 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     static unsigned long long attr_done = 0;                                                \
     if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
       HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<W, GA>,                        \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4_BYTES)); \
       attr_done |= 1ull << (dev & 63);                                                      \
     }                                                                                       \
-    hipLaunchKernelGGL((wgram4_kernel<W, GA>), grid, block4, lds, st, args);                \
+    hipLaunchKernelGGL((wgram4_kernel<W, GA>), grid, block4, LDS4_BYTES, st, args);         \
   } while (0)
       if (weighted) { if (gather) CVM_LAUNCH4(true, true); else CVM_LAUNCH4(true, false); }
       else { if (gather) CVM_LAUNCH4(false, true); else CVM_LAUNCH4(false, false); }

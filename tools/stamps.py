@@ -14,11 +14,12 @@ lib = L.load(); print(lib.cvm_version().decode())
 buf = (C.c_ulonglong * (1024 * 8 * 4))()
 lib.cvm_debug_stamps(buf)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8, 4).astype(np.float64)
-a = a[a[:, 0, 3] > 0]; nw = 4 if a[:, 4:, 3].sum() == 0 else 8; a = a[:, :nw]
-st = a[:, :, 3]
-print("workgroups", a.shape[0], "stages/WG", st.mean())
-for name, i in (("issue(top)", 0), ("compute", 1), ("tail(write+barrier)", 2)):
+a = a[:500]
+st = np.maximum(a[:, :, 3], 1)
+print("workgroups", a.shape[0], "stages/WG", a[:, 0, 3].mean())
+for name, i in (("phase A", 0), ("phase B", 1), ("phase C", 2)):
     per = a[:, :, i] / st
-    print(f"{name:22s} cycles/stage: mean {per.mean():8.0f}  by wave {np.round(per.mean(0))}")
+    print(f"{name:10s} cycles/stage by wave {np.round(per.mean(0))}")
 tot = (a[:, :, 0] + a[:, :, 1] + a[:, :, 2]) / st
-print("total cycles/stage", tot.mean(), " (MFMA-bound ideal 4096/CU-stage with 2 waves/SIMD)")
+print("total cycles/stage by wave", np.round(tot.mean(0)))
+print("compute waves 0-3: A=-, B=compute, C=barrier wait; DMA loaders 4-6: A=issue, B=vmcnt wait, C=barrier wait")
