@@ -36,8 +36,8 @@ constexpr int YPITCH = 48;    // LDS row pitch of the Y tile, in elements
 constexpr int NTHREADS = 512; // 8 waves, two per SIMD
 constexpr int PANEL_ELEMS = STAGE_ROWS * PITCH;             // 2304
 constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + STAGE_ROWS;     // A panel, B panel | Y tile, w
-constexpr int TARGET_WG_1 = 256;  // resident workgroups, register-staged kernel: one per CU
-constexpr int TARGET_WG_2 = 256;  // DMA kernel (<= 128 VGPRs): two per CU
+constexpr int TARGET_WG_1 = 256;  // resident workgroups (both Gram kernels: one 8-wave workgroup per CU)
+constexpr int TARGET_WG_2 = 256;
 // LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
 // f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
 // the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
@@ -182,13 +182,6 @@ __device__ __forceinline__ void split_range(int64_t n, int splits, int sp, int64
 // barrier per stage).  Row numbers come from a 3-slot LDS ring filled three stages ahead,
 // so no global load in the loop depends on another one.
 // ----------------------------------------------------------------------------------
-//
-// DMA variant (float64, 16-byte aligned rows): the X panels go global -> LDS directly
-// (global_load_lds_dwordx4: one wave instruction = one 1 KiB panel row, per-lane source
-// address = gather by row number, rows past the end / columns past K read a zero line).
-// No staging registers and no ds_write pass, and the kernel fits 128 VGPRs so that TWO
-// workgroups share a CU: while one waits at its stage barrier the other keeps the MFMA
-// pipe busy.
 __device__ double g_zero_line[128];  // zero-initialised at code-object load
 __device__ double g_one_line[2] = {1.0, 1.0};
 #ifdef CVM_STAMPS
@@ -197,9 +190,8 @@ __device__ unsigned long long g_stamps[1024 * 8 * 4];
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
-template <typename T, bool WEIGHTED, bool GATHER, bool ALIGNED, bool DMA>
+template <typename T, bool WEIGHTED, bool GATHER, bool ALIGNED>
 __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a) {
-  static_assert(!DMA || (ALIGNED && sizeof(T) == 8), "DMA path: aligned float64 only");
   typedef typename MF<T>::acc_t acc_t;
   constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte chunk
   constexpr int CPR = TILE / VEC;                   // chunks per panel row
@@ -269,17 +261,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
       if (only_j >= 0 && j != only_j) continue;
       const int64_t row = ring[(s % 3) * STAGE_ROWS + st_row0 + j * ST_ROW_STEP];
       const int col = col0 + st_col;
-      if (DMA) {
-        // st_row0 == wave for float64: the LDS row address is wave-uniform
-        const T *src = (row >= 0 && col < g.K) ? a.X + row * (int64_t)g.K + col
-                                               : reinterpret_cast<const T *>(g_zero_line);
-        char *dst_row = smem_raw + ((size_t)((s & 1) * BUF_ELEMS + region * PANEL_ELEMS +
-                                             (wave + j * ST_ROW_STEP) * PITCH)) * sizeof(T);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)src,
-            (__attribute__((address_space(3))) void *)dst_row, 16, 0, 0);
-        continue;
-      }
       vec_t v;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[e] = 0;
@@ -294,13 +275,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
       }
       dst[j] = v;
     }
-  };
-  // DMA path: the panel loads are issued one "piece" (one 1 KiB LDS-DMA per wave) per MFMA
-  // k-step, in the shadow of that k-step's MFMAs.  pieces 0,1: panel A rows wave, wave+8;
-  // pieces 2,3: panel B (off-diagonal tiles only).
-  auto issue_piece = [&](int s, int piece) {
-    if (piece < 2) load_panel(ra, colA0, s, 0, piece);
-    else if (!diag) load_panel(rb, colB0, s, 1, piece - 2);
   };
   auto issue_loads = [&](int s, bool panels) {
     if (panels) {
@@ -322,17 +296,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   };
   auto write_lds = [&](int buf) {
     T *base = smem + buf * BUF_ELEMS;
-    if (!DMA) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+      *reinterpret_cast<vec_t *>(base + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = ra[j];
+    if (!diag) {
 #pragma unroll
       for (int j = 0; j < NCH; ++j)
-        *reinterpret_cast<vec_t *>(base + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = ra[j];
-    }
-    if (!diag) {
-      if (!DMA) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-          *reinterpret_cast<vec_t *>(base + PANEL_ELEMS + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = rb[j];
-      }
+        *reinterpret_cast<vec_t *>(base + PANEL_ELEMS + (st_row0 + j * ST_ROW_STEP) * PITCH + st_col) = rb[j];
     } else {
       base[PANEL_ELEMS + y_row * YPITCH + y_m] = ry;
     }
@@ -386,7 +356,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
 #ifdef CVM_STAMPS
     STAMP(t0);
 #endif
-    if (LD) issue_loads(s + 1, !DMA);
+    if (LD) issue_loads(s + 1, true);
     const int64_t ring_next = ring_load(s + 3);
     const T *buf = smem + (s & 1) * BUF_ELEMS;
     const T *wb = buf + 2 * PANEL_ELEMS;
@@ -460,11 +430,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
             for (int n = 0; n < 2; ++n)
               acc[m * 2 + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * 2 + n]);
         }
-        if (DMA && LD) issue_piece(s + 1, ks);
       }
-    } else if (DMA && LD) {
-#pragma unroll
-      for (int piece = 0; piece < 4; ++piece) issue_piece(s + 1, piece);
     }
 #ifdef CVM_STAMPS
     STAMP(t2);
@@ -566,13 +532,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
 //              (the "H wave") computes panel_i^T W Y[:, 32c..32c+32) (8x2 MFMA tiles).
 //              Waves 0 and 3 also sum the X columns of their A fragments, wave 1 (panel 0)
 //              the Y columns, sw and nz -- on the VALU, in the shadow of their MFMAs.
-//   waves 4-6  DMA LOADERS.  X panel rows go global -> LDS by LDS-DMA
-//              (global_load_lds_dwordx4: one wave instruction = one 1 KiB panel row,
-//              gathered by row number; rows past the end / columns past K read a zero
-//              line).  They run THREE stages ahead of the compute waves through a ring of
-//              four LDS stage buffers, with a hand-counted s_waitcnt vmcnt(2 stages).
-//   wave 7     SMALL LOADER: row numbers (ring), weights and the Y tile, through registers,
-//              two stages ahead.
+//   waves 4-7  LOADERS.  Loader d owns stage rows d, d+4, d+8, d+12 and moves, per row, the
+//              X panel rows, the Y tile row (diagonal tiles) and the weight global -> LDS
+//              by LDS-DMA (global_load_lds: one wave instruction = one 1 KiB panel row,
+//              gathered by row number; rows past the end read a zero line).  They run
+//              THREE stages ahead of the compute waves through a ring of four LDS stage
+//              buffers behind a hand-counted s_waitcnt vmcnt, and contain no VALU
+//              instruction at all (see the loader section for why).
 // One s_barrier per 16-row stage joins all eight waves.
 // ----------------------------------------------------------------------------------
 constexpr int NT4 = 512;
@@ -583,7 +549,7 @@ constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;
 // register allocator has to give all roles one common assignment of the 128 accumulator
 // registers and spills hundreds of values; as separate functions every role fits.
 //   ROLER 0/1/2: compute wave without sums / with X column sums / with Y column sums
-//   ROLER 3: DMA loader, ROLER 4: small loader
+//   ROLER 3: loader wave
 template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER>
 __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   typedef double T;
@@ -721,8 +687,10 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
         dma4_lo2(wsrc, vw, bufb + (unsigned)(2 * PANEL_ELEMS + lrow) * 8u);
       }
     };
-    // 12 LDS-DMA instructions per stage; two stages may stay in flight across a barrier
-    auto wait_two_stages_in_flight = [&]() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); };
+    // 12 LDS-DMA instructions per stage; ONE stage may stay in flight across a barrier, so
+    // that at barrier B_s stage s+2 is in LDS: the compute waves may then read the first
+    // fragments of stage s+1 before they reach B_s
+    auto wait_one_stage_in_flight = [&]() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); };
     int64_t rn[4];
     bool ok[4];
     __builtin_amdgcn_s_setprio(3);
@@ -731,7 +699,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
       row_numbers(t, rn, ok);
       issue_stage(t, rn, ok);
     }
-    wait_two_stages_in_flight();                      // stage 0 has landed
+    wait_one_stage_in_flight();                       // stages 0 and 1 have landed
     __builtin_amdgcn_s_barrier();                     // B_a (two barriers in every role's prologue)
     __builtin_amdgcn_s_barrier();                     // B_-1
 #ifdef CVM_STAMPS
@@ -747,7 +715,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #ifdef CVM_STAMPS
       STAMP(t1);
 #endif
-      wait_two_stages_in_flight();                    // stage s+1 has landed
+      wait_one_stage_in_flight();                     // stage s+2 has landed
 #ifdef CVM_STAMPS
       STAMP(t2);
 #endif
@@ -789,76 +757,88 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   constexpr bool HW = HWR, MFM = MFMR;
   constexpr int ROLE = ROLER;
   constexpr int NA = HW ? 8 : 4, NB = HW ? 2 : 4;
+  // Fragments of the NEXT k-step are read while the current one computes, across the
+  // stage barrier too (the loaders guarantee stage s+1 is in LDS before stage s starts);
+  // the next k-step's weighting (and column sums) sit in the middle of the current
+  // k-step's MFMAs, so no MFMA ever waits for LDS or for a VALU result.
+  T af[2][NA], bf[2][NB], yf[2][2], wv[2], raw[4];
+  auto read_frags = [&](const T *buf, int ks, int slot) {
+    const int r = 4 * ks + lk;
+    if (MFM || ROLE == 1) {
+#pragma unroll
+      for (int m = 0; m < NA; ++m) af[slot][m] = buf[a_off + r * PITCH + 16 * m];
+    }
+    if (MFM) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) bf[slot][n] = buf[b_off + r * (HW ? YPITCH : PITCH) + 16 * n];
+    }
+    if (ROLE == 2) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) yf[slot][n] = buf[PANEL_ELEMS + r * YPITCH + 16 * n + lc];
+    }
+    wv[slot] = buf[2 * PANEL_ELEMS + r];
+  };
+  // column sums and weighting of one k-step's fragments (slot c); see wgram_kernel for the
+  // summation order (same row classes, same combine)
+  auto prepare = [&](int c) {
+    if (ROLE == 1) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        raw[m] = af[c][m];
+        const T pv = WEIGHTED ? (T)(af[c][m] * wv[c]) : af[c][m];
+        st_s[m] += pv; st_q[m] += (T)(pv * raw[m]);
+        af[c][m] = pv;
+      }
+    } else {
+      if (ROLE == 2) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const T yv = yf[c][n];
+          const T pv = WEIGHTED ? (T)(yv * wv[c]) : yv;
+          st_s[n] += pv; st_q[n] += (T)(pv * yv);
+        }
+        st_s[2] += wv[c];
+        st_s[3] += (wv[c] != (T)0) ? 1.0 : 0.0;
+        st_q[3] += (wv[c] < (T)0) ? 1.0 : 0.0;
+      }
+      if (MFM && WEIGHTED) {
+#pragma unroll
+        for (int m = 0; m < NA; ++m) af[c][m] *= wv[c];
+      }
+    }
+  };
+  if (MFM || ROLE != 0) {
+    read_frags(smem, 0, 0);
+    prepare(0);
+  }
 #pragma unroll 1
   for (int s = 0; s < nstages; ++s) {
 #ifdef CVM_STAMPS
     STAMP(t0);
     STAMP(t1);
-#endif
-    const T *buf = smem + (s % NBUF4) * BUF_ELEMS;
-    const T *wb = buf + 2 * PANEL_ELEMS;
-#ifdef CVM_STAMPS
     if (a.dbg & 2) { __syncthreads(); continue; }   // diagnostic: loaders alone
 #endif
+    const T *buf = smem + (s % NBUF4) * BUF_ELEMS;
+    const T *nbuf = smem + ((s + 1) % NBUF4) * BUF_ELEMS;
     if (MFM || ROLE != 0) {
-      T af[2][NA], bf[2][NB], yf[2][2], wv[2];
-      auto read_frags = [&](int ks, int slot) {
-        const int r = 4 * ks + lk;
-        if (MFM || ROLE == 1) {
-#pragma unroll
-          for (int m = 0; m < NA; ++m) af[slot][m] = buf[a_off + r * PITCH + 16 * m];
-        }
-        if (MFM) {
-#pragma unroll
-          for (int n = 0; n < NB; ++n) bf[slot][n] = buf[b_off + r * (HW ? YPITCH : PITCH) + 16 * n];
-        }
-        if (ROLE == 2) {
-#pragma unroll
-          for (int n = 0; n < 2; ++n) yf[slot][n] = buf[PANEL_ELEMS + r * YPITCH + 16 * n + lc];
-        }
-        wv[slot] = wb[r];
-      };
-#ifdef CVM_STAMPS
-      const bool no_reads = (a.dbg & 8) && s > 0, no_mfma = a.dbg & 32;
-      if (!no_reads)
-#endif
-      read_frags(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int c = ks & 1;
-#ifdef CVM_STAMPS
-        if (!no_reads)
-#endif
-        if (ks < 3) read_frags(ks + 1, c ^ 1);
-        __builtin_amdgcn_sched_barrier(0);   // keep exactly one k-step of fragments in flight
-        // column sums: see wgram_kernel (same row classes, same combine order)
-        if (ROLE == 1) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const T pv = WEIGHTED ? (T)(af[c][m] * wv[c]) : af[c][m];
-            st_s[m] += pv; st_q[m] += (T)(pv * af[c][m]);
-          }
-        } else if (ROLE == 2) {
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            const T yv = yf[c][n];
-            const T pv = WEIGHTED ? (T)(yv * wv[c]) : yv;
-            st_s[n] += pv; st_q[n] += (T)(pv * yv);
-          }
-          st_s[2] += wv[c];
-          st_s[3] += (wv[c] != (T)0) ? 1.0 : 0.0;
-          st_q[3] += (wv[c] < (T)0) ? 1.0 : 0.0;
-        }
-#ifdef CVM_STAMPS
-        if (!no_mfma)
-#endif
+        if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (MFM) {
-          if (WEIGHTED) {
 #pragma unroll
-            for (int m = 0; m < NA; ++m) af[c][m] *= wv[c];
-          }
+          for (int m = 0; m < NA / 2; ++m)
 #pragma unroll
-          for (int m = 0; m < NA; ++m)
+            for (int n = 0; n < NB; ++n)
+              acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prepare(c ^ 1);   // the other slot: its LDS reads were issued half a k-step ago
+        __builtin_amdgcn_sched_barrier(0);
+        if (MFM) {
+#pragma unroll
+          for (int m = NA / 2; m < NA; ++m)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
               acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
@@ -1206,21 +1186,29 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   const long per_xcd = (a.n_items + 7) / 8;
   WgramArgs<T> args = a;
   args.items_per_xcd = per_xcd;
+  // CVM_FORCE_FALLBACK=1 sends float64 problems through the general (register-staged)
+  // kernel too -- used by the tests to cover both kernels.  The ablation switches of
+  // CVM_DEBUG (wrong results by design) exist in the -DCVM_STAMPS diagnostic build only.
+  static const bool force_fallback = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
+#ifdef CVM_STAMPS
   static const int dbg_env = getenv("CVM_DEBUG") ? atoi(getenv("CVM_DEBUG")) : 0;
+#else
+  static const int dbg_env = 0;
+#endif
   args.dbg = dbg_env;
   const dim3 grid((unsigned)(per_xcd * 8)), block(NTHREADS);
   const size_t lds = 2 * BUF_ELEMS * sizeof(T) + 3 * STAGE_ROWS * sizeof(int64_t);
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
-#define CVM_LAUNCH(W, GA, AL, DM)                                                             \
+#define CVM_LAUNCH(W, GA, AL)                                                                 \
   do {                                                                                     \
     static unsigned long long attr_done = 0;   /* one bit per device */                   \
     if (!((attr_done >> (dev & 63)) & 1ull)) {                                             \
-      HIP_OK(hipFuncSetAttribute((const void *)wgram_kernel<T, W, GA, AL, DM>,             \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram_kernel<T, W, GA, AL>,                 \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
       attr_done |= 1ull << (dev & 63);                                                     \
     }                                                                                      \
-    hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL, DM>), grid, block, lds, st, args);      \
+    hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL>), grid, block, lds, st, args);          \
   } while (0)
   TimedLaunch *tl = nullptr;
   if (g_timing && g_ntimed < 8192) {
@@ -1230,7 +1218,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     HIP_OK(hipEventRecord(tl->a, st));
   }
   constexpr bool CAN_DMA = sizeof(T) == 8;
-  const bool fast = CAN_DMA && aligned && (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) && !(dbg_env & 16);
+  const bool fast = CAN_DMA && aligned && (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) &&
+                    ((uintptr_t)a.w % 8 == 0) && !force_fallback && !(dbg_env & 16);
   if (fast) {
     if constexpr (CAN_DMA) {
       const dim3 block4(NT4);
@@ -1249,11 +1238,11 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
 #undef CVM_LAUNCH4
     }
   } else if (weighted) {
-    if (gather) { if (aligned) CVM_LAUNCH(true, true, true, false); else CVM_LAUNCH(true, true, false, false); }
-    else { if (aligned) CVM_LAUNCH(true, false, true, false); else CVM_LAUNCH(true, false, false, false); }
+    if (gather) { if (aligned) CVM_LAUNCH(true, true, true); else CVM_LAUNCH(true, true, false); }
+    else { if (aligned) CVM_LAUNCH(true, false, true); else CVM_LAUNCH(true, false, false); }
   } else {
-    if (gather) { if (aligned) CVM_LAUNCH(false, true, true, false); else CVM_LAUNCH(false, true, false, false); }
-    else { if (aligned) CVM_LAUNCH(false, false, true, false); else CVM_LAUNCH(false, false, false, false); }
+    if (gather) { if (aligned) CVM_LAUNCH(false, true, true); else CVM_LAUNCH(false, true, false); }
+    else { if (aligned) CVM_LAUNCH(false, false, true); else CVM_LAUNCH(false, false, false); }
   }
 #undef CVM_LAUNCH
   if (tl) { HIP_OK(hipEventRecord(tl->b, st)); ++g_ntimed; }

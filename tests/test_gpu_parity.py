@@ -347,3 +347,48 @@ def test_full_size_c3_naive_crosscheck_one_fold(amd):
     np.testing.assert_allclose(to_np(xtx), nx, atol=1e-8, rtol=1e-7)
     np.testing.assert_allclose(to_np(xty), ny, atol=1e-8, rtol=1e-7)
     assert_stats(st, nst, 1e-9, "c3 naive")
+
+
+def test_fallback_kernel_matches_fast_kernel(amd):
+    """float64 problems normally run the 4+4-wave LDS-DMA kernel; CVM_FORCE_FALLBACK=1 (read
+    once per process) sends them through the general register-staged kernel that float32,
+    odd K and odd M use.  Run the same problem in a child process with the switch set and
+    compare with this process's result and with the oracle."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    rng = np.random.default_rng(77)
+    N, K, M = 6000, 256, 6
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    folds = [np.arange(i, N, 4) for i in range(4)]
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    (ax, ay), ast = m.training_XTX_XTY_batched(folds)
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), X=X, Y=Y, w=w)
+        code = (
+            "import numpy as np, sys\n"
+            f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+            "from cvmatrix_amd import CVMatrix\n"
+            f"z = np.load({os.path.join(td, 'in.npz')!r})\n"
+            "m = CVMatrix(); m.fit(z['X'], z['Y'], z['w'])\n"
+            "N = z['X'].shape[0]\n"
+            "(x, y), st = m.training_XTX_XTY_batched([np.arange(i, N, 4) for i in range(4)])\n"
+            f"np.savez({os.path.join(td, 'out.npz')!r}, x=x.cpu().numpy(), y=y.cpu().numpy(),\n"
+            "         g=m.XTX.cpu().numpy(), mu=st[0].cpu().numpy(), sd=st[1].cpu().numpy())\n"
+        )
+        env = dict(os.environ, CVM_FORCE_FALLBACK="1")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+        z = np.load(os.path.join(td, "out.npz"))
+    assert_normwise(ax, z["x"], 1e-12, "fallback vs fast XTX")
+    assert_normwise(ay, z["y"], 1e-12, "fallback vs fast XTY")
+    assert_normwise(m.XTX, z["g"], 1e-12, "fallback vs fast fit Gram")
+    np.testing.assert_allclose(to_np(ast[0]), z["mu"], rtol=1e-12)
+    np.testing.assert_allclose(to_np(ast[1]), z["sd"], rtol=1e-12)
+    o = OracleCVMatrix()
+    o.fit(X, Y, w)
+    (rx, ry), _ = o.training_XTX_XTY(folds[1])
+    assert_normwise(z["x"][1], rx, TOL)
+    assert_normwise(z["y"][1], ry, TOL)
