@@ -1,0 +1,134 @@
+"""CPU (-m "not gpu"): host-side logic of the product package -- Partitioner (incl. the
+vectorised path and the CSR export), constructor / backend / dtype errors, loud failure
+without a GPU, and the C-ABI library: it loads and exports every symbol include/cvmhip.h
+declares (no compute calls without a GPU)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cvmatrix_amd
+from cvmatrix_amd import CVMatrix, Partitioner, _lib
+from conftest import ROOT, load_json
+from oracle.cvmatrix_oracle import OraclePartitioner
+
+
+def same_partition(a, b):
+    assert list(a.folds_dict) == list(b.folds_dict)
+    for k in a.folds_dict:
+        assert np.array_equal(a.folds_dict[k], b.folds_dict[k])
+        assert a.folds_dict[k].dtype == b.folds_dict[k].dtype == np.dtype(int)
+
+
+@pytest.mark.parametrize("folds", [
+    np.array([0, 0, 1, 1, 2]),
+    np.arange(1000) % 7,
+    np.random.default_rng(0).integers(-5, 5, size=999),
+    np.array([3, 3, 3]),
+    np.array([True, False, True]),
+    [0, "one", 2, 2],
+    ["a", "b", "a", ("t", 1), ("t", 1)],
+    np.array(["x", "y", "x"]),
+    np.array([1.5, 2.5, 1.5]),
+    [],
+    np.zeros(0, dtype=int),
+])
+def test_partitioner_matches_reference_semantics(folds):
+    """cvmatrix/partitioner.py:89-107: keys in first-seen order, ascending int indices."""
+    same_partition(Partitioner(folds), OraclePartitioner(folds))
+
+
+def test_partitioner_missing_fold_message():
+    gold = load_json("g5_errors.json")
+    for name, fn in (("fold_missing", lambda: Partitioner([0, 1, 1]).get_validation_indices(7)),
+                     ("fold_missing_str", lambda: Partitioner([0, "a"]).get_validation_indices("b"))):
+        with pytest.raises(ValueError) as ei:
+            fn()
+        assert str(ei.value) == gold[name][1]
+        assert isinstance(ei.value.__cause__, KeyError)
+
+
+def test_partitioner_csr_export():
+    folds = np.random.default_rng(1).integers(0, 6, size=500)
+    p = Partitioner(folds)
+    idx, off = p.csr()
+    assert idx.dtype == np.int64 and off.dtype == np.int64 and off[0] == 0 and off[-1] == 500
+    for i, k in enumerate(p.folds_dict):
+        assert np.array_equal(idx[off[i]:off[i + 1]], p.get_validation_indices(k))
+    assert sorted(idx.tolist()) == list(range(500))
+
+
+def test_constructor_surface_and_errors():
+    """cvmatrix.py:157-205: flags stored, resolution = 10 * finfo.resolution; backend and
+    dtype outside the device's offer are refused loudly."""
+    m = CVMatrix(False, True, False, True, ddof=0, dtype=np.float32, copy=False)
+    assert (m.center_X, m.center_Y, m.scale_X, m.scale_Y) == (False, True, False, True)
+    assert m.ddof == 0 and m.dtype is np.float32 and m.copy is False and m.backend == "hip"
+    assert m.resolution == np.finfo(np.float32).resolution * 10
+    assert CVMatrix(dtype=np.dtype("float64")).dtype is np.float64
+    assert CVMatrix().resolution == np.finfo(np.float64).resolution * 10  # ~1e-14
+    assert m.X is None and m.XTX is None and m.sum_X is None and m.sum_w is None
+    for bad in ("numpy", "jax", "tpu"):
+        with pytest.raises(ValueError, match="Invalid backend"):
+            CVMatrix(backend=bad)
+    for bad in (np.float16, np.longdouble, np.int32):
+        with pytest.raises(TypeError):
+            CVMatrix(dtype=bad)
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = CVMatrix()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.fit(np.ones((4, 2)))
+    with pytest.raises(RuntimeError, match="fit"):
+        m.training_XTX_batched([np.array([0])])
+    with pytest.raises(ValueError, match="At least one of"):
+        m._training_matrices(False, False, np.array([0]))
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under cvmatrix_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "cvmatrix_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """include/cvmhip.h <-> libcvmhip.so <-> cvmatrix_amd/_lib.py agree on the symbol set."""
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    header = open(os.path.join(ROOT, "include", "cvmhip.h")).read()
+    declared = set(re.findall(r"\b(cvm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _lib.load()
+    assert loaded.cvm_version().decode().startswith("cvmhip")
+    # host-only entry points are callable without a GPU
+    assert loaded.cvm_gstats_len(512, 16) == 2 * 512 + 2 * 16 + 2
+    assert loaded.cvm_fit_workspace_bytes(100000, 512, 16, _lib.CVM_F64) > 0
+    assert loaded.cvm_fold_workspace_bytes(10, 100000, 10000, 512, 16, _lib.CVM_F64, 0x3F) > 0
+    info = (ctypes.c_int64 * 8)()
+    assert loaded.cvm_plan_fold(10, 10000, 512, 16, _lib.CVM_F64, 0x3F, 1 << 40, info) == 0
+    splits, wgs, panels, items = info[0], info[1], info[2], info[3]
+    assert panels == 4 and items == 10 and wgs == 10 * splits * items and splits >= 1
+    # bad arguments are refused with a message, not a crash
+    assert loaded.cvm_gram_fit(None, None, None, 1, 1, 0, 1, None, None, None, None, None, 0, None) == 1
+    assert b"null pointer" in loaded.cvm_last_error()
+
+
+def test_package_metadata():
+    assert cvmatrix_amd.__all__ == ["CVMatrix", "Partitioner", "FoldBatch"]
