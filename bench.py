@@ -68,11 +68,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
                      "(one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  (CVM_DIST_BACKEND=gloo lets several ranks share one GPU: used only
+    # to exercise the N>1 code path on a 1-GPU box.)
+    backend = os.environ.get("CVM_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from cvmatrix_amd import Partitioner, _lib
     from cvmatrix_amd.distributed import ShardedCVMatrix

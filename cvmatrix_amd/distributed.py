@@ -106,7 +106,15 @@ class ShardedCVMatrix(CVMatrix):
         if self.mode == "row_sharded":
             super().fit(X, Y, weights)
             allreduce_globals(self.XTX, self.XTY, self._gstats, self.group)
-            self._sync_totals()
+            # the global counts depend on the weights and the row counts only: when the same
+            # (unmodified) device tensors are fitted again, skip the device read-back
+            key = (self._weights_key(weights), self.N, self.world)
+            if key[0] is not None and key == getattr(self, "_totals_key", None):
+                self._n_total, self._nz_total = self._totals_val
+                self._sum_w = None
+            else:
+                self._sync_totals()
+                self._totals_key, self._totals_val = key, (self._n_total, self._nz_total)
         else:
             if self.rank == self.src:
                 super().fit(X, Y, weights)
