@@ -974,6 +974,7 @@ template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *
     else if (c < 2 * g.K + 2 * g.M) src = 2 * g.Kp + g.Mp + (c - 2 * g.K - g.M);
     else src = 2 * g.Kp + 2 * g.Mp + (c - 2 * g.K - 2 * g.M);
     double s = 0;
+#pragma unroll 4
     for (int p = 0; p < a.splits; ++p) s += unit_stats<T>((char *)a.ws, g, p)[src];
     if (c < total - 1) gstats[c] = s;
     else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
@@ -1021,6 +1022,7 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
     const int s_src = isX ? cc : 2 * g.Kp + cc;
     const int q_src = isX ? g.Kp + cc : 2 * g.Kp + g.Mp + cc;
     double sv = 0, qv = 0;
+#pragma unroll 4
     for (int p = 0; p < a.splits; ++p) {
       const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
       sv += st[s_src]; qv += st[q_src];
@@ -1049,9 +1051,11 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
 // A 16-row slab of one 128x128 upper tile (or one 128 x M panel of H) of one segment:
 // ordered sum of the split partials, then (fold mode) total - partial, rank-1 centring,
 // outer-std scaling in the reference's order (cvmatrix.py:1001-1010); the XTX tile is
-// mirrored into the lower triangle.
+// mirrored into the lower triangle.  HBM-bound: every thread owns two adjacent columns
+// (16-byte loads), the split loop keeps four loads in flight and adds in split order.
 constexpr int APPLY_THREADS = 256;
 constexpr int APPLY_SUB = 8;   // slabs per tile
+template <typename T> struct Pair { T a, b; };
 template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) void apply_kernel(const FinArgs a) {
   const Geom &g = a.g;
   const int f = blockIdx.y;
@@ -1063,6 +1067,7 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
   const size_t fo = (size_t)(a.seg0 + f);
+  const char *ws0 = a.ws + (size_t)u0 * g.unit_bytes;
   if (x < g.nTiles * APPLY_SUB) {
     if (!a.out_XTX) return;
     const int t = x / APPLY_SUB, sub = x - t * APPLY_SUB;
@@ -1071,33 +1076,43 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
     T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
     const T *Gt = (const T *)a.G;
     constexpr int ROWS = TILE / APPLY_SUB;
-    for (int e = threadIdx.x; e < ROWS * TILE; e += APPLY_THREADS) {
-      const int ra = sub * ROWS + (e >> 7), cb = e & 127;
+    for (int e = threadIdx.x; e < ROWS * (TILE / 2); e += APPLY_THREADS) {
+      const int ra = sub * ROWS + (e >> 6), cb = (e & 63) * 2;
       const int ga = ti * TILE + ra, gb = tj * TILE + cb;
-      if (ga >= K || gb >= K || (ti == tj && ra > cb)) continue;
+      if (ga >= K || gb >= K || (ti == tj && ra > cb + 1)) continue;
       const size_t off = (size_t)t * TILE * TILE + (size_t)ra * TILE + cb;
-      double v = 0;
-      for (int p = 0; p < a.splits; ++p) v += (double)unit_tiles<T>((char *)a.ws, g, u0 + p)[off];
-      if (FOLD) {
-        v = (double)Gt[(size_t)ga * K + gb] - v;
-        if (cX) v -= swt * (fs[ga] * fs[gb]);
-        if (sX) v = v / (fs[K + ga] * fs[K + gb]);
+      double v0 = 0, v1 = 0;
+      const char *pp = ws0 + off * sizeof(T);
+#pragma unroll 4
+      for (int p = 0; p < a.splits; ++p) {
+        const Pair<T> q = *reinterpret_cast<const Pair<T> *>(pp + (size_t)p * g.unit_bytes);
+        v0 += (double)q.a; v1 += (double)q.b;
       }
-      out[(size_t)ga * K + gb] = (T)v;
-      out[(size_t)gb * K + ga] = (T)v;
+      const bool has1 = gb + 1 < K;
+      if (FOLD) {
+        v0 = (double)Gt[(size_t)ga * K + gb] - v0;
+        if (has1) v1 = (double)Gt[(size_t)ga * K + gb + 1] - v1;
+        if (cX) { v0 -= swt * (fs[ga] * fs[gb]); if (has1) v1 -= swt * (fs[ga] * fs[gb + 1]); }
+        if (sX) { v0 = v0 / (fs[K + ga] * fs[K + gb]); if (has1) v1 = v1 / (fs[K + ga] * fs[K + gb + 1]); }
+      }
+      const bool up0 = !(ti == tj && ra > cb), up1 = has1 && !(ti == tj && ra > cb + 1);
+      if (up0) { out[(size_t)ga * K + gb] = (T)v0; out[(size_t)gb * K + ga] = (T)v0; }
+      if (up1) { out[(size_t)ga * K + gb + 1] = (T)v1; out[(size_t)(gb + 1) * K + ga] = (T)v1; }
     }
   } else {
     if (!a.out_XTY || M == 0) return;
     const int ti = x - g.nTiles * APPLY_SUB;
     T *out = (T *)a.out_XTY + (FOLD ? fo * (size_t)K * M : 0);
     const T *Ht = (const T *)a.H;
+    const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
     for (int e = threadIdx.x; e < TILE * M; e += APPLY_THREADS) {
       const int ra = e / M, m = e - ra * M;
       const int ga = ti * TILE + ra;
       if (ga >= K) continue;
       double v = 0;
-      for (int p = 0; p < a.splits; ++p)
-        v += (double)unit_h<T>((char *)a.ws, g, u0 + p)[(size_t)ga * g.Mp + m];
+      const char *pp = ws0 + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
+#pragma unroll 4
+      for (int p = 0; p < a.splits; ++p) v += (double)*reinterpret_cast<const T *>(pp + (size_t)p * g.unit_bytes);
       if (FOLD) {
         v = (double)Ht[(size_t)ga * M + m] - v;
         if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
@@ -1331,6 +1346,79 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   return CVM_OK;
 }
 
+// One-sweep cross-validation: when the folds partition the rows, the
+// full-data matrices are the ordered sum of the folds' validation matrices, G = sum_f G_Vf.
+// sweep_fit runs the Gram kernel ONCE over all folds (gathered), sums every unit's partials
+// into G, H, gstats and leaves the partials in the workspace; sweep_folds then only runs
+// the finalize kernels on them.  Half the flops of fit + fold update.
+template <typename T>
+int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
+                   const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                   int K, int M, int dtype, void *G, void *H, double *gstats, int32_t *neg_flag,
+                   void *ws, size_t ws_bytes, hipStream_t st, int64_t *splits_out) {
+  int64_t max_rows = 0;
+  for (int64_t f = 0; f < n_folds; ++f) {
+    const int64_t n = host_offsets[f + 1] - host_offsets[f];
+    if (n < 0) return fail(CVM_EINVAL, "cvm_sweep_fit: offsets must be non-decreasing%s");
+    if (n > max_rows) max_rows = n;
+  }
+  if (host_offsets[n_folds] - host_offsets[0] != N)
+    return fail(CVM_EINVAL, "cvm_sweep_fit: the folds must cover each of the N rows exactly once%s");
+  Plan p;
+  const unsigned flags = CVM_RET_XTX | CVM_RET_XTY;
+  int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
+  if (rc != CVM_OK || p.folds_per_batch < n_folds)
+    return fail(CVM_EWORKSPACE, "cvm_sweep_fit: the workspace must hold the partials of all folds%s");
+  WgramArgs<T> a;
+  a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+  a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = 0;
+  a.n_seg = (int)n_folds; a.splits = p.splits; a.g = p.g;
+  a.n_items = (long)n_folds * p.splits * p.g.nT; a.items_per_xcd = 0;
+  a.ws = (char *)ws;
+  g_timing_kind = 1;
+  rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st);
+  if (rc != CVM_OK) return rc;
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = p.g; f.splits = (int)(n_folds * p.splits);   // every unit of every fold, fold-major
+  f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
+  f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
+  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
+  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
+                     dim3(APPLY_THREADS), 0, st, f);
+  HIP_OK(hipGetLastError());
+  if (splits_out) *splits_out = p.splits;
+  return CVM_OK;
+}
+
+template <typename T>
+int sweep_folds_impl(const int64_t *offsets, int64_t n_folds, int K, int M, int dtype, unsigned flags,
+                     double ddof, double resolution, int weighted, const void *G, const void *H,
+                     const double *gstats, void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX,
+                     void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
+                     int64_t splits, hipStream_t st) {
+  const Geom g = make_geom(K, M, sizeof(T), 0);
+  const size_t units = (size_t)n_folds * (size_t)splits * g.unit_bytes;
+  if (units + (size_t)n_folds * fstat_len(K, M) * 8 > ws_bytes)
+    return fail(CVM_EWORKSPACE, "cvm_sweep_folds: workspace smaller than the one cvm_sweep_fit filled%s");
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = g; f.splits = (int)splits; f.n_seg = (int)n_folds; f.seg0 = 0; f.ws = (const char *)ws;
+  f.fstats = (double *)((char *)ws + units);
+  f.offs = offsets; f.w = weighted ? (const void *)G : nullptr;   // non-null = weighted
+  f.G = G; f.H = H; f.gstats = gstats;
+  f.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
+  f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
+  f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+  f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+  hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)n_folds), dim3(256), 0, st, f);
+  if (f.out_XTX || f.out_XTY)
+    hipLaunchKernelGGL((apply_kernel<T, true>), dim3(g.nTiles * APPLY_SUB + g.P, (unsigned)n_folds),
+                       dim3(APPLY_THREADS), 0, st, f);
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------
@@ -1409,6 +1497,49 @@ int cvm_debug_stamps(unsigned long long *host_out) {
   return CVM_OK;
 }
 #endif
+
+size_t cvm_sweep_workspace_bytes(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype) {
+  const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
+  const int splits = choose_splits(n_folds, max_fold_rows, g, target_wg(K, M, dtype == CVM_F64 ? 8 : 4));
+  return ((size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256)) * (size_t)(n_folds > 0 ? n_folds : 1);
+}
+
+int cvm_sweep_fit(const void *X, const void *Y, const void *w, const int64_t *idx,
+                  const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                  int K, int M, int dtype, void *G, void *H, double *gstats, int32_t *neg_flag,
+                  void *ws, size_t ws_bytes, void *stream, int64_t *splits_out) {
+  if (!X || !idx || !offsets || !host_offsets || !G || !gstats || !ws)
+    return fail(CVM_EINVAL, "cvm_sweep_fit: null pointer%s");
+  if (n_folds <= 0 || N <= 0 || K <= 0 || M < 0 || (M > 0 && (!Y || !H)) || (M == 0 && Y))
+    return fail(CVM_EINVAL, "cvm_sweep_fit: bad shape%s");
+  if (dtype == CVM_F64)
+    return sweep_fit_impl<double>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype, G, H,
+                                  gstats, neg_flag, ws, ws_bytes, (hipStream_t)stream, splits_out);
+  if (dtype == CVM_F32)
+    return sweep_fit_impl<float>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype, G, H,
+                                 gstats, neg_flag, ws, ws_bytes, (hipStream_t)stream, splits_out);
+  return fail(CVM_EINVAL, "cvm_sweep_fit: dtype must be CVM_F32 or CVM_F64%s");
+}
+
+int cvm_sweep_folds(const int64_t *offsets, int64_t n_folds, int K, int M, int dtype, unsigned flags,
+                    double ddof, double resolution, int weighted, const void *G, const void *H,
+                    const double *gstats, void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX,
+                    void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
+                    int64_t splits, void *stream) {
+  if (!offsets || !G || !gstats || !ws) return fail(CVM_EINVAL, "cvm_sweep_folds: null pointer%s");
+  if (n_folds <= 0 || K <= 0 || M < 0 || splits <= 0) return fail(CVM_EINVAL, "cvm_sweep_folds: bad shape%s");
+  if ((flags & CVM_RET_XTY) && (M == 0 || !H))
+    return fail(CVM_EINVAL, "cvm_sweep_folds: CVM_RET_XTY needs Y and H%s");
+  if (dtype == CVM_F64)
+    return sweep_folds_impl<double>(offsets, n_folds, K, M, dtype, flags, ddof, resolution, weighted, G, H,
+                                    gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold,
+                                    ws, ws_bytes, splits, (hipStream_t)stream);
+  if (dtype == CVM_F32)
+    return sweep_folds_impl<float>(offsets, n_folds, K, M, dtype, flags, ddof, resolution, weighted, G, H,
+                                   gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold,
+                                   ws, ws_bytes, splits, (hipStream_t)stream);
+  return fail(CVM_EINVAL, "cvm_sweep_folds: dtype must be CVM_F32 or CVM_F64%s");
+}
 
 int cvm_timing_enable(int on) {
   g_timing = on != 0;

@@ -56,9 +56,10 @@ class FoldBatch:
     Built by ``CVMatrix.prepare_folds``; reusable across ``*_batched`` calls.
     """
 
-    def __init__(self, idx, offsets, host_offsets, nz_val, labels=None):
+    def __init__(self, idx, offsets, host_offsets, nz_val, labels=None, is_partition=False):
         self.idx, self.offsets = idx, offsets
         self.host_offsets, self.nz_val, self.labels = host_offsets, nz_val, labels
+        self.is_partition = is_partition   # every row of X in exactly one fold
 
     @property
     def n_folds(self) -> int:
@@ -117,6 +118,9 @@ class CVMatrix:
         self._gstats = None
         self._w_host = None
         self._ws = None
+        self._sweep = None
+        self._sweep_ws = None
+        self.sweep_folds = None
         self._w_checked = None
 
     # ------------------------------------------------------------------ plumbing
@@ -158,14 +162,22 @@ class CVMatrix:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     # ------------------------------------------------------------------ fit stage
-    def fit(self, X, Y=None, weights=None) -> None:
+    def fit(self, X, Y=None, weights=None, folds=None) -> None:
         """Store ``X``, ``Y``, ``weights`` on the device and compute the full-data
         ``XᵀWX``, ``XᵀWY`` and column statistics in one pass (cvmatrix.py:207-328).
+
+        ``folds`` (not in the reference; optional): a ``Partitioner``, a list of index arrays
+        or a ``FoldBatch`` that PARTITIONS the rows.  The full-data matrices are then formed
+        as the sum of the folds' validation matrices in one sweep, and a later
+        ``training_*_batched`` call with the same ``FoldBatch`` (returned by
+        ``prepare_folds`` / kept in ``self.sweep_folds``) only runs the correction kernels:
+        half the arithmetic of ``fit`` + fold update.  Results agree to rounding.
 
         Raises ``ValueError("Weights must be non-negative.")`` like cvmatrix.py:1188-1189.
         """
         lib = _lib.load()
         self.device = self._pick_device()
+        self._sweep = None
         with torch.cuda.device(self.device):
             self.X = self._init_mat(X)
             self.N, self.K = self.X.shape
@@ -190,13 +202,17 @@ class CVMatrix:
             self._gstats = torch.empty(lib.cvm_gstats_len(self.K, M), dtype=torch.float64,
                                        device=self.device)
             neg = torch.zeros(1, dtype=torch.int32, device=self.device)
-            ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self.K, M, self._cdt))
-            rc = lib.cvm_gram_fit(
-                self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), self.N, self.K, M,
-                self._cdt, self.XTX.data_ptr(), _lib.ptr(self.XTY), self._gstats.data_ptr(),
-                neg.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(),
-            )
-            _lib.check(rc, "cvm_gram_fit")
+            if folds is not None:
+                self._fit_sweep(lib, folds, neg)
+            else:
+                ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self.K, M, self._cdt))
+                rc = lib.cvm_gram_fit(
+                    self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), self.N, self.K,
+                    M, self._cdt, self.XTX.data_ptr(), _lib.ptr(self.XTY),
+                    self._gstats.data_ptr(), neg.data_ptr(), ws.data_ptr(), ws.numel(),
+                    self._stream(),
+                )
+                _lib.check(rc, "cvm_gram_fit")
             if self.weights is not None and self._w_host is None:
                 # device-resident weights: one readback for the sign check and for the
                 # host-side fold validity checks (non-zero counts)
@@ -205,6 +221,36 @@ class CVMatrix:
                 self._w_host = self.weights.reshape(-1).cpu().numpy()
                 self._w_checked = self._weights_key(weights)
             self._publish_stats()
+
+    def _fit_sweep(self, lib, folds, neg) -> None:
+        """One-sweep fit: Gram kernel over all folds once, full-data matrices = their sum
+        (cvm_sweep_fit); the per-fold partials stay in a dedicated workspace."""
+        if self.weights is not None and self._w_host is None:
+            # device-resident weights seen for the first time: the fold bookkeeping needs
+            # their non-zero pattern on the host before the launch
+            self._w_host = self.weights.reshape(-1).cpu().numpy()
+            if bool(np.any(self._w_host < 0)):
+                raise ValueError(MSG_NEG_W)
+        batch = self.prepare_folds(folds)
+        if not batch.is_partition:
+            raise ValueError("fit(folds=...) needs folds that contain every row exactly once")
+        K, M, P = self.K, self.M or 0, batch.n_folds
+        want = lib.cvm_sweep_workspace_bytes(P, int(batch.sizes.max()), K, M, self._cdt)
+        if (getattr(self, "_sweep_ws", None) is None or self._sweep_ws.numel() < want
+                or self._sweep_ws.device != self.device):
+            self._sweep_ws = torch.empty(int(want), dtype=torch.uint8, device=self.device)
+        import ctypes as C
+
+        splits = C.c_int64(0)
+        rc = lib.cvm_sweep_fit(
+            self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), batch.idx.data_ptr(),
+            batch.offsets.data_ptr(), batch.host_offsets.ctypes.data, P, self.N, K, M, self._cdt,
+            self.XTX.data_ptr(), _lib.ptr(self.XTY), self._gstats.data_ptr(), neg.data_ptr(),
+            self._sweep_ws.data_ptr(), self._sweep_ws.numel(), self._stream(), C.byref(splits),
+        )
+        _lib.check(rc, "cvm_sweep_fit")
+        self._sweep = (batch, int(splits.value))
+        self.sweep_folds = batch
 
     @staticmethod
     def _weights_key(w):
@@ -322,6 +368,8 @@ class CVMatrix:
         host_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
         np.cumsum(sizes, out=host_offsets[1:])
         idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+        is_partition = bool(idx.size == self.N and
+                            (np.bincount(idx, minlength=self.N) == 1).all()) if self.N else False
         if self._w_host is not None:
             nzmask = (self._w_host != 0).astype(np.int64)
             csum = np.concatenate([[0], np.cumsum(nzmask[idx])])
@@ -331,7 +379,7 @@ class CVMatrix:
         with torch.cuda.device(self.device):
             d_idx = torch.from_numpy(idx).to(self.device)
             d_off = torch.from_numpy(host_offsets).to(self.device)
-        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels)
+        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, is_partition)
 
     def _validate(self, batch: FoldBatch, need_stats: bool, need_std: bool) -> None:
         """The reference's data-dependent raises, in its order (zero check first, weighted
@@ -370,6 +418,19 @@ class CVMatrix:
             muY = torch.empty((P, 1, M), dtype=dt, device=dev) if M else None
             sdY = torch.empty((P, 1, M), dtype=dt, device=dev) if M else None
             out_fold = torch.empty((P, 4), dtype=torch.float64, device=dev)
+            sweep = getattr(self, "_sweep", None)
+            if sweep is not None and sweep[0] is batch:
+                # the partials of exactly these folds are still in the sweep workspace
+                rc = lib.cvm_sweep_folds(
+                    batch.offsets.data_ptr(), P, K, M, self._cdt, flags, float(self.ddof),
+                    float(self.resolution), 1 if self.weights is not None else 0,
+                    self.XTX.data_ptr(), _lib.ptr(self.XTY), self._gstats.data_ptr(),
+                    _lib.ptr(out_XTX), _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(),
+                    _lib.ptr(muY), _lib.ptr(sdY), out_fold.data_ptr(),
+                    self._sweep_ws.data_ptr(), self._sweep_ws.numel(), sweep[1], self._stream(),
+                )
+                _lib.check(rc, "cvm_sweep_folds")
+                return out_XTX, out_XTY, (muX, sdX, muY, sdY), out_fold
             sizes = batch.sizes
             want = lib.cvm_fold_workspace_bytes(P, int(batch.host_offsets[-1]),
                                                 int(sizes.max()) if P else 0, K, M,

@@ -100,11 +100,11 @@ class ShardedCVMatrix(CVMatrix):
     def my_folds(self, sizes: Sequence[int]) -> List[int]:
         return assign_folds(sizes, self.world)[self.rank]
 
-    def fit(self, X, Y=None, weights=None) -> None:
+    def fit(self, X, Y=None, weights=None, folds=None) -> None:
         if self.world == 1:
-            return super().fit(X, Y, weights)
+            return super().fit(X, Y, weights, folds=folds)
         if self.mode == "row_sharded":
-            super().fit(X, Y, weights)
+            super().fit(X, Y, weights, folds=folds)   # folds: this rank's rows, partitioned
             allreduce_globals(self.XTX, self.XTY, self._gstats, self.group)
             # the global counts depend on the weights and the row counts only: when the same
             # (unmodified) device tensors are fitted again, skip the device read-back
@@ -116,6 +116,8 @@ class ShardedCVMatrix(CVMatrix):
                 self._sync_totals()
                 self._totals_key, self._totals_val = key, (self._n_total, self._nz_total)
         else:
+            if folds is not None:
+                raise ValueError("fit(folds=...) needs mode='row_sharded' (or a single process)")
             if self.rank == self.src:
                 super().fit(X, Y, weights)
             else:

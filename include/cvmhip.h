@@ -106,6 +106,28 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
                     void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
                     void *ws, size_t ws_bytes, void *stream);
 
+/* One-sweep cross-validation (no counterpart in the reference).  When the
+ * folds PARTITION the rows -- every row of X in exactly one fold, as the reference's own
+ * benchmark and README build them (benchmarks/benchmark.py:232, README.md:120-141) -- the
+ * full-data matrices of cvm_gram_fit are the sum of the folds' validation matrices.
+ *   cvm_sweep_fit    runs the Gram kernel once over all folds (rows gathered by idx), writes
+ *                    G, H, gstats, neg_flag exactly like cvm_gram_fit (summation order: fold-
+ *                    major) and leaves the per-fold partials in ws; *splits_out identifies them
+ *   cvm_sweep_folds  = the finalize half of cvm_fold_update on those partials (same outputs),
+ *                    valid while ws is untouched; `weighted` = 1 if cvm_sweep_fit got w != NULL
+ * Together they do half the arithmetic of cvm_gram_fit + cvm_fold_update.  The caller
+ * checks the partition property; ws must hold all folds (cvm_sweep_workspace_bytes). */
+size_t cvm_sweep_workspace_bytes(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype);
+int cvm_sweep_fit(const void *X, const void *Y, const void *w, const int64_t *idx,
+                  const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                  int K, int M, int dtype, void *G, void *H, double *gstats, int32_t *neg_flag,
+                  void *ws, size_t ws_bytes, void *stream, int64_t *splits_out);
+int cvm_sweep_folds(const int64_t *offsets, int64_t n_folds, int K, int M, int dtype, unsigned flags,
+                    double ddof, double resolution, int weighted, const void *G, const void *H,
+                    const double *gstats, void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX,
+                    void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
+                    int64_t splits, void *stream);
+
 /* Benchmark support: when enabled, a hipEvent pair is recorded on the launch stream around
  * every launch of the Gram kernel (at most 8192 pairs between reads).  cvm_timing_read
  * waits for the recorded events, returns the summed kernel milliseconds and launch counts

@@ -392,3 +392,57 @@ def test_fallback_kernel_matches_fast_kernel(amd):
     (rx, ry), _ = o.training_XTX_XTY(folds[1])
     assert_normwise(z["x"][1], rx, TOL)
     assert_normwise(z["y"][1], ry, TOL)
+
+
+def test_one_sweep_fit_matches_two_stage(amd):
+    """fit(folds=partition) forms the full-data matrices as the sum of the folds' validation
+    matrices (cvm_sweep_fit) and the batched update reuses the partials (cvm_sweep_folds):
+    same results as fit() + training_XTX_XTY_batched() to rounding, and as the oracle."""
+    rng = np.random.default_rng(31)
+    N, K, M, P = 9000, 384, 10, 7
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    w[rng.choice(N, 500, replace=False)] = 0
+    part = amd.Partitioner(rng.integers(0, P, size=N))       # ragged folds
+    for weights in (w, None):
+        a = amd.CVMatrix()
+        a.fit(X, Y, weights)
+        (ax, ay), ast = a.training_XTX_XTY_batched(part)
+        b = amd.CVMatrix()
+        b.fit(X, Y, weights, folds=part)
+        assert b.sweep_folds is not None and b.sweep_folds.is_partition
+        assert_normwise(b.XTX, to_np(a.XTX), 1e-12, "sweep fit G")
+        assert_normwise(b.XTY, to_np(a.XTY), 1e-12, "sweep fit H")
+        np.testing.assert_allclose(to_np(b.sum_X), to_np(a.sum_X), rtol=1e-12)
+        (bx, by), bst = b.training_XTX_XTY_batched(b.sweep_folds)
+        assert_normwise(bx, to_np(ax), 1e-11, "sweep XTX")
+        assert_normwise(by, to_np(ay), 1e-11, "sweep XTY")
+        for s, t in zip(ast, bst):
+            np.testing.assert_allclose(to_np(t), to_np(s), rtol=1e-11)
+        # other methods on the sweep batch, and a different fold set (normal path) still work
+        cx, cst = b.training_XTX_batched(b.sweep_folds)
+        assert_normwise(cx, to_np(ax), 1e-11)
+        st = b.training_statistics_batched(b.sweep_folds)
+        np.testing.assert_allclose(to_np(st[1]), to_np(ast[1]), rtol=1e-11)
+        o = OracleCVMatrix()
+        o.fit(X, Y, weights)
+        keys = list(part.folds_dict)
+        (rx, ry), rst = o.training_XTX_XTY(part.get_validation_indices(keys[2]))
+        assert_normwise(bx[2], rx, TOL)
+        assert_normwise(by[2], ry, TOL)
+        assert_stats(tuple(s[2] for s in bst), rst, TOL)
+        (dx, dy), _ = b.training_XTX_XTY(part.get_validation_indices(keys[3]))
+        assert_normwise(dx, to_np(ax[3]), 1e-11)
+    with pytest.raises(ValueError, match="exactly once"):
+        amd.CVMatrix().fit(X, Y, w, folds=[np.arange(10), np.arange(5, N)])
+
+
+def test_one_sweep_digest_c3(amd):
+    """The one-sweep path at the full C3 shape against the reference digests."""
+    z = load_npz("g6_digest.npz")
+    X, Y, w, folds = benchmark_inputs(100000, 512, 16, 10)
+    m = amd.CVMatrix()
+    p = amd.Partitioner(folds)
+    m.fit(X, Y, w, folds=p)
+    (bx, by), bst = m.training_XTX_XTY_batched(m.sweep_folds)
+    for f in (0, 3, 9):
+        pc.check_digest(z, "c3", f, bx[f], by[f], tuple(s[f] for s in bst), TOL)
