@@ -446,3 +446,50 @@ def test_one_sweep_digest_c3(amd):
     (bx, by), bst = m.training_XTX_XTY_batched(m.sweep_folds)
     for f in (0, 3, 9):
         pc.check_digest(z, "c3", f, bx[f], by[f], tuple(s[f] for s in bst), TOL)
+
+
+@pytest.mark.parametrize("K,M", [(1, 1), (7, 0), (66, 3), (129, 33), (257, 70)])
+def test_small_fold_direct_path(amd, K, M):
+    """Folds of at most 32 rows (leave-one-out and neighbours) take the direct, HBM-bound
+    kernels (small_stats / small_apply) instead of the MFMA Gram + finalize sequence: ragged
+    tiny folds incl. empty, 1-row and 32-row ones, odd K, tile edges, several flag sets,
+    weighted and unweighted, against the oracle."""
+    rng = np.random.default_rng(200 + K)
+    N = 400
+    X = rng.standard_normal((N, K)) + 0.5
+    Y = rng.random((N, M)) if M else None
+    w = rng.random(N)
+    w[rng.choice(N, 40, replace=False)] = 0
+    perm = rng.permutation(N)
+    folds = [perm[0:1], perm[1:6], np.zeros(0, dtype=int), perm[6:38], perm[38:55], perm[55:56]]
+    assert max(len(f) for f in folds) == 32
+    for flags in [(True,) * 4, (False,) * 4, (False, True, True, False)]:
+        _compare_with_oracle(amd, X, Y, w, folds, flags)
+    _compare_with_oracle(amd, X, Y, None, folds, (True,) * 4, ddof=0)
+
+
+def test_small_fold_loocv_fp32_and_constant_column(amd):
+    """Leave-one-out in float32 against the float64 oracle, and the exact-variance property
+    of a constant-one column on the direct path."""
+    rng = np.random.default_rng(17)
+    N, K, M = 300, 96, 4
+    X = rng.random((N, K)).astype(np.float32)
+    X[:, 5] = 1.0
+    Y = rng.random((N, M)).astype(np.float32)
+    w = rng.random(N).astype(np.float32)
+    folds = [np.array([i]) for i in range(40)]
+    m = amd.CVMatrix(dtype=np.float32)
+    m.fit(X, Y, w)
+    (bx, by), (muX, sdX, muY, sdY) = m.training_XTX_XTY_batched(folds)
+    assert bool((sdX[:, 0, 5] == 1.0).all())
+    o = OracleCVMatrix()
+    o.fit(X.astype(np.float64), Y.astype(np.float64), w.astype(np.float64))
+    for i in (0, 7, 39):
+        (rx, ry), rst = o.training_XTX_XTY(folds[i])
+        rx[5, :] = rx[:, 5] = 0  # the clamped column: oracle divides by ~1e-8 there
+        gx = to_np(bx[i]).astype(np.float64)
+        gx[5, :] = gx[:, 5] = 0
+        assert np.abs(gx - rx).max() <= 5e-4 * np.abs(rx).max()
+        mask = np.ones(K, bool); mask[5] = False
+        assert np.abs(to_np(by[i]).astype(np.float64)[mask] - ry[mask]).max() <= 5e-4 * np.abs(ry[mask]).max()
+        np.testing.assert_allclose(to_np(muX[i]), rst[0], rtol=1e-5)
