@@ -802,8 +802,13 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
         st_q[3] += (wv[c] < (T)0) ? 1.0 : 0.0;
       }
       if (MFM && WEIGHTED) {
+        if (HW) {   // H wave: 2 Y fragments instead of 8 X fragments
 #pragma unroll
-        for (int m = 0; m < NA; ++m) af[c][m] *= wv[c];
+          for (int n = 0; n < NB; ++n) bf[c][n] *= wv[c];
+        } else {
+#pragma unroll
+          for (int m = 0; m < NA; ++m) af[c][m] *= wv[c];
+        }
       }
     }
   };
@@ -811,6 +816,9 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
     read_frags(smem, 0, 0);
     prepare(0);
   }
+  // (unrolling this loop over the four LDS buffers to make every LDS address an immediate
+  //  was tried: the role functions grow to 11-15 KB each, the instruction cache thrashes and
+  //  the kernel loses 25 %)
 #pragma unroll 1
   for (int s = 0; s < nstages; ++s) {
 #ifdef CVM_STAMPS

@@ -493,3 +493,30 @@ def test_small_fold_loocv_fp32_and_constant_column(amd):
         mask = np.ones(K, bool); mask[5] = False
         assert np.abs(to_np(by[i]).astype(np.float64)[mask] - ry[mask]).max() <= 5e-4 * np.abs(ry[mask]).max()
         np.testing.assert_allclose(to_np(muX[i]), rst[0], rtol=1e-5)
+
+
+def test_race_screen_bitwise_repeatability_c3(amd):
+    """The fast kernel hands LDS buffers from loader waves to compute waves behind a counted
+    vmcnt and one barrier per stage; a misplaced wait would show up as rare wrong tiles.
+    Screen: 25 back-to-back runs of fit + batched update (and the one-sweep path) at the C3
+    shape must be bit-identical."""
+    import torch
+
+    X, Y, w, folds = benchmark_inputs(100000, 512, 16, 10)
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    b = m.prepare_folds(amd.Partitioner(folds))
+    (x0, y0), s0 = m.training_XTX_XTY_batched(b)
+    g0 = m.XTX.clone()
+    Xd, Yd, wd = m.X, m.Y, m.weights.reshape(-1)
+    for _ in range(25):
+        m.fit(Xd, Yd, wd)
+        (x1, y1), s1 = m.training_XTX_XTY_batched(b)
+        assert torch.equal(g0, m.XTX) and torch.equal(x0, x1) and torch.equal(y0, y1)
+        assert all(torch.equal(p, q) for p, q in zip(s0, s1))
+    m.fit(Xd, Yd, wd, folds=b)
+    (xs, ys), _ = m.training_XTX_XTY_batched(b)
+    for _ in range(10):
+        m.fit(Xd, Yd, wd, folds=b)
+        (x1, y1), _ = m.training_XTX_XTY_batched(b)
+        assert torch.equal(xs, x1) and torch.equal(ys, y1)
