@@ -141,6 +141,18 @@ def main():
     fit_ms = timed(lambda: model.fit(Xd, Yd, wd))
     fold_ms = timed(lambda: model.training_XTX_XTY_batched(batch))
 
+    # the reference's NumPy call pattern, fold by fold (benchmarks/benchmark.py:153-158):
+    # fit, then one training_XTX_XTY(validation_indices) call per fold with host index arrays
+    part = Partitioner(folds)
+    fold_idx = [part.get_validation_indices(f) for f in part.folds_dict]
+
+    def loop_step():
+        model.fit(Xd, Yd, wd)
+        return [model.training_XTX_XTY(v) for v in fold_idx]
+
+    loop_step()
+    loop_ms = timed(loop_step, reps=5)
+
     # one-sweep variant (reported next to the headline, not as `value`): the
     # folds partition the rows, so fit(folds=...) forms the full-data matrices as the sum
     # of the folds' validation matrices and the fold stage only runs the correction kernels
@@ -284,6 +296,8 @@ def main():
                        "parallelism": f"folds+rows sharded over {world} GPU(s); one all-reduce of [G|H|stats]"},
             "fit_ms": round(fit_ms, 4), "fold_stage_ms": round(fold_ms, 4),
             "update_only_folds_per_s": round(P / (fold_ms * 1e-3), 1),
+            "per_fold_call_ms_per_step": round(loop_ms, 4),
+            "per_fold_call_folds_per_s": round(P * world / (loop_ms * 1e-3), 1),
             "one_sweep_ms_per_step": round(sweep_ms, 4),
             "one_sweep_folds_per_s": round(P * world / (sweep_ms * 1e-3), 1),
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu,

@@ -56,10 +56,19 @@ class FoldBatch:
     Built by ``CVMatrix.prepare_folds``; reusable across ``*_batched`` calls.
     """
 
-    def __init__(self, idx, offsets, host_offsets, nz_val, labels=None, is_partition=False):
+    def __init__(self, idx, offsets, host_offsets, nz_val, labels=None, host_idx=None, n_rows=0):
         self.idx, self.offsets = idx, offsets
         self.host_offsets, self.nz_val, self.labels = host_offsets, nz_val, labels
-        self.is_partition = is_partition   # every row of X in exactly one fold
+        self._host_idx, self._n_rows, self._is_partition = host_idx, n_rows, None
+
+    @property
+    def is_partition(self) -> bool:
+        """Every row of X in exactly one fold (checked once, on first use)."""
+        if self._is_partition is None:
+            i, n = self._host_idx, self._n_rows
+            self._is_partition = bool(i is not None and n > 0 and i.size == n
+                                      and (np.bincount(i, minlength=n) == 1).all())
+        return self._is_partition
 
     @property
     def n_folds(self) -> int:
@@ -368,8 +377,6 @@ class CVMatrix:
         host_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
         np.cumsum(sizes, out=host_offsets[1:])
         idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
-        is_partition = bool(idx.size == self.N and
-                            (np.bincount(idx, minlength=self.N) == 1).all()) if self.N else False
         if self._w_host is not None:
             nzmask = (self._w_host != 0).astype(np.int64)
             csum = np.concatenate([[0], np.cumsum(nzmask[idx])])
@@ -379,7 +386,7 @@ class CVMatrix:
         with torch.cuda.device(self.device):
             d_idx = torch.from_numpy(idx).to(self.device)
             d_off = torch.from_numpy(host_offsets).to(self.device)
-        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, is_partition)
+        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N)
 
     def _validate(self, batch: FoldBatch, need_stats: bool, need_std: bool) -> None:
         """The reference's data-dependent raises, in its order (zero check first, weighted
