@@ -1056,14 +1056,93 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
   }
 }
 
-// A 16-row slab of one 128x128 upper tile (or one 128 x M panel of H) of one segment:
-// ordered sum of the split partials, then (fold mode) total - partial, rank-1 centring,
-// outer-std scaling in the reference's order (cvmatrix.py:1001-1010); the XTX tile is
-// mirrored into the lower triangle.  HBM-bound: every thread owns two adjacent columns
-// (16-byte loads), the split loop keeps four loads in flight and adds in split order.
+// Finish one 64x64 tile whose raw update (sum over the fold's rows of w*x_a*x_b) sits in
+// Ts, and store it twice: as rows a / columns b and, off the diagonal, mirrored as rows b /
+// columns a.  Row-contiguous mapping: a lane owns 16 contiguous bytes of one row, 64/VW
+// lanes cover a 64-column row segment, so every wave instruction reads G and writes XTX in
+// whole contiguous row segments.  Pass 0 finishes the tile in the reference's order
+// (cvmatrix.py:1001-1010: total - update, - sw_T*(mu_a*mu_b), / (sd_a*sd_b)), parks the
+// finished values in Ts and stores them; pass 1 stores the transposed Ts.  On a diagonal tile
+// the lower triangle takes the update of its mirror element, so the result is exactly
+// symmetric (G is, and the corrections are products of the same two factors).
+constexpr int ST = 64;                 // tile edge of the finishing code
+template <typename T, bool FOLD>
+__device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool diag, int a0, int b0, int K,
+                                                  const T *Gt, T *out, const double *fs, double swt,
+                                                  bool cX, bool sX, int tid, int nthreads) {
+  constexpr int VW = 16 / sizeof(T);            // elements per 16-byte access
+  constexpr int LPR = ST / VW;                  // lanes per row segment
+  typedef T vst_t __attribute__((ext_vector_type(VW)));
+  const bool vec_ok = ((size_t)K * sizeof(T)) % 16 == 0 && ((uintptr_t)out % 16 == 0) &&
+                      (!FOLD || (uintptr_t)Gt % 16 == 0);
+  for (int pass = 0; pass < (diag ? 1 : 2); ++pass) {
+    const int r0g = pass ? b0 : a0, c0g = pass ? a0 : b0;
+    for (int q = tid; q < ST * LPR; q += nthreads) {
+      const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+      const int gr = r0g + lr, gc = c0g + lc;
+      if (gr >= K || gc >= K) continue;
+      const bool full = vec_ok && gc + VW <= K;
+      T vals[VW];
+      if (pass == 0) {
+        T gvv[VW];
+        if (FOLD) {
+          if (full) {
+            const vst_t t = *reinterpret_cast<const vst_t *>(Gt + (size_t)gr * K + gc);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) gvv[e] = t[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) gvv[e] = (gc + e < K) ? Gt[(size_t)gr * K + gc + e] : (T)0;
+          }
+        }
+        const double mur = (FOLD && cX) ? fs[gr] : 0.0, sdr = (FOLD && sX) ? fs[K + gr] : 1.0;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          const int cc = lc + e, gce = gc + e;
+          double v = 0;
+          if (gce < K) {
+            const double upd = (diag && lr > cc) ? Ts[cc][lr] : Ts[lr][cc];
+            if (FOLD) {
+              v = (double)gvv[e] - upd;
+              if (cX) v -= swt * (mur * fs[gce]);
+              if (sX) v = v / (sdr * fs[K + gce]);
+            } else {
+              v = upd;
+            }
+          }
+          vals[e] = (T)v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vals[e] = (T)Ts[lc + e][lr];   // finished, transposed
+      }
+      T *dst = out + (size_t)gr * K + gc;
+      if (full) {
+        vst_t vv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vv[e] = vals[e];
+        *reinterpret_cast<vst_t *>(dst) = vv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) if (gc + e < K) dst[e] = vals[e];
+      }
+      if (pass == 0 && !diag) {
+        // park the finished values in place (off the diagonal every raw element is read by
+        // this thread only) for the mirrored pass
+#pragma unroll
+        for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = (double)vals[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// One 64x64 sub-tile of a 128x128 upper tile (or one 128 x M panel of H) of one segment:
+// ordered sum of the split partials (16-byte loads, four in flight, added in split order)
+// staged in LDS, then finish_store_tile: total - partial, rank-1 centring, outer-std scaling
+// and the mirrored store.  HBM-bound.
 constexpr int APPLY_THREADS = 256;
-constexpr int APPLY_SUB = 8;   // slabs per tile
-template <typename T> struct Pair { T a, b; };
+constexpr int APPLY_SUB = 4;   // 64x64 sub-tiles per 128x128 tile
 template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) void apply_kernel(const FinArgs a) {
   const Geom &g = a.g;
   const int f = blockIdx.y;
@@ -1081,32 +1160,36 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
     const int t = x / APPLY_SUB, sub = x - t * APPLY_SUB;
     int ti, tj;
     decode_tile(t, g.P, ti, tj);
-    T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
-    const T *Gt = (const T *)a.G;
-    constexpr int ROWS = TILE / APPLY_SUB;
-    for (int e = threadIdx.x; e < ROWS * (TILE / 2); e += APPLY_THREADS) {
-      const int ra = sub * ROWS + (e >> 6), cb = (e & 63) * 2;
-      const int ga = ti * TILE + ra, gb = tj * TILE + cb;
-      if (ga >= K || gb >= K || (ti == tj && ra > cb + 1)) continue;
-      const size_t off = (size_t)t * TILE * TILE + (size_t)ra * TILE + cb;
-      double v0 = 0, v1 = 0;
+    const int si = sub >> 1, sj = sub & 1;
+    if (ti == tj && si > sj) return;                 // strictly lower: mirror of sub-tile (0,1)
+    const int a0 = ti * TILE + si * ST, b0 = tj * TILE + sj * ST;
+    if (a0 >= K || b0 >= K) return;
+    __shared__ __attribute__((aligned(16))) double sm[ST * (ST + 1)];
+    double (*Ts)[ST + 1] = reinterpret_cast<double (*)[ST + 1]>(sm);
+    constexpr int VW = 16 / sizeof(T);
+    constexpr int LPR = ST / VW;
+    typedef T vld_t __attribute__((ext_vector_type(VW)));
+    const int tid = threadIdx.x;
+    for (int q = tid; q < ST * LPR; q += APPLY_THREADS) {
+      const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+      const size_t off = (size_t)t * TILE * TILE + (size_t)(si * ST + lr) * TILE + sj * ST + lc;
       const char *pp = ws0 + off * sizeof(T);
+      double v[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] = 0;
 #pragma unroll 4
       for (int p = 0; p < a.splits; ++p) {
-        const Pair<T> q = *reinterpret_cast<const Pair<T> *>(pp + (size_t)p * g.unit_bytes);
-        v0 += (double)q.a; v1 += (double)q.b;
+        const vld_t qv = *reinterpret_cast<const vld_t *>(pp + (size_t)p * g.unit_bytes);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[e] += (double)qv[e];
       }
-      const bool has1 = gb + 1 < K;
-      if (FOLD) {
-        v0 = (double)Gt[(size_t)ga * K + gb] - v0;
-        if (has1) v1 = (double)Gt[(size_t)ga * K + gb + 1] - v1;
-        if (cX) { v0 -= swt * (fs[ga] * fs[gb]); if (has1) v1 -= swt * (fs[ga] * fs[gb + 1]); }
-        if (sX) { v0 = v0 / (fs[K + ga] * fs[K + gb]); if (has1) v1 = v1 / (fs[K + ga] * fs[K + gb + 1]); }
-      }
-      const bool up0 = !(ti == tj && ra > cb), up1 = has1 && !(ti == tj && ra > cb + 1);
-      if (up0) { out[(size_t)ga * K + gb] = (T)v0; out[(size_t)gb * K + ga] = (T)v0; }
-      if (up1) { out[(size_t)ga * K + gb + 1] = (T)v1; out[(size_t)(gb + 1) * K + ga] = (T)v1; }
+#pragma unroll
+      for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = v[e];
     }
+    __syncthreads();
+    T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
+    finish_store_tile<T, FOLD>(Ts, ti == tj && si == sj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX,
+                               tid, APPLY_THREADS);
   } else {
     if (!a.out_XTY || M == 0) return;
     const int ti = x - g.nTiles * APPLY_SUB;
@@ -1148,7 +1231,6 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
 //                       twice -- as is and transposed through LDS -- with coalesced stores.
 // ----------------------------------------------------------------------------------
 constexpr int SMALL_ROWS = 32;
-constexpr int ST = 64;                 // tile edge of the small path
 struct SmallArgs {
   const void *X, *Y, *w;
   const int64_t *idx, *offs;
@@ -1294,74 +1376,8 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
 #pragma unroll
       for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
     __syncthreads();
-    // Finish and store in a row-contiguous mapping: a lane owns 16 contiguous bytes of one
-    // row, 64/VW lanes cover a 64-column row segment, so every wave instruction reads G and
-    // writes XTX in whole contiguous row segments.  Pass 0 finishes the tile (rows a,
-    // columns b), parks the finished values in Ts and stores them; pass 1 stores the
-    // mirrored tile (rows b, columns a) from the transposed Ts.  On a diagonal tile the
-    // lower triangle takes the update of its mirror element, so the result is exactly
-    // symmetric (G is, and the corrections are products of the same two factors).
-    constexpr int VW = 16 / sizeof(T);            // elements per 16-byte access
-    constexpr int LPR = ST / VW;                  // lanes per row segment
-    typedef T vst_t __attribute__((ext_vector_type(VW)));
-    const T *Gt = (const T *)a.G;
     T *out = (T *)a.out_XTX + fo * (size_t)K * K;
-    const bool vec_ok = ((size_t)K * sizeof(T)) % 16 == 0 && ((uintptr_t)out % 16 == 0) &&
-                        ((uintptr_t)Gt % 16 == 0);
-    for (int pass = 0; pass < (ti == tj ? 1 : 2); ++pass) {
-      const int r0g = pass ? b0 : a0, c0g = pass ? a0 : b0;
-      for (int q = tid; q < ST * LPR; q += 256) {
-        const int lr = q / LPR, lc = (q - lr * LPR) * VW;
-        const int gr = r0g + lr, gc = c0g + lc;
-        if (gr >= K || gc >= K) continue;
-        const bool full = vec_ok && gc + VW <= K;
-        T vals[VW];
-        if (pass == 0) {
-          T gvv[VW];
-          if (full) {
-            const vst_t t = *reinterpret_cast<const vst_t *>(Gt + (size_t)gr * K + gc);
-#pragma unroll
-            for (int e = 0; e < VW; ++e) gvv[e] = t[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) gvv[e] = (gc + e < K) ? Gt[(size_t)gr * K + gc + e] : (T)0;
-          }
-          const double mur = cX ? fs[gr] : 0.0, sdr = sX ? fs[K + gr] : 1.0;
-#pragma unroll
-          for (int e = 0; e < VW; ++e) {
-            const int cc = lc + e, gce = gc + e;
-            double v = 0;
-            if (gce < K) {
-              const double upd = (ti == tj && lr > cc) ? Ts[cc][lr] : Ts[lr][cc];
-              v = (double)gvv[e] - upd;
-              if (cX) v -= swt * (mur * fs[gce]);
-              if (sX) v = v / (sdr * fs[K + gce]);
-            }
-            vals[e] = (T)v;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < VW; ++e) vals[e] = (T)Ts[lc + e][lr];   // finished, transposed
-        }
-        T *dst = out + (size_t)gr * K + gc;
-        if (full) {
-          vst_t vv;
-#pragma unroll
-          for (int e = 0; e < VW; ++e) vv[e] = vals[e];
-          *reinterpret_cast<vst_t *>(dst) = vv;
-        } else {
-#pragma unroll
-          for (int e = 0; e < VW; ++e) if (gc + e < K) dst[e] = vals[e];
-        }
-        if (pass == 0 && ti != tj) {
-          // park the finished values in place (off the diagonal every raw element is read
-          // by this thread only) for the mirrored pass
-#pragma unroll
-          for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = (double)vals[e];
-        }
-      }
-      __syncthreads();
-    }
+    finish_store_tile<T, true>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256);
   } else {
     if (!a.out_XTY || M == 0) return;
     const int ti = x - a.nT64;
