@@ -187,6 +187,8 @@ __device__ double g_one_line[2] = {1.0, 1.0};
 #ifdef CVM_STAMPS
 // diagnostic build only: per (workgroup, wave) cycle sums of the three phases of a stage
 __device__ unsigned long long g_stamps[1024 * 8 * 4];
+__device__ unsigned long long g_stamps2[1024 * 8 * 4];
+__device__ unsigned long long g_stamps3[1024 * 8 * 2];   // per compute wave: prologue, epilogue cycles   // per wave: shader cycles, 100 MHz ticks, start tick
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
@@ -554,6 +556,9 @@ template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER>
 __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   typedef double T;
   typedef MF<double>::acc_t acc_t;
+#ifdef CVM_STAMPS
+  const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
+#endif
   const WgramArgs<double> a = scalarize(a_ref);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
@@ -719,6 +724,9 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #ifdef CVM_STAMPS
       STAMP(t2);
 #endif
+#ifdef CVM_STAMPS
+      if (!(a.dbg & 4))
+#endif
       __builtin_amdgcn_s_barrier();                   // B_s
 #ifdef CVM_STAMPS
       STAMP(t3);
@@ -753,6 +761,8 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 
 #ifdef CVM_STAMPS
   unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
+  unsigned long long c_loop0, c_loop1;
+  STAMP(c_loop0);
 #endif
   constexpr bool HW = HWR, MFM = MFMR;
   constexpr int ROLE = ROLER;
@@ -856,6 +866,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
     }
 #ifdef CVM_STAMPS
     STAMP(t2);
+    if (!(a.dbg & 4))   // diagnostic: free-running waves (wrong results)
 #endif
     __syncthreads();   // B_s
 #ifdef CVM_STAMPS
@@ -864,6 +875,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #endif
   }
 #ifdef CVM_STAMPS
+  STAMP(c_loop1);
   if (lane == 0 && blockIdx.x < 1024) {
     unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
     o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = (unsigned long long)nstages;
@@ -922,6 +934,16 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
         for (int r = 0; r < 4; ++r)
           tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc] = acc[m * 4 + n][r];
   }
+#ifdef CVM_STAMPS
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long c_exit = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned long long *o = g_stamps3 + ((size_t)blockIdx.x * 8 + wave) * 2;
+      o[0] = c_loop0 - c_entry; o[1] = c_exit - c_loop1;
+    }
+  }
+#endif
 }
 
 template <bool WEIGHTED, bool GATHER>
@@ -933,7 +955,19 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
   const long b = blockIdx.x;
   const long item = (b & 7) * a.items_per_xcd + (b >> 3);
   if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+#ifdef CVM_STAMPS
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), q0 = __builtin_amdgcn_s_memrealtime();
+  auto fin = [&]() {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
+      unsigned long long *o = g_stamps2 + ((size_t)blockIdx.x * 8 + wave_all) * 4;
+      o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
+    }
+  };
+  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3>(a); fin(); return; }
+#else
   if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3>(a); return; }
+#endif
   const int it = (int)(item % g.nT);
   int ti, tj, yc;
   if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
@@ -946,6 +980,9 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
   else if (role == 1) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 1>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 1>(a); }
   else if (role == 2) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 2>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 2>(a); }
   else { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 0>(a); }
+#ifdef CVM_STAMPS
+  fin();
+#endif
 }
 
 // ----------------------------------------------------------------------------------
@@ -1825,6 +1862,16 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
 int cvm_debug_stamps(unsigned long long *host_out) {
   HIP_OK(hipDeviceSynchronize());
   HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024 * 8 * 4));
+  return CVM_OK;
+}
+int cvm_debug_stamps3(unsigned long long *host_out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps3), sizeof(unsigned long long) * 1024 * 8 * 2));
+  return CVM_OK;
+}
+int cvm_debug_stamps2(unsigned long long *host_out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * 1024 * 8 * 4));
   return CVM_OK;
 }
 #endif

@@ -1,0 +1,216 @@
+// What does the compute wave's k-step cost on its own?  One wave per SIMD (4 waves per CU,
+// one WG per CU), a 64x64 block per wave (16 accumulators), 16-row "stages" of 4 k-steps, as in
+// wgram4_kernel, with the pieces added one at a time:
+//   0  64 MFMAs per loop iteration, operands fixed in registers
+//   1  + the 9 LDS fragment reads of the next k-step (double-buffered registers)
+//   2  + the 4 weighting multiplies in the middle of each k-step
+//   3  + one s_barrier per stage
+//   4  as 0 but 8 MFMAs + branch per iteration (the shape of tools/mfma_peak.hip)
+//   5  as 3, but the LDS reads and the multiplies spread between the MFMAs
+//      (sched_group_barrier pipeline) instead of issued in two clumps
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/mfma_mix.hip -o tools/mfma_mix
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int PITCH = 144, ROWS = 16, PANEL = ROWS * PITCH, BUF = 2 * PANEL + 16;
+
+template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in, double* out, int stages) {
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 4 * BUF; i += 512) smem[i] = in[i % 4096];
+  __syncthreads();
+  if (wave >= 4) return;   // (the real kernel's loader waves)
+  d4 acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = (d4){0, 0, 0, 0};
+  const int lk = lane >> 4, lc = lane & 15;
+  const int a_off = 64 * (wave >> 1) + lc, b_off = PANEL + 64 * (wave & 1) + lc;
+  double af[2][4], bf[2][4], wv[2];
+  auto read_frags = [&](const double* buf, int ks, int slot) {
+    const int r = 4 * ks + lk;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) af[slot][m] = buf[a_off + r * PITCH + 16 * m];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bf[slot][n] = buf[b_off + r * PITCH + 16 * n];
+    wv[slot] = buf[2 * PANEL + r];
+  };
+  read_frags(smem, 0, 0);
+  read_frags(smem, 1, 1);
+  if (V == 4) {
+    for (int s = 0; s < stages * 8; ++s) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][m], bf[0][n], acc[m * 4 + n], 0, 0, 0);
+    }
+  } else if (V == 5) {
+#pragma unroll 1
+    for (int s = 0; s < stages; ++s) {
+      const double* buf = smem + (s & 3) * BUF;
+      const double* nbuf = smem + ((s + 1) & 3) * BUF;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m * 4 + n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[c ^ 1][m] *= wv[c ^ 1];
+        // pipeline: MFMA, DS read, MFMA, DS read ... then MFMAs, then MFMA, VALU ...
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // address VALU for the read
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < stages; ++s) {
+      const double* buf = smem + (s & 3) * BUF;
+      const double* nbuf = smem + ((s + 1) & 3) * BUF;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        if (V >= 1) { if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m * 4 + n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (V >= 2) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) af[c ^ 1][m] *= wv[c ^ 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 2; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m * 4 + n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (V >= 3) __syncthreads();
+    }
+  }
+  double sacc = 0;
+  for (int i = 0; i < 16; ++i) for (int j = 0; j < 4; ++j) sacc += acc[i][j];
+  out[blockIdx.x * 512 + tid] = sacc;
+}
+
+// 8 compute waves per CU (two per SIMD), a 64x32 block each: the same work per CU and stage.
+//   V = 0: reads + weighting (of the 2 B fragments) + barrier, in two clumps per k-step
+template <int V> __global__ __launch_bounds__(768, 1) void kern8(const double* in, double* out, int stages) {
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 4 * BUF; i += 768) smem[i] = in[i % 4096];
+  __syncthreads();
+  if (wave >= 8) return;   // (loader waves)
+  d4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = (d4){0, 0, 0, 0};
+  const int lk = lane >> 4, lc = lane & 15;
+  const int a_off = 64 * (wave >> 2) + lc, b_off = PANEL + 32 * (wave & 3) + lc;
+  double af[2][4], bf[2][2], wv[2];
+  auto read_frags = [&](const double* buf, int ks, int slot) {
+    const int r = 4 * ks + lk;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) af[slot][m] = buf[a_off + r * PITCH + 16 * m];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) bf[slot][n] = buf[b_off + r * PITCH + 16 * n];
+    wv[slot] = buf[2 * PANEL + r];
+  };
+  read_frags(smem, 0, 0);
+#pragma unroll 1
+  for (int s = 0; s < stages; ++s) {
+    const double* buf = smem + (s & 3) * BUF;
+    const double* nbuf = smem + ((s + 1) & 3) * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks & 1;
+      if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m * 2 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m * 2 + n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bf[c ^ 1][n] *= wv[c ^ 1];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 2; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m * 2 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m * 2 + n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (V == 0) __syncthreads();
+  }
+  double sacc = 0;
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) sacc += acc[i][j];
+  out[blockIdx.x * 768 + tid] = sacc;
+}
+
+template <int V> void run8(const double* din, double* dout, const char* what) {
+  const int stages = 4000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipFuncSetAttribute((const void*)kern8<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BUF * 8);
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern8<V>, dim3(256), dim3(768), 4 * BUF * 8, 0, din, dout, stages);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double mf = 256.0 * 4 * stages * 64.0;
+  printf("%-58s %.3f ms  %.2f TFLOP/s  %.1f ns/stage\n", what, ms, mf * 2048.0 / ms / 1e9, ms * 1e6 / stages);
+}
+
+template <int V> void run(const double* din, double* dout, const char* what) {
+  const int stages = 4000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipFuncSetAttribute((const void*)kern<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BUF * 8);
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern<V>, dim3(256), dim3(512), 4 * BUF * 8, 0, din, dout, stages);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double mf = 256.0 * 4 * stages * 64.0;
+  printf("%-58s %.3f ms  %.2f TFLOP/s  %.1f ns/stage\n", what, ms, mf * 2048.0 / ms / 1e9, ms * 1e6 / stages);
+}
+
+int main() {
+  double* din; double* dout;
+  hipMalloc(&din, 4096 * 8); hipMalloc(&dout, 256 * 768 * 8);
+  double h[4096];
+  for (int i = 0; i < 4096; ++i) h[i] = (rand() / (double)RAND_MAX) - 0.5;
+  hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice);
+  run<4>(din, dout, "8 MFMAs per branch, registers only");
+  run<0>(din, dout, "64 MFMAs per branch, registers only");
+  run<1>(din, dout, "+ 9 LDS fragment reads per k-step");
+  run<2>(din, dout, "+ 4 weighting multiplies per k-step");
+  run<3>(din, dout, "+ one barrier per stage (4 waves)");
+  run<5>(din, dout, "same, reads and multiplies spread between the MFMAs");
+  run8<0>(din, dout, "8 waves x 64x32 (2 per SIMD): reads + weighting + barrier");
+  run8<1>(din, dout, "8 waves x 64x32 (2 per SIMD): reads + weighting, no barrier");
+  return 0;
+}

@@ -12,6 +12,12 @@ if os.environ.get("UNWEIGHTED"): w = None
 m = CVMatrix(); m.fit(X, Y, w)
 b = m.prepare_folds(Partitioner(np.arange(N) % P))
 for _ in range(3): m.training_XTX_XTY_batched(b)
+L.load().cvm_timing_enable(1)
+for _ in range(5): m.training_XTX_XTY_batched(b)
+torch.cuda.synchronize()
+_mf, _mo, _nf, _no = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
+L.load().cvm_timing_read(C.byref(_mf), C.byref(_nf), C.byref(_mo), C.byref(_no))
+print("fold-stage Gram launch ms", _mo.value / max(_no.value, 1), "CVM_DEBUG", os.environ.get("CVM_DEBUG"))
 lib = L.load(); print(lib.cvm_version().decode())
 buf = (C.c_ulonglong * (1024 * 8 * 4))()
 lib.cvm_debug_stamps(buf)
@@ -25,3 +31,22 @@ for name, i in (("phase A", 0), ("phase B", 1), ("phase C", 2)):
 tot = (a[:, :, 0] + a[:, :, 1] + a[:, :, 2]) / st
 print("total cycles/stage by wave", np.round(tot.mean(0)))
 print("compute waves 0-3: A=-, B=compute, C=barrier wait; DMA loaders 4-6: A=issue, B=vmcnt wait, C=barrier wait")
+
+buf2 = (C.c_ulonglong * (1024 * 8 * 4))()
+lib.cvm_debug_stamps2(buf2)
+b2 = np.frombuffer(buf2, dtype=np.uint64).reshape(1024, 8, 4).astype(np.float64)
+b2 = b2[b2[:, 0, 2] > 0]
+cyc, ticks = b2[:, 0, 0], b2[:, 0, 1]
+print("workgroups seen", len(b2))
+print("per-WG (wave 0): shader cycles mean %.0f, 100MHz ticks mean %.1f -> clock %.3f GHz" % (cyc.mean(), ticks.mean(), cyc.mean() / ticks.mean() / 10))
+t0 = b2[:, :, 2].min(); t1 = b2[:, :, 3].max()
+print("kernel span (first WG start -> last WG end) %.1f us; WG duration mean %.1f us, max %.1f us" % ((t1 - t0) / 100, ticks.mean() / 100, ticks.max() / 100))
+st_ = np.sort((b2[:, 0, 2] - t0) / 100)
+print("WG start times us: round 1 last %.1f; round 2 first %.1f mean %.1f last %.1f" % (st_[255], st_[256], st_[256:].mean(), st_[-1]))
+en_ = (b2[:, 0, 3] - t0) / 100
+print("WG end times us: quantiles", np.round(np.quantile(en_, [0, .25, .5, .75, 1]), 1))
+buf3 = (C.c_ulonglong * (1024 * 8 * 2))()
+lib.cvm_debug_stamps3(buf3)
+b3 = np.frombuffer(buf3, dtype=np.uint64).reshape(1024, 8, 2).astype(np.float64)
+b3 = b3[b3[:, 0, 0] > 0]
+print("compute waves: prologue cycles by wave", np.round(b3[:, :4, 0].mean(0)), "epilogue", np.round(b3[:, :4, 1].mean(0)))
