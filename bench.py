@@ -270,6 +270,23 @@ def main():
                                            "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
                                            "bytes_per_fold": "s*n*(K+M+1) + 8n + 2*s*K*(K+M)"}}
                 del Xs, Ys, ws_, ms_, bs_
+        # statistics only (training_statistics): the column-statistics kernel
+        # streams the validation rows once -> HBM-bound
+        if supp is not None:
+            model.training_statistics_batched(batch)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tl = []
+            for _ in range(10):
+                e0.record(); model.training_statistics_batched(batch); e1.record()
+                torch.cuda.synchronize(); tl.append(e0.elapsed_time(e1))
+            ms1 = float(np.median(tl))
+            bts = float((es * n_val * (K + M + 1) + 8 * n_val).sum())
+            supp[f"training_statistics ({args.workload})"] = {
+                "folds": P, "ms": round(ms1, 4), "folds_per_s": round(P / ms1 * 1e3, 1),
+                "roofline": {"bound": "hbm", "achieved": round(bts / ms1 / 1e6, 1), "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
+                             "bytes_per_fold": "s*n*(K+M+1) + 8n"}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not ho:
             from oracle.cvmatrix_oracle import run_cv

@@ -1007,6 +1007,15 @@ struct FinArgs {
 };
 __host__ __device__ inline size_t fstat_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 4; }
 
+// column chunks (grid.y) of fold_stats_kernel: enough workgroups to fill the chip when there are
+// few folds and many columns, one when there are many folds
+inline int fold_stats_chunks(int K, int M, int64_t n_folds) {
+  int c = (K + M + 255) / 256;
+  const int64_t cap = n_folds >= 512 ? 1 : (512 + n_folds - 1) / n_folds;
+  if (c > cap) c = (int)cap;
+  return c < 1 ? 1 : c;
+}
+
 // fit: gstats = ordered sum of the split partials
 template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *gstats) {
   const Geom &g = a.g;
@@ -1048,7 +1057,7 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
   const double swt = gsw - swv, nzt = gnz - nzv;
   const double divisor = (nzt - a.ddof) * swt / nzt;
   double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
     fs[2 * K + 2 * M] = swt;
     if (a.out_fold) {
       double *o = a.out_fold + 4 * (a.seg0 + f);
@@ -1060,7 +1069,7 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
   const bool rXTY = a.flags & CVM_RET_XTY;
   const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
   const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
-  for (int c = threadIdx.x; c < K + M; c += blockDim.x) {
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < K + M; c += gridDim.y * blockDim.x) {
     const bool isX = c < K;
     const int cc = isX ? c : c - K;
     if (isX ? !(want_muX) : !(want_muY)) continue;
@@ -1254,6 +1263,140 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
 }
 
 // ----------------------------------------------------------------------------------
+// colstats_kernel: statistics-only fold stage (training_statistics, cvmatrix.py:519-574;
+// SURVEY.md 8f-3).  HBM-bound: the validation rows are streamed once, nothing else is read.
+//   grid (column blocks of X + 1 block for Y, units); unit = (fold, row split)
+//   a thread owns VEC = 16/sizeof(T) adjacent columns and walks the unit's rows in order,
+//   eight rows in flight; s += w x, q += (w x) x, sw += w all in that one row order, so a
+//   constant-one column gives s == q == sw bit for bit (as in the Gram kernels).
+// Output: the unit's statistics vector in the layout fold_stats_kernel reads
+//   [ sX(Kp) | qX(Kp) | sY(Mp) | qY(Mp) | sw nz neg - ].
+// ----------------------------------------------------------------------------------
+struct ColArgs {
+  const void *X, *Y, *w;
+  const int64_t *idx, *offs;
+  int64_t seg0;
+  int splits;
+  Geom g;               // tile_elems = h_elems = 0: a unit is its statistics vector
+  char *ws;
+};
+constexpr int COL_THREADS = 256;
+#ifndef CVM_COL_UNROLL
+#define CVM_COL_UNROLL 8
+#endif
+#ifndef CVM_COL_ROWS
+#define CVM_COL_ROWS 256
+#endif
+constexpr int COL_UNROLL = CVM_COL_UNROLL;
+
+template <typename T, bool WEIGHTED, bool ALIGNED>
+__global__ __launch_bounds__(COL_THREADS) void colstats_kernel(const ColArgs a) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  const Geom &g = a.g;
+  const int K = g.K, M = g.M;
+  const long u = blockIdx.y;
+  const int seg = (int)(u / a.splits), sp = (int)(u - (long)seg * a.splits);
+  const int64_t seg_begin = a.offs[a.seg0 + seg];
+  const int64_t seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin;
+  int64_t r0, r1;
+  split_range(seg_rows, a.splits, sp, r0, r1);
+  const int64_t *idx = a.idx + seg_begin;
+  const T *wp = (const T *)a.w;
+  double *st = unit_stats<T>(a.ws, g, u);
+  const int nxb = (K + COL_THREADS * VEC - 1) / (COL_THREADS * VEC);
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nxb) {
+    const int c0 = ((int)blockIdx.x * COL_THREADS + tid) * VEC;
+    const bool live = c0 < K;
+    const T *Xp = (const T *)a.X;
+    double s[VEC], q[VEC], sw = 0, nz = 0, ng = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0;
+    auto load = [&](int64_t row) -> vec_t {
+      vec_t x;
+      const T *p = Xp + row * (int64_t)K + c0;
+      if (ALIGNED && c0 + VEC <= K) x = *reinterpret_cast<const vec_t *>(p);
+      else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[v] = (c0 + v < K) ? p[v] : (T)0;
+      }
+      return x;
+    };
+    auto acc1 = [&](const vec_t &x, T wr) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const T pv = WEIGHTED ? (T)(x[v] * wr) : x[v];
+        s[v] += (double)pv; q[v] += (double)(T)(pv * x[v]);
+      }
+      if (WEIGHTED) { sw += (double)wr; nz += (wr != (T)0) ? 1.0 : 0.0; ng += (wr < (T)0) ? 1.0 : 0.0; }
+    };
+    int64_t r = r0;
+    if (live) {
+      for (; r + COL_UNROLL <= r1; r += COL_UNROLL) {
+        int64_t rows[COL_UNROLL];
+        T wr[COL_UNROLL];
+        vec_t x[COL_UNROLL];
+#pragma unroll
+        for (int j = 0; j < COL_UNROLL; ++j) rows[j] = idx[r + j];
+#pragma unroll
+        for (int j = 0; j < COL_UNROLL; ++j) { x[j] = load(rows[j]); wr[j] = WEIGHTED ? wp[rows[j]] : (T)1; }
+#pragma unroll
+        for (int j = 0; j < COL_UNROLL; ++j) acc1(x[j], wr[j]);
+      }
+      for (; r < r1; ++r) {
+        const int64_t row = idx[r];
+        acc1(load(row), WEIGHTED ? wp[row] : (T)1);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (c0 + v < K) { st[c0 + v] = s[v]; st[g.Kp + c0 + v] = q[v]; }
+    }
+    if (blockIdx.x == 0 && tid == 0 && M == 0) {
+      if (!WEIGHTED) { sw = nz = (double)(r1 - r0); }
+      st[2 * g.Kp + 2 * g.Mp + 0] = sw; st[2 * g.Kp + 2 * g.Mp + 1] = nz; st[2 * g.Kp + 2 * g.Mp + 2] = ng;
+    }
+    return;
+  }
+  // the Y block: one column per thread (M is small), the same row order
+  const T *Yp = (const T *)a.Y;
+  for (int cb = 0; cb < M || cb == 0; cb += COL_THREADS) {
+    const int c = cb + tid;
+    const bool live = c < M;
+    double s = 0, q = 0, sw = 0, nz = 0, ng = 0;
+    int64_t r = r0;
+    auto acc1 = [&](T y, T wr) {
+      const T pv = WEIGHTED ? (T)(y * wr) : y;
+      s += (double)pv; q += (double)(T)(pv * y);
+      if (WEIGHTED) { sw += (double)wr; nz += (wr != (T)0) ? 1.0 : 0.0; ng += (wr < (T)0) ? 1.0 : 0.0; }
+    };
+    for (; r + COL_UNROLL <= r1; r += COL_UNROLL) {
+      int64_t rows[COL_UNROLL];
+      T wr[COL_UNROLL], y[COL_UNROLL];
+#pragma unroll
+      for (int j = 0; j < COL_UNROLL; ++j) rows[j] = idx[r + j];
+#pragma unroll
+      for (int j = 0; j < COL_UNROLL; ++j) {
+        y[j] = live ? Yp[rows[j] * (int64_t)M + c] : (T)0;
+        wr[j] = WEIGHTED ? wp[rows[j]] : (T)1;
+      }
+#pragma unroll
+      for (int j = 0; j < COL_UNROLL; ++j) acc1(y[j], wr[j]);
+    }
+    for (; r < r1; ++r) {
+      const int64_t row = idx[r];
+      acc1(live ? Yp[row * (int64_t)M + c] : (T)0, WEIGHTED ? wp[row] : (T)1);
+    }
+    if (live) { st[2 * g.Kp + c] = s; st[2 * g.Kp + g.Mp + c] = q; }
+    if (cb == 0 && tid == 0) {
+      if (!WEIGHTED) { sw = nz = (double)(r1 - r0); }
+      st[2 * g.Kp + 2 * g.Mp + 0] = sw; st[2 * g.Kp + 2 * g.Mp + 1] = nz; st[2 * g.Kp + 2 * g.Mp + 2] = ng;
+    }
+    if (M == 0) break;
+  }
+}
+
+// ----------------------------------------------------------------------------------
 // Small folds (at most SMALL_ROWS validation rows: leave-one-out and its neighbours).
 // The Gram of a handful of rows is no MFMA problem: the fold update is a stream over
 // K x (K+M) outputs (read G, H once, write XTX, XTY once) -- HBM-bound.  Two kernels, no
@@ -1303,7 +1446,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const double swt = gsw - swv, nzt = gnz - nzv;
   const double divisor = (nzt - a.ddof) * swt / nzt;
   double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
     fs[2 * K + 2 * M] = swt;
     if (a.out_fold) {
       double *o = a.out_fold + 4 * (a.seg0 + f);
@@ -1315,7 +1458,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const bool rXTY = a.flags & CVM_RET_XTY;
   const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
   const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
-  for (int c = threadIdx.x; c < K + M; c += blockDim.x) {
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < K + M; c += gridDim.y * blockDim.x) {
     const bool isX = c < K;
     const int cc = isX ? c : c - K;
     if (isX ? !(want_muX) : !(want_muY)) continue;
@@ -1657,6 +1800,56 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
   return CVM_OK;
 }
 
+// statistics-only fold stage: colstats_kernel + fold_stats_kernel, no Gram launch
+template <typename T>
+int fold_statistics_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
+                         const int64_t *offsets, int64_t n_folds, int64_t max_rows, int K, int M,
+                         unsigned flags, double ddof, double resolution, const double *gstats,
+                         void *out_muX, void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
+                         void *ws, size_t ws_bytes, hipStream_t st) {
+  Geom g = make_geom(K, M, sizeof(T), 1);
+  g.tile_elems = 0; g.h_elems = 0;
+  g.unit_bytes = align_up(g.stat_len * 8, 256);
+  const size_t fst = align_up(fstat_len(K, M) * 8, 256);
+  // rows per unit: short enough for >1000 workgroups in flight at the benchmark shapes, long
+  // enough that the units' statistics vectors stay a few per cent of the bytes streamed
+  int64_t splits = (max_rows + CVM_COL_ROWS - 1) / CVM_COL_ROWS;
+  if (splits < 1) splits = 1;
+  if (splits > 1024) splits = 1024;
+  while (splits > 1 && (size_t)splits * g.unit_bytes + fst > ws_bytes) splits /= 2;
+  const size_t per_fold = (size_t)splits * g.unit_bytes + fst;
+  if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
+  int64_t per_batch = (int64_t)(ws_bytes / per_fold);
+  if (per_batch > 32768) per_batch = 32768;
+  const bool aligned = rows_aligned(X, K, sizeof(T));
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nxb = (K + COL_THREADS * VEC - 1) / (COL_THREADS * VEC);
+  for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
+    const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
+    ColArgs c;
+    c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0; c.splits = (int)splits;
+    c.g = g; c.ws = (char *)ws;
+    const dim3 grid((unsigned)(nxb + 1), (unsigned)(nb * splits));
+    if (w) {
+      if (aligned) hipLaunchKernelGGL((colstats_kernel<T, true, true>), grid, dim3(COL_THREADS), 0, st, c);
+      else hipLaunchKernelGGL((colstats_kernel<T, true, false>), grid, dim3(COL_THREADS), 0, st, c);
+    } else {
+      if (aligned) hipLaunchKernelGGL((colstats_kernel<T, false, true>), grid, dim3(COL_THREADS), 0, st, c);
+      else hipLaunchKernelGGL((colstats_kernel<T, false, false>), grid, dim3(COL_THREADS), 0, st, c);
+    }
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.g = g; f.splits = (int)splits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
+    f.fstats = (double *)((char *)ws + (size_t)nb * splits * g.unit_bytes);
+    f.offs = offsets; f.w = w; f.gstats = gstats;
+    f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+    f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+    hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)), dim3(256), 0, st, f);
+    HIP_OK(hipGetLastError());
+  }
+  return CVM_OK;
+}
+
 template <typename T>
 int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
                      const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
@@ -1673,6 +1866,10 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   if (max_rows <= SMALL_ROWS)
     return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
+  const bool want_xtx = (flags & CVM_RET_XTX) && out_XTX, want_xty = (flags & CVM_RET_XTY) && out_XTY;
+  if (!want_xtx && !want_xty)   // statistics only: stream the rows once, no Gram launch
+    return fold_statistics_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution,
+                                   gstats, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
   Plan p;
   int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
   if (rc != CVM_OK) return fail(rc, "cvm_fold_update: workspace cannot hold one fold%s");
@@ -1700,7 +1897,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
     f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
     // fstats rows are fstat_len doubles apart inside the 256-byte aligned slots? keep dense
-    hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, f);
+    hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)), dim3(256), 0, st, f);
     if (f.out_XTX || f.out_XTY) {
       hipLaunchKernelGGL((apply_kernel<T, true>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, (unsigned)nb),
                          dim3(APPLY_THREADS), 0, st, f);
@@ -1775,7 +1972,7 @@ int sweep_folds_impl(const int64_t *offsets, int64_t n_folds, int K, int M, int 
   f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
   f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
   f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
-  hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)n_folds), dim3(256), 0, st, f);
+  hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)n_folds, (unsigned)fold_stats_chunks(K, M, n_folds)), dim3(256), 0, st, f);
   if (f.out_XTX || f.out_XTY)
     hipLaunchKernelGGL((apply_kernel<T, true>), dim3(g.nTiles * APPLY_SUB + g.P, (unsigned)n_folds),
                        dim3(APPLY_THREADS), 0, st, f);

@@ -520,3 +520,64 @@ def test_race_screen_bitwise_repeatability_c3(amd):
         m.fit(Xd, Yd, wd, folds=b)
         (x1, y1), _ = m.training_XTX_XTY_batched(b)
         assert torch.equal(xs, x1) and torch.equal(ys, y1)
+
+
+# ---------------------------------------------------------------- statistics-only path
+@pytest.mark.parametrize("K,M,dtype", [(130, 16, np.float64), (129, 3, np.float64),
+                                       (1100, 0, np.float64), (70, 5, np.float32),
+                                       (1028, 300, np.float32)])
+def test_training_statistics_streaming_kernel(amd, K, M, dtype):
+    """training_statistics (cvmatrix.py:519-574) on folds of more than 32 rows runs the
+    column-statistics kernel instead of the Gram kernel: every flag combination that changes
+    its output map, weighted and unweighted, aligned and unaligned rows, several column
+    blocks, ragged folds with an empty one; against the oracle, and against the statistics
+    the matrix methods return for the same folds."""
+    rng = np.random.default_rng(K + M)
+    N = 2500
+    X = (rng.standard_normal((N, K)) + 0.5).astype(dtype)
+    Y = rng.random((N, M)).astype(dtype) if M else None
+    w = rng.random(N).astype(dtype)
+    w[rng.choice(N, 100, replace=False)] = 0
+    perm = rng.permutation(N)
+    folds = [perm[:900], perm[900:933], np.zeros(0, dtype=int), perm[933:1500], perm[1500:]]
+    tol = TOL if dtype == np.float64 else 2e-5
+    for flags in [(True,) * 4, (True, False, False, False), (False, False, True, True),
+                  (False, True, False, True)]:
+        for weights in (w, None):
+            m = amd.CVMatrix(*flags, ddof=1, dtype=dtype)
+            o = OracleCVMatrix(*flags, ddof=1, dtype=np.float64)
+            m.fit(X, Y, weights)
+            o.fit(X.astype(np.float64), None if Y is None else Y.astype(np.float64),
+                  None if weights is None else weights.astype(np.float64))
+            st = m.training_statistics_batched(folds)
+            for i, v in enumerate(folds):
+                ref = o.training_statistics(v)
+                got = tuple(None if s is None else s[i] for s in st)
+                assert_stats(got, ref, tol, f"flags={flags} fold{i}")
+            one = m.training_statistics(folds[3])
+            assert_stats(one, o.training_statistics(folds[3]), tol, "single fold")
+            if dtype == np.float64 and M:
+                (_, _), mst = m.training_XTX_XTY_batched(folds)
+                for a_, b_ in zip(st, mst):
+                    if a_ is not None and b_ is not None:
+                        np.testing.assert_allclose(to_np(a_), to_np(b_), rtol=1e-12, atol=1e-13)
+
+
+def test_training_statistics_constant_column_and_determinism(amd):
+    """The streaming kernel keeps the exactness property of the Gram kernels (constant-one
+    column -> std exactly 1, also weighted) and is bitwise reproducible."""
+    rng = np.random.default_rng(77)
+    N, K = 6000, 96
+    X = rng.random((N, K)); X[:, 5] = 1.0
+    Y = rng.random((N, 4)); Y[:, 2] = 1.0
+    w = rng.random(N)
+    folds = [np.arange(i, N, 6) for i in range(6)]
+    for weights in (None, w):
+        m = amd.CVMatrix()
+        m.fit(X, Y, weights)
+        muX, sdX, muY, sdY = m.training_statistics_batched(folds)
+        assert bool((sdX[:, 0, 5] == 1.0).all()) and bool((sdY[:, 0, 2] == 1.0).all())
+        assert bool((muX[:, 0, 5] == 1.0).all()) and bool((muY[:, 0, 2] == 1.0).all())
+        again = m.training_statistics_batched(folds)
+        for a_, b_ in zip((muX, sdX, muY, sdY), again):
+            assert bool((a_ == b_).all())
