@@ -106,6 +106,11 @@ template <typename T> struct WgramArgs {
   Geom g;
   long n_items, items_per_xcd;
   char *ws;             // unit u at ws + u*unit_bytes
+  // fused single-split fold update (wgram4_kernel<.., FUSED>): finish in the epilogue
+  const double *fstats; // per fold of the batch: means / stds / sw_train (fold_stats_kernel)
+  const void *G, *H;    // full-data matrices
+  void *out_XTX, *out_XTY;
+  unsigned flags;
   int dbg;              // diagnostic ablations (env CVM_DEBUG): 1 no global loads after the
                         // first stage, 2 no MFMA, 4 no VALU column sums; results are wrong
 };
@@ -144,6 +149,8 @@ template <typename T> __device__ __forceinline__ WgramArgs<T> scalarize(const Wg
   a.g.unit_bytes = (size_t)uni64((long long)r.g.unit_bytes);
   a.n_items = uni64(r.n_items); a.items_per_xcd = uni64(r.items_per_xcd);
   a.ws = unip(r.ws); a.dbg = uni(r.dbg);
+  a.fstats = unip(r.fstats); a.G = unip(r.G); a.H = unip(r.H);
+  a.out_XTX = unip(r.out_XTX); a.out_XTY = unip(r.out_XTY); a.flags = (unsigned)uni((int)r.flags);
   return a;
 }
 
@@ -552,7 +559,13 @@ constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;
 // registers and spills hundreds of values; as separate functions every role fits.
 //   ROLER 0/1/2: compute wave without sums / with X column sums / with Y column sums
 //   ROLER 3: loader wave
-template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER>
+__host__ __device__ inline size_t fstat_len(int K, int M);
+__device__ __forceinline__ void fused_finish_block(double (*Ts)[65], const double *rs, bool diagb, int a0,
+                                                   int b0, int K, const double *Gt, double *out,
+                                                   double swt, bool cX, bool sX, int lane);
+constexpr int WAVE_LDS_DOUBLES = 64 * 65 + 256;   // a wave's 64x64 block + row/column means and stds
+
+template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
 __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   typedef double T;
   typedef MF<double>::acc_t acc_t;
@@ -734,6 +747,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing in flight at wave exit
+    if (FUSEDR) __builtin_amdgcn_s_barrier();       // the compute waves reuse the ring in their epilogue
 #ifdef CVM_STAMPS
     if (lane == 0 && blockIdx.x < 1024) {
       unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave_all) * 4;
@@ -882,6 +896,65 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   }
 #endif
 
+  if (FUSEDR) {
+    // ---- fused single-split epilogue: no partials, no apply kernel --------------------------
+    // The fold's statistics are already in a.fstats (colstats_kernel + fold_stats_kernel ran
+    // first); every wave finishes its own block: total - update, rank-1 centring, outer-std
+    // scaling (cvmatrix.py:1001-1010), mirrored store through the wave's slice of the ring.
+    __syncthreads();   // all loaders have drained their LDS-DMA
+    const int K = g.K, M = g.M;
+    const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
+    const double swt = fs[2 * K + 2 * M];
+    const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+    const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+    const size_t fo = (size_t)(a.seg0 + seg);
+    if (h_wave) {
+      if (a.out_XTY && M > 0) {
+        double *out = (double *)a.out_XTY + fo * (size_t)K * M;
+        const double *Ht = (const double *)a.H;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = ti * TILE + 16 * m + MF<T>::drow(lane, r), col = yc * YT + 16 * n + lc;
+              if (row < K && col < M) {
+                double v = Ht[(size_t)row * M + col] - acc[m * 2 + n][r];
+                if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
+                if (sX && sY) v = v / (fs[K + row] * fs[2 * K + M + col]);
+                else if (sX) v = v / fs[K + row];
+                else if (sY) v = v / fs[2 * K + M + col];
+                out[(size_t)row * M + col] = v;
+              }
+            }
+      }
+    } else if (do_g && MFM && a.out_XTX) {
+      const int a0 = ti * TILE + 64 * wr, b0 = tj * TILE + 64 * wc;
+      if (a0 < K && b0 < K) {
+        double *slice = smem + (size_t)wave * WAVE_LDS_DOUBLES;
+        double (*Ts)[65] = reinterpret_cast<double (*)[65]>(slice);
+        double *rs = slice + 64 * 65;
+        rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
+        rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
+        rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
+        rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              Ts[16 * m + MF<T>::drow(lane, r)][16 * n + lc] = acc[m * 4 + n][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fused_finish_block(Ts, rs, diag && wr == wc, a0, b0, K, (const double *)a.G,
+                           (double *)a.out_XTX + fo * (size_t)K * K, swt, cX, sX, lane);
+      }
+    }
+    return;
+  }
+
   auto comb = [&](double v) -> double {
     const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
     return ((v + v1) + v2) + v3;
@@ -946,7 +1019,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #endif
 }
 
-template <bool WEIGHTED, bool GATHER>
+template <bool WEIGHTED, bool GATHER, bool FUSED = false>
 __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> a) {
   // role of this wave (same decode as in the body)
   const Geom &g = a.g;
@@ -964,9 +1037,9 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
       o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
     }
   };
-  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3>(a); fin(); return; }
+  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3, FUSED>(a); fin(); return; }
 #else
-  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3>(a); return; }
+  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3, FUSED>(a); return; }
 #endif
   const int it = (int)(item % g.nT);
   int ti, tj, yc;
@@ -975,6 +1048,15 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
   else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
   const bool diag = (ti == tj);
   const bool do_g = !g.diag_only && yc == 0;
+  if (FUSED) {   // statistics come from colstats_kernel: no summing roles
+    if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0, true>(a);
+    else if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0, true>(a);
+    else wgram4_body<WEIGHTED, GATHER, false, false, 0, true>(a);
+#ifdef CVM_STAMPS
+    fin();
+#endif
+    return;
+  }
   const int role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
   if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0>(a);
   else if (role == 1) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 1>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 1>(a); }
@@ -1180,6 +1262,54 @@ __device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool dia
       }
     }
     __syncthreads();
+  }
+}
+
+// The same finishing step for ONE WAVE inside wgram4_kernel<.., FUSED> (float64, K even): the raw
+// update of a 64x64 block is in Ts, the row/column means and stds in rs[0..255].  A wave has no
+// other wave to hide its latency behind, so the G loads go out eight rows at a time.
+__device__ __forceinline__ void fused_finish_block(double (*Ts)[65], const double *rs, bool diagb, int a0,
+                                                   int b0, int K, const double *Gt, double *out,
+                                                   double swt, bool cX, bool sX, int lane) {
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const int half = lane >> 5, lc = 2 * (lane & 31);
+  const int gc = b0 + lc;
+  const bool col_ok = gc < K;                      // K is even: gc + 1 < K too
+  const double muc0 = rs[128 + lc], muc1 = rs[128 + lc + 1];
+  const double sdc0 = rs[192 + lc], sdc1 = rs[192 + lc + 1];
+#pragma unroll 1
+  for (int it0 = 0; it0 < 32; it0 += 8) {
+    v2 gv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int lr = 2 * (it0 + j) + half, gr = a0 + lr;
+      gv[j] = (col_ok && gr < K) ? *reinterpret_cast<const v2 *>(Gt + (size_t)gr * K + gc) : (v2){0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int lr = 2 * (it0 + j) + half, gr = a0 + lr;
+      if (!(col_ok && gr < K)) continue;
+      const double mur = rs[lr], sdr = rs[64 + lr];
+      const double u0 = (diagb && lr > lc) ? Ts[lc][lr] : Ts[lr][lc];
+      const double u1 = (diagb && lr > lc + 1) ? Ts[lc + 1][lr] : Ts[lr][lc + 1];
+      double v0 = gv[j][0] - u0, v1 = gv[j][1] - u1;
+      if (cX) { v0 -= swt * (mur * muc0); v1 -= swt * (mur * muc1); }
+      if (sX) { v0 = v0 / (sdr * sdc0); v1 = v1 / (sdr * sdc1); }
+      *reinterpret_cast<v2 *>(out + (size_t)gr * K + gc) = (v2){v0, v1};
+      if (!diagb) { Ts[lr][lc] = v0; Ts[lr][lc + 1] = v1; }   // parked for the mirrored store
+    }
+  }
+  if (diagb) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // mirrored block: rows b0.., columns a0..; out[b0 + r][a0 + c] = finished[c][r]
+  const int gc2 = a0 + lc;
+  if (gc2 >= K) return;
+#pragma unroll 4
+  for (int it = 0; it < 32; ++it) {
+    const int lr = 2 * it + half, gr = b0 + lr;
+    if (gr >= K) continue;
+    *reinterpret_cast<v2 *>(out + (size_t)gr * K + gc2) = (v2){Ts[lc][lr], Ts[lc + 1][lr]};
   }
 }
 
@@ -1632,13 +1762,18 @@ int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g, int TARGET_WG)
   if (cap > mem_cap) cap = mem_cap;
   if (cap > 64) cap = 64;
   if (cap < 1) cap = 1;
+  // estimated launch time in 16-row stages: rounds of workgroups x (stages of one split + a
+  // fixed per-workgroup cost: prologue, epilogue, partial store ~ 6 stages); fewest splits on
+  // near-ties (less partial traffic; one split per fold also lets the float64 kernel finish
+  // folds in its epilogue)
   int best = 1;
-  double best_score = -1;
+  double best_score = 1e300;
   for (int64_t s = 1; s <= cap; ++s) {
     const int64_t W = items * s;
     const int64_t rounds = (W + TARGET_WG - 1) / TARGET_WG;
-    const double score = (double)W / (double)(rounds * TARGET_WG) - 0.002 * (double)s;
-    if (score > best_score) { best_score = score; best = (int)s; }
+    const int64_t stages = ((max_rows + s - 1) / s + STAGE_ROWS - 1) / STAGE_ROWS;
+    const double score = (double)rounds * (double)(stages + 6) + 0.5 * (double)s;
+    if (score < best_score) { best_score = score; best = (int)s; }
   }
   return best;
 }
@@ -1665,15 +1800,22 @@ int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsign
   }
 }
 
+// can this problem take the float64 LDS-DMA kernel (wgram4_kernel)?
+template <typename T> bool wgram4_ok(const WgramArgs<T> &a, bool aligned) {
+  static const bool force_fallback = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
+  return sizeof(T) == 8 && aligned && (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) &&
+         ((uintptr_t)a.w % 8 == 0) && !force_fallback;
+}
+
 template <typename T>
-int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st) {
+int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st,
+                 bool fused = false) {
   const long per_xcd = (a.n_items + 7) / 8;
   WgramArgs<T> args = a;
   args.items_per_xcd = per_xcd;
   // CVM_FORCE_FALLBACK=1 sends float64 problems through the general (register-staged)
   // kernel too -- used by the tests to cover both kernels.  The ablation switches of
   // CVM_DEBUG (wrong results by design) exist in the -DCVM_STAMPS diagnostic build only.
-  static const bool force_fallback = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
 #ifdef CVM_STAMPS
   static const int dbg_env = getenv("CVM_DEBUG") ? atoi(getenv("CVM_DEBUG")) : 0;
 #else
@@ -1702,8 +1844,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     HIP_OK(hipEventRecord(tl->a, st));
   }
   constexpr bool CAN_DMA = sizeof(T) == 8;
-  const bool fast = CAN_DMA && aligned && (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) &&
-                    ((uintptr_t)a.w % 8 == 0) && !force_fallback && !(dbg_env & 16);
+  const bool fast = wgram4_ok<T>(a, aligned) && !(dbg_env & 16);
+  if (fused && !(fast && gather)) return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
   if (fast) {
     if constexpr (CAN_DMA) {
       const dim3 block4(NT4);
@@ -1717,7 +1859,20 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     }                                                                                       \
     hipLaunchKernelGGL((wgram4_kernel<W, GA>), grid, block4, LDS4_BYTES, st, args);         \
   } while (0)
-      if (weighted) { if (gather) CVM_LAUNCH4(true, true); else CVM_LAUNCH4(true, false); }
+      if (fused) {
+#define CVM_LAUNCH4F(W)                                                                     \
+  do {                                                                                      \
+    static unsigned long long attr_done = 0;                                                \
+    if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<W, true, true>,                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4_BYTES)); \
+      attr_done |= 1ull << (dev & 63);                                                      \
+    }                                                                                       \
+    hipLaunchKernelGGL((wgram4_kernel<W, true, true>), grid, block4, LDS4_BYTES, st, args); \
+  } while (0)
+        if (weighted) CVM_LAUNCH4F(true); else CVM_LAUNCH4F(false);
+#undef CVM_LAUNCH4F
+      } else if (weighted) { if (gather) CVM_LAUNCH4(true, true); else CVM_LAUNCH4(true, false); }
       else { if (gather) CVM_LAUNCH4(false, true); else CVM_LAUNCH4(false, false); }
 #undef CVM_LAUNCH4
     }
@@ -1746,6 +1901,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   int rc = make_plan(1, N, K, M, dtype, CVM_RET_XTX | CVM_RET_XTY, ws_bytes, false, p);
   if (rc != CVM_OK) return fail(rc, "cvm_gram_fit: workspace too small%s");
   WgramArgs<T> a;
+  memset(&a, 0, sizeof(a));
   a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
   a.idx = nullptr; a.offs = nullptr; a.N = N; a.seg0 = 0;
   a.n_seg = 1; a.splits = p.splits; a.g = p.g;
@@ -1874,11 +2030,67 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
   if (rc != CVM_OK) return fail(rc, "cvm_fold_update: workspace cannot hold one fold%s");
   const bool aligned = rows_aligned(X, K, sizeof(T));
+  {
+    // Folds too small to be split over workgroups (one unit per fold): finish in the Gram
+    // kernel's epilogue instead of writing partials for apply_kernel to read back.  The fold
+    // statistics the epilogue needs come from the streaming kernel first.
+    static const bool no_fused = getenv("CVM_NO_FUSED") && atoi(getenv("CVM_NO_FUSED")) != 0;
+    WgramArgs<T> probe;
+    memset(&probe, 0, sizeof(probe));
+    probe.Y = (const T *)Y; probe.w = (const T *)w; probe.g = p.g;
+    if (p.splits == 1 && want_xtx && !no_fused && wgram4_ok<T>(probe, aligned)) {
+      Geom gs = make_geom(K, M, sizeof(T), 1);
+      gs.tile_elems = 0; gs.h_elems = 0;
+      gs.unit_bytes = align_up(gs.stat_len * 8, 256);
+      const size_t fst = align_up(fstat_len(K, M) * 8, 256);
+      int64_t csplits = (max_rows + CVM_COL_ROWS - 1) / CVM_COL_ROWS;
+      if (csplits < 1) csplits = 1;
+      while (csplits > 1 && (size_t)csplits * gs.unit_bytes + fst > ws_bytes) csplits /= 2;
+      const size_t per_fold = (size_t)csplits * gs.unit_bytes + fst;
+      if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
+      int64_t per_batch = (int64_t)(ws_bytes / per_fold);
+      if (per_batch > 16384) per_batch = 16384;
+      constexpr int VEC = 16 / (int)sizeof(T);
+      const int nxb = (K + COL_THREADS * VEC - 1) / (COL_THREADS * VEC);
+      for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
+        const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
+        ColArgs c;
+        c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0; c.splits = (int)csplits;
+        c.g = gs; c.ws = (char *)ws;
+        const dim3 cgrid((unsigned)(nxb + 1), (unsigned)(nb * csplits));
+        if (w) hipLaunchKernelGGL((colstats_kernel<T, true, true>), cgrid, dim3(COL_THREADS), 0, st, c);
+        else hipLaunchKernelGGL((colstats_kernel<T, false, true>), cgrid, dim3(COL_THREADS), 0, st, c);
+        FinArgs f;
+        memset(&f, 0, sizeof(f));
+        f.g = gs; f.splits = (int)csplits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
+        f.fstats = (double *)((char *)ws + (size_t)nb * csplits * gs.unit_bytes);
+        f.offs = offsets; f.w = w; f.gstats = gstats;
+        f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+        f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+        hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)),
+                           dim3(256), 0, st, f);
+        WgramArgs<T> a;
+        memset(&a, 0, sizeof(a));
+        a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+        a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
+        a.n_seg = (int)nb; a.splits = 1; a.g = p.g;
+        a.n_items = (long)nb * p.g.nT; a.items_per_xcd = 0;
+        a.ws = nullptr;
+        a.fstats = f.fstats; a.G = G; a.H = H;
+        a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
+        g_timing_kind = 1;
+        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, true);
+        if (rc != CVM_OK) return rc;
+      }
+      return CVM_OK;
+    }
+  }
   for (int64_t f0 = 0; f0 < n_folds; f0 += p.folds_per_batch) {
     const int64_t nb = (n_folds - f0 < p.folds_per_batch) ? n_folds - f0 : p.folds_per_batch;
     char *units = (char *)ws;
     double *fstats = (double *)((char *)ws + (size_t)nb * p.splits * p.g.unit_bytes);
     WgramArgs<T> a;
+    memset(&a, 0, sizeof(a));
     a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
     a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
     a.n_seg = (int)nb; a.splits = p.splits; a.g = p.g;
@@ -1931,6 +2143,7 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   if (rc != CVM_OK || p.folds_per_batch < n_folds)
     return fail(CVM_EWORKSPACE, "cvm_sweep_fit: the workspace must hold the partials of all folds%s");
   WgramArgs<T> a;
+  memset(&a, 0, sizeof(a));
   a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
   a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = 0;
   a.n_seg = (int)n_folds; a.splits = p.splits; a.g = p.g;

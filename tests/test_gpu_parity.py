@@ -581,3 +581,102 @@ def test_training_statistics_constant_column_and_determinism(amd):
         again = m.training_statistics_batched(folds)
         for a_, b_ in zip((muX, sdX, muY, sdY), again):
             assert bool((a_ == b_).all())
+
+
+# ---------------------------------------------------------------- fused mid-size folds
+def _midsize_folds(rng, N, P):
+    """P ragged folds of 33..~3N/P rows plus an empty one; every fold has more than 32 rows
+    or none, so the batch takes the MFMA path, and there are enough folds for one unit each."""
+    perm = rng.permutation(N)
+    cuts = np.sort(rng.choice(np.arange(1, N // 40), P - 1, replace=False)) * 40
+    folds = [f for f in np.split(perm, cuts) if len(f) > 32][:P]
+    folds.insert(3, np.zeros(0, dtype=int))
+    return folds
+
+
+@pytest.mark.parametrize("K,M", [(130, 16), (200, 0), (384, 34), (512, 2)])
+def test_fused_single_split_epilogue_matches_oracle(amd, K, M):
+    """Many folds of 33..~500 rows: one unit per fold, so the float64 Gram kernel finishes
+    every fold in its own epilogue (statistics from the streaming kernel first, no partials,
+    no apply kernel).  K and M off the tile edges, Y absent, weighted and unweighted, every
+    flag family, ragged folds with an empty one; each return shape against the oracle."""
+    rng = np.random.default_rng(K * 7 + M)
+    N = 24000
+    X = rng.standard_normal((N, K)) + 0.5
+    Y = rng.random((N, M)) if M else None
+    w = rng.random(N)
+    w[rng.choice(N, 800, replace=False)] = 0
+    folds = _midsize_folds(rng, N, 120)
+    assert max(len(f) for f in folds) > 32
+    check = [0, 3, 4, len(folds) // 2, len(folds) - 1]
+    for flags in [(True,) * 4, (False,) * 4, (True, False, True, False), (False, True, False, True)]:
+        for weights in (w, None):
+            m = amd.CVMatrix(*flags, ddof=1)
+            o = OracleCVMatrix(*flags, ddof=1)
+            m.fit(X, Y, weights)
+            o.fit(X, Y, weights)
+            if M:
+                (bx, by), bst = m.training_XTX_XTY_batched(folds)
+                by2, bst2 = m.training_XTY_batched(folds)
+            else:
+                bx, bst = m.training_XTX_batched(folds)
+            bx1, bst1 = m.training_XTX_batched(folds)
+            for i in check:
+                v = folds[i]
+                if M:
+                    (rx, ry), rst = o.training_XTX_XTY(v)
+                    assert_normwise(by[i], ry, TOL, f"fold{i} XTY")
+                    ry2, rst2 = o.training_XTY(v)
+                    assert_normwise(by2[i], ry2, TOL, f"fold{i} XTY only")
+                    assert_stats(tuple(None if s is None else s[i] for s in bst2), rst2, TOL, f"fold{i} XTY only")
+                else:
+                    rx, rst = o.training_XTX(v)
+                assert_normwise(bx[i], rx, TOL, f"fold{i} XTX")
+                assert_stats(tuple(None if s is None else s[i] for s in bst), rst, TOL, f"fold{i}")
+                rx1, rst1 = o.training_XTX(v)
+                assert_normwise(bx1[i], rx1, TOL, f"fold{i} XTX only")
+                assert_stats(tuple(None if s is None else s[i] for s in bst1), rst1, TOL, f"fold{i} XTX only")
+            # exactly symmetric outputs
+            t = bx[check[1] + 1]
+            assert bool((t == t.T).all())
+
+
+def test_fused_epilogue_equals_two_stage_path(amd):
+    """CVM_NO_FUSED=1 (read once per process) keeps the partials + apply_kernel route for the
+    same problem: both routes must agree to rounding, bitwise-reproducibly within a route."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    rng = np.random.default_rng(5)
+    N, K, M, P = 30000, 256, 6, 200
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    X[:, 3] = 1.0
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    folds = [np.arange(i, N, P) for i in range(P)]
+    (ax, ay), ast = m.training_XTX_XTY_batched(folds)
+    (bx, by), _ = m.training_XTX_XTY_batched(folds)
+    assert bool((ax == bx).all()) and bool((ay == by).all())
+    assert bool((ast[1][:, 0, 3] == 1.0).all())          # constant column: std exactly 1
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), X=X, Y=Y, w=w)
+        code = (
+            "import numpy as np, sys\n"
+            f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+            "from cvmatrix_amd import CVMatrix\n"
+            f"z = np.load({os.path.join(td, 'in.npz')!r})\n"
+            "m = CVMatrix(); m.fit(z['X'], z['Y'], z['w'])\n"
+            f"N, P = z['X'].shape[0], {P}\n"
+            "(x, y), st = m.training_XTX_XTY_batched([np.arange(i, N, P) for i in range(P)])\n"
+            f"np.savez({os.path.join(td, 'out.npz')!r}, x=x[::17].cpu().numpy(), y=y[::17].cpu().numpy(),\n"
+            "         mu=st[0].cpu().numpy(), sd=st[1].cpu().numpy())\n"
+        )
+        env = dict(os.environ, CVM_NO_FUSED="1")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+        z = np.load(os.path.join(td, "out.npz"))
+    assert_normwise(ax[::17], z["x"], 1e-12, "fused vs two-stage XTX")
+    assert_normwise(ay[::17], z["y"], 1e-12, "fused vs two-stage XTY")
+    np.testing.assert_allclose(to_np(ast[0]), z["mu"], rtol=1e-12)
+    np.testing.assert_allclose(to_np(ast[1]), z["sd"], rtol=1e-12)
