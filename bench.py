@@ -304,7 +304,20 @@ def main():
                 run_cv(X, Y, w if weighted else None, folds, *flags, ddof=1, dtype=dtype)
                 times.append(time.perf_counter() - a)
             cpu_s = float(np.median(times))
+            # one BLAS thread, one pass: lines up with the reference's published single-thread
+            # numbers (benchmarks/README.md:5)
+            one_thread = None
+            try:
+                from threadpoolctl import threadpool_limits
+
+                with threadpool_limits(limits=1):
+                    a = time.perf_counter()
+                    run_cv(X, Y, w if weighted else None, folds, *flags, ddof=1, dtype=dtype)
+                    one_thread = round(P / (time.perf_counter() - a), 3)
+            except Exception:  # noqa: BLE001
+                pass
             cpu = {"value": round(P / cpu_s, 3), "unit": "folds/s", "cores": int(thr),
+                   "single_thread_value": one_thread,
                    "kind": "port",
                    "sample": f"the full {args.workload} workload (ctor+Partitioner+fit+{P} folds) "
                              f"{len(times)} times, median {cpu_s:.2f} s per pass "

@@ -126,6 +126,7 @@ class CVMatrix:
         self._n_total = self._nz_total = None
         self._gstats = None
         self._w_host = None
+        self._nz_mask = None
         self._ws = None
         self._sweep = None
         self._sweep_ws = None
@@ -378,14 +379,22 @@ class CVMatrix:
         np.cumsum(sizes, out=host_offsets[1:])
         idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
         if self._w_host is not None:
-            nzmask = (self._w_host != 0).astype(np.int64)
-            csum = np.concatenate([[0], np.cumsum(nzmask[idx])])
-            nz_val = csum[host_offsets[1:]] - csum[host_offsets[:-1]]
+            wh = self._w_host
+            if self._nz_mask is None or self._nz_mask[0] is not wh:
+                self._nz_mask = (wh, (wh != 0).astype(np.int64))   # once per fit
+            nzmask = self._nz_mask[1]
+            if len(parts) == 1:
+                nz_val = np.array([int(nzmask[idx].sum())], dtype=np.int64)
+            else:
+                csum = np.concatenate([[0], np.cumsum(nzmask[idx])])
+                nz_val = csum[host_offsets[1:]] - csum[host_offsets[:-1]]
         else:
             nz_val = sizes.copy()
+        # one host->device copy for both arrays: [offsets | idx]
+        packed = np.concatenate([host_offsets, idx])
         with torch.cuda.device(self.device):
-            d_idx = torch.from_numpy(idx).to(self.device)
-            d_off = torch.from_numpy(host_offsets).to(self.device)
+            d_all = torch.from_numpy(packed).to(self.device)
+        d_off, d_idx = d_all[:host_offsets.size], d_all[host_offsets.size:]
         return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N)
 
     def _validate(self, batch: FoldBatch, need_stats: bool, need_std: bool) -> None:
