@@ -780,6 +780,13 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #endif
   constexpr bool HW = HWR, MFM = MFMR;
   constexpr int ROLE = ROLER;
+  // the X-summing waves are exactly the diagonal 64x64 blocks of a diagonal tile: nothing reads
+  // the strictly-lower 16x16 tiles of such a block (the finalize kernels mirror the upper ones),
+  // so they are not computed -- 10 MFMAs per k-step instead of 16.  (Not wall time: the block's
+  // wave waits for the others at the stage barrier; but the kernel is power-limited and the
+  // clock rises, about 1 % measured.  Dropping the padded second column tile of the H wave the
+  // same way made the gathered variant 1.7 % slower -- code placement -- and was not kept.)
+  constexpr bool TRI = (ROLE == 1) && !HW;
   constexpr int NA = HW ? 8 : 4, NB = HW ? 2 : 4;
   // Fragments of the NEXT k-step are read while the current one computes, across the
   // stage barrier too (the loaders guarantee stage s+1 is in LDS before stage s starts);
@@ -863,7 +870,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
           for (int m = 0; m < NA / 2; ++m)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
+              if (!TRI || m <= n) acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
         }
         __builtin_amdgcn_sched_barrier(0);
         prepare(c ^ 1);   // the other slot: its LDS reads were issued half a k-step ago
@@ -873,7 +880,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
           for (int m = NA / 2; m < NA; ++m)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
+              if (!TRI || m <= n) acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -2367,7 +2374,10 @@ int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtyp
   info[4] = p.folds_per_batch;
   // MFMA instructions issued per 4 rows of one unit (executed work, incl. padding)
   int64_t per4 = 0;
-  if (!p.g.diag_only) per4 += (int64_t)(p.g.nTiles - p.g.P) * 64 + (int64_t)p.g.P * 48;
+  // a diagonal tile runs 3 blocks of 16; the float64 LDS-DMA kernel skips the strictly-lower
+  // tiles of its two diagonal blocks (16 + 10 + 10) unless it finishes folds in its epilogue
+  const bool tri = dtype == CVM_F64 && ((size_t)K * 8) % 16 == 0 && M % 2 == 0 && !(fold_mode && p.splits == 1);
+  if (!p.g.diag_only) per4 += (int64_t)(p.g.nTiles - p.g.P) * 64 + (int64_t)p.g.P * (tri ? 36 : 48);
   if (M > 0) per4 += (int64_t)p.g.P * p.g.Yc * 16;   // two H waves x 8
   info[5] = per4;
   return CVM_OK;
