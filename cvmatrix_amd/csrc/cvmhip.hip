@@ -2034,8 +2034,9 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     return fold_statistics_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution,
                                    gstats, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
   Plan p;
-  int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
-  if (rc != CVM_OK) return fail(rc, "cvm_fold_update: workspace cannot hold one fold%s");
+  // (planned against an unlimited workspace first: the fused route below needs far less than
+  //  the partials the general route plans for)
+  int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, (size_t)1 << 60, true, p);
   const bool aligned = rows_aligned(X, K, sizeof(T));
   {
     // Folds too small to be split over workgroups (one unit per fold): finish in the Gram
@@ -2092,6 +2093,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       return CVM_OK;
     }
   }
+  rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
+  if (rc != CVM_OK) return fail(rc, "cvm_fold_update: workspace cannot hold one fold%s");
   for (int64_t f0 = 0; f0 < n_folds; f0 += p.folds_per_batch) {
     const int64_t nb = (n_folds - f0 < p.folds_per_batch) ? n_folds - f0 : p.folds_per_batch;
     char *units = (char *)ws;

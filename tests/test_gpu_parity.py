@@ -680,3 +680,44 @@ def test_fused_epilogue_equals_two_stage_path(amd):
     assert_normwise(ay[::17], z["y"], 1e-12, "fused vs two-stage XTY")
     np.testing.assert_allclose(to_np(ast[0]), z["mu"], rtol=1e-12)
     np.testing.assert_allclose(to_np(ast[1]), z["sd"], rtol=1e-12)
+
+
+def test_fused_route_with_small_workspace_and_many_folds(amd):
+    """The fused route walks the folds in batches when the workspace holds only some of
+    their statistics vectors; and a single call over 40 000 leave-one-out folds (more than
+    one internal batch of the small-fold route) matches the oracle on sampled folds."""
+    import torch
+
+    rng = np.random.default_rng(18)
+    N, K, M, P = 16000, 256, 4, 250
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    folds = [np.arange(i, N, P) for i in range(P)]          # 64 rows each: one unit per fold
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    (a, b), ast = m.training_XTX_XTY_batched(folds)
+    m._ws = torch.empty(40 * 8192, dtype=torch.uint8, device=m.device)   # ~30 folds per batch
+    m._workspace = lambda n: m._ws
+    (c, d), cst = m.training_XTX_XTY_batched(folds)
+    assert bool((a == c).all()) and bool((b == d).all())
+    for s, t in zip(ast, cst):
+        assert bool((s == t).all())
+    o = OracleCVMatrix()
+    o.fit(X, Y, w)
+    for i in (0, 29, 30, 31, 249):
+        (rx, ry), rst = o.training_XTX_XTY(folds[i])
+        assert_normwise(c[i], rx, TOL, f"fold{i}")
+        assert_normwise(d[i], ry, TOL, f"fold{i}")
+        assert_stats(tuple(s[i] for s in cst), rst, TOL, f"fold{i}")
+
+    N2, K2, M2 = 40000, 48, 2
+    X2, Y2, w2 = rng.random((N2, K2)), rng.random((N2, M2)), rng.random(N2)
+    m2 = amd.CVMatrix()
+    m2.fit(X2, Y2, w2)
+    (x2, y2), st2 = m2.training_XTX_XTY_batched([np.array([i]) for i in range(N2)])
+    o2 = OracleCVMatrix()
+    o2.fit(X2, Y2, w2)
+    for i in (0, 32767, 32768, 39999):
+        (rx, ry), rst = o2.training_XTX_XTY(np.array([i]))
+        assert_normwise(x2[i], rx, TOL, f"loocv{i}")
+        assert_normwise(y2[i], ry, TOL, f"loocv{i}")
+        assert_stats(tuple(s[i] for s in st2), rst, TOL, f"loocv{i}")
