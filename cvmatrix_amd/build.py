@@ -11,7 +11,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-sh
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    deps = [SRC, os.path.join(HERE, "..", "include", "cvmhip.h")]
+    csrc = os.path.join(HERE, "csrc")
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(HERE, "..", "include", "cvmhip.h")]
     if (not force and os.path.exists(OUT)
             and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
         return OUT

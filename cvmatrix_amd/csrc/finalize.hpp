@@ -1,0 +1,329 @@
+// finalize.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
+// Finalize kernels: ordered reduction of the row-split partials, fold statistics, the
+// subtract-and-correct update with mirrored stores.
+#pragma once
+
+// ----------------------------------------------------------------------------------
+// finalize kernels
+// ----------------------------------------------------------------------------------
+struct FinArgs {
+  Geom g;
+  int splits;
+  int n_seg;            // segments (folds) in this batch
+  int64_t seg0;         // first fold of the batch (for output addressing)
+  const char *ws;       // unit partials
+  double *fstats;       // per fold of the batch: [muX(K) sdX(K) muY(M) sdY(M) swT pad..]
+  const int64_t *offs;  // device offsets (fold sizes) or nullptr
+  const void *w;        // non-null: weighted
+  const void *G, *H;    // global Gram (fold mode)
+  const double *gstats;
+  void *out_XTX, *out_XTY, *out_muX, *out_sdX, *out_muY, *out_sdY;
+  double *out_fold;
+  double ddof, resolution;
+  unsigned flags;
+  int32_t *neg_flag;
+};
+__host__ __device__ inline size_t fstat_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 4; }
+
+// column chunks (grid.y) of fold_stats_kernel: enough workgroups to fill the chip when there are
+// few folds and many columns, one when there are many folds
+inline int fold_stats_chunks(int K, int M, int64_t n_folds) {
+  int c = (K + M + 255) / 256;
+  const int64_t cap = n_folds >= 512 ? 1 : (512 + n_folds - 1) / n_folds;
+  if (c > cap) c = (int)cap;
+  return c < 1 ? 1 : c;
+}
+
+// fit: gstats = ordered sum of the split partials
+template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *gstats) {
+  const Geom &g = a.g;
+  const int total = 2 * g.K + 2 * g.M + 3;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
+    int src;
+    if (c < g.K) src = c;
+    else if (c < 2 * g.K) src = g.Kp + (c - g.K);
+    else if (c < 2 * g.K + g.M) src = 2 * g.Kp + (c - 2 * g.K);
+    else if (c < 2 * g.K + 2 * g.M) src = 2 * g.Kp + g.Mp + (c - 2 * g.K - g.M);
+    else src = 2 * g.Kp + 2 * g.Mp + (c - 2 * g.K - 2 * g.M);
+    double s = 0;
+#pragma unroll 4
+    for (int p = 0; p < a.splits; ++p) s += unit_stats<T>((char *)a.ws, g, p)[src];
+    if (c < total - 1) gstats[c] = s;
+    else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
+  }
+}
+
+// fold: training-set mean / std of every column; reference operation order
+// (cvmatrix.py:612-620, 709-745, 1043, 1079, 1119-1128)
+template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
+  const Geom &g = a.g;
+  const int f = blockIdx.x;
+  const int K = g.K, M = g.M;
+  const bool weighted = a.w != nullptr;
+  const long u0 = (long)f * a.splits;
+  double swv = 0, nzv = 0;
+  if (weighted) {
+    for (int p = 0; p < a.splits; ++p) {
+      const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
+      swv += st[2 * g.Kp + 2 * g.Mp + 0];
+      nzv += st[2 * g.Kp + 2 * g.Mp + 1];
+    }
+  } else {
+    swv = nzv = (double)(a.offs[a.seg0 + f + 1] - a.offs[a.seg0 + f]);
+  }
+  const double gsw = a.gstats[2 * K + 2 * M], gnz = a.gstats[2 * K + 2 * M + 1];
+  const double swt = gsw - swv, nzt = gnz - nzv;
+  const double divisor = (nzt - a.ddof) * swt / nzt;
+  double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
+    fs[2 * K + 2 * M] = swt;
+    if (a.out_fold) {
+      double *o = a.out_fold + 4 * (a.seg0 + f);
+      o[0] = swt; o[1] = nzt; o[2] = swv; o[3] = nzv;
+    }
+  }
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const bool rXTY = a.flags & CVM_RET_XTY;
+  const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
+  const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < K + M; c += gridDim.y * blockDim.x) {
+    const bool isX = c < K;
+    const int cc = isX ? c : c - K;
+    if (isX ? !(want_muX) : !(want_muY)) continue;
+    const int s_src = isX ? cc : 2 * g.Kp + cc;
+    const int q_src = isX ? g.Kp + cc : 2 * g.Kp + g.Mp + cc;
+    double sv = 0, qv = 0;
+#pragma unroll 4
+    for (int p = 0; p < a.splits; ++p) {
+      const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
+      sv += st[s_src]; qv += st[q_src];
+    }
+    const double gs = isX ? a.gstats[cc] : a.gstats[2 * K + cc];
+    const double gq = isX ? a.gstats[K + cc] : a.gstats[2 * K + M + cc];
+    const double st_ = gs - sv;          // cvmatrix.py:1020
+    const double mu = st_ / swt;         // cvmatrix.py:1043
+    double sd = 1.0;
+    if (isX ? want_sdX : want_sdY) {
+      const double qt = gq - qv;
+      double var = (-2 * mu * st_ + swt * (mu * mu) + qt) / divisor;   // 1119-1123
+      var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
+      sd = sqrt(var);
+      if (sd <= a.resolution) sd = 1.0;  // 1128
+    }
+    fs[isX ? cc : 2 * K + cc] = mu;
+    fs[isX ? K + cc : 2 * K + M + cc] = sd;
+    T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
+    const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
+    if (omu) omu[o] = (T)mu;
+    if (osd && (isX ? want_sdX : want_sdY)) osd[o] = (T)sd;
+  }
+}
+
+// Finish one 64x64 tile whose raw update (sum over the fold's rows of w*x_a*x_b) sits in
+// Ts, and store it twice: as rows a / columns b and, off the diagonal, mirrored as rows b /
+// columns a.  Row-contiguous mapping: a lane owns 16 contiguous bytes of one row, 64/VW
+// lanes cover a 64-column row segment, so every wave instruction reads G and writes XTX in
+// whole contiguous row segments.  Pass 0 finishes the tile in the reference's order
+// (cvmatrix.py:1001-1010: total - update, - sw_T*(mu_a*mu_b), / (sd_a*sd_b)), parks the
+// finished values in Ts and stores them; pass 1 stores the transposed Ts.  On a diagonal tile
+// the lower triangle takes the update of its mirror element, so the result is exactly
+// symmetric (G is, and the corrections are products of the same two factors).
+constexpr int ST = 64;                 // tile edge of the finishing code
+template <typename T, bool FOLD>
+__device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool diag, int a0, int b0, int K,
+                                                  const T *Gt, T *out, const double *fs, double swt,
+                                                  bool cX, bool sX, int tid, int nthreads) {
+  constexpr int VW = 16 / sizeof(T);            // elements per 16-byte access
+  constexpr int LPR = ST / VW;                  // lanes per row segment
+  typedef T vst_t __attribute__((ext_vector_type(VW)));
+  const bool vec_ok = ((size_t)K * sizeof(T)) % 16 == 0 && ((uintptr_t)out % 16 == 0) &&
+                      (!FOLD || (uintptr_t)Gt % 16 == 0);
+  for (int pass = 0; pass < (diag ? 1 : 2); ++pass) {
+    const int r0g = pass ? b0 : a0, c0g = pass ? a0 : b0;
+    for (int q = tid; q < ST * LPR; q += nthreads) {
+      const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+      const int gr = r0g + lr, gc = c0g + lc;
+      if (gr >= K || gc >= K) continue;
+      const bool full = vec_ok && gc + VW <= K;
+      T vals[VW];
+      if (pass == 0) {
+        T gvv[VW];
+        if (FOLD) {
+          if (full) {
+            const vst_t t = *reinterpret_cast<const vst_t *>(Gt + (size_t)gr * K + gc);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) gvv[e] = t[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) gvv[e] = (gc + e < K) ? Gt[(size_t)gr * K + gc + e] : (T)0;
+          }
+        }
+        const double mur = (FOLD && cX) ? fs[gr] : 0.0, sdr = (FOLD && sX) ? fs[K + gr] : 1.0;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          const int cc = lc + e, gce = gc + e;
+          double v = 0;
+          if (gce < K) {
+            const double upd = (diag && lr > cc) ? Ts[cc][lr] : Ts[lr][cc];
+            if (FOLD) {
+              v = (double)gvv[e] - upd;
+              if (cX) v -= swt * (mur * fs[gce]);
+              if (sX) v = v / (sdr * fs[K + gce]);
+            } else {
+              v = upd;
+            }
+          }
+          vals[e] = (T)v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vals[e] = (T)Ts[lc + e][lr];   // finished, transposed
+      }
+      T *dst = out + (size_t)gr * K + gc;
+      if (full) {
+        vst_t vv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vv[e] = vals[e];
+        *reinterpret_cast<vst_t *>(dst) = vv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) if (gc + e < K) dst[e] = vals[e];
+      }
+      if (pass == 0 && !diag) {
+        // park the finished values in place (off the diagonal every raw element is read by
+        // this thread only) for the mirrored pass
+#pragma unroll
+        for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = (double)vals[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The same finishing step for ONE WAVE inside wgram4_kernel<.., FUSED> (float64, K even): the raw
+// update of a 64x64 block is in Ts, the row/column means and stds in rs[0..255].  A wave has no
+// other wave to hide its latency behind, so the G loads go out eight rows at a time.
+__device__ __forceinline__ void fused_finish_block(double (*Ts)[65], const double *rs, bool diagb, int a0,
+                                                   int b0, int K, const double *Gt, double *out,
+                                                   double swt, bool cX, bool sX, int lane) {
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const int half = lane >> 5, lc = 2 * (lane & 31);
+  const int gc = b0 + lc;
+  const bool col_ok = gc < K;                      // K is even: gc + 1 < K too
+  const double muc0 = rs[128 + lc], muc1 = rs[128 + lc + 1];
+  const double sdc0 = rs[192 + lc], sdc1 = rs[192 + lc + 1];
+#pragma unroll 1
+  for (int it0 = 0; it0 < 32; it0 += 8) {
+    v2 gv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int lr = 2 * (it0 + j) + half, gr = a0 + lr;
+      gv[j] = (col_ok && gr < K) ? *reinterpret_cast<const v2 *>(Gt + (size_t)gr * K + gc) : (v2){0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int lr = 2 * (it0 + j) + half, gr = a0 + lr;
+      if (!(col_ok && gr < K)) continue;
+      const double mur = rs[lr], sdr = rs[64 + lr];
+      const double u0 = (diagb && lr > lc) ? Ts[lc][lr] : Ts[lr][lc];
+      const double u1 = (diagb && lr > lc + 1) ? Ts[lc + 1][lr] : Ts[lr][lc + 1];
+      double v0 = gv[j][0] - u0, v1 = gv[j][1] - u1;
+      if (cX) { v0 -= swt * (mur * muc0); v1 -= swt * (mur * muc1); }
+      if (sX) { v0 = v0 / (sdr * sdc0); v1 = v1 / (sdr * sdc1); }
+      *reinterpret_cast<v2 *>(out + (size_t)gr * K + gc) = (v2){v0, v1};
+      if (!diagb) { Ts[lr][lc] = v0; Ts[lr][lc + 1] = v1; }   // parked for the mirrored store
+    }
+  }
+  if (diagb) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // mirrored block: rows b0.., columns a0..; out[b0 + r][a0 + c] = finished[c][r]
+  const int gc2 = a0 + lc;
+  if (gc2 >= K) return;
+#pragma unroll 4
+  for (int it = 0; it < 32; ++it) {
+    const int lr = 2 * it + half, gr = b0 + lr;
+    if (gr >= K) continue;
+    *reinterpret_cast<v2 *>(out + (size_t)gr * K + gc2) = (v2){Ts[lc][lr], Ts[lc + 1][lr]};
+  }
+}
+
+// One 64x64 sub-tile of a 128x128 upper tile (or one 128 x M panel of H) of one segment:
+// ordered sum of the split partials (16-byte loads, four in flight, added in split order)
+// staged in LDS, then finish_store_tile: total - partial, rank-1 centring, outer-std scaling
+// and the mirrored store.  HBM-bound.
+constexpr int APPLY_THREADS = 256;
+constexpr int APPLY_SUB = 4;   // 64x64 sub-tiles per 128x128 tile
+template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) void apply_kernel(const FinArgs a) {
+  const Geom &g = a.g;
+  const int f = blockIdx.y;
+  const int x = blockIdx.x;
+  const int K = g.K, M = g.M;
+  const long u0 = (long)f * a.splits;
+  const double *fs = FOLD ? a.fstats + (size_t)f * fstat_len(K, M) : nullptr;
+  const double swt = FOLD ? fs[2 * K + 2 * M] : 0.0;
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const size_t fo = (size_t)(a.seg0 + f);
+  const char *ws0 = a.ws + (size_t)u0 * g.unit_bytes;
+  if (x < g.nTiles * APPLY_SUB) {
+    if (!a.out_XTX) return;
+    const int t = x / APPLY_SUB, sub = x - t * APPLY_SUB;
+    int ti, tj;
+    decode_tile(t, g.P, ti, tj);
+    const int si = sub >> 1, sj = sub & 1;
+    if (ti == tj && si > sj) return;                 // strictly lower: mirror of sub-tile (0,1)
+    const int a0 = ti * TILE + si * ST, b0 = tj * TILE + sj * ST;
+    if (a0 >= K || b0 >= K) return;
+    __shared__ __attribute__((aligned(16))) double sm[ST * (ST + 1)];
+    double (*Ts)[ST + 1] = reinterpret_cast<double (*)[ST + 1]>(sm);
+    constexpr int VW = 16 / sizeof(T);
+    constexpr int LPR = ST / VW;
+    typedef T vld_t __attribute__((ext_vector_type(VW)));
+    const int tid = threadIdx.x;
+    for (int q = tid; q < ST * LPR; q += APPLY_THREADS) {
+      const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+      const size_t off = (size_t)t * TILE * TILE + (size_t)(si * ST + lr) * TILE + sj * ST + lc;
+      const char *pp = ws0 + off * sizeof(T);
+      double v[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] = 0;
+#pragma unroll 4
+      for (int p = 0; p < a.splits; ++p) {
+        const vld_t qv = *reinterpret_cast<const vld_t *>(pp + (size_t)p * g.unit_bytes);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[e] += (double)qv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = v[e];
+    }
+    __syncthreads();
+    T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
+    finish_store_tile<T, FOLD>(Ts, ti == tj && si == sj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX,
+                               tid, APPLY_THREADS);
+  } else {
+    if (!a.out_XTY || M == 0) return;
+    const int ti = x - g.nTiles * APPLY_SUB;
+    T *out = (T *)a.out_XTY + (FOLD ? fo * (size_t)K * M : 0);
+    const T *Ht = (const T *)a.H;
+    const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
+    for (int e = threadIdx.x; e < TILE * M; e += APPLY_THREADS) {
+      const int ra = e / M, m = e - ra * M;
+      const int ga = ti * TILE + ra;
+      if (ga >= K) continue;
+      double v = 0;
+      const char *pp = ws0 + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
+#pragma unroll 4
+      for (int p = 0; p < a.splits; ++p) v += (double)*reinterpret_cast<const T *>(pp + (size_t)p * g.unit_bytes);
+      if (FOLD) {
+        v = (double)Ht[(size_t)ga * M + m] - v;
+        if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
+        if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + m]);
+        else if (sX) v = v / fs[K + ga];
+        else if (sY) v = v / fs[2 * K + M + m];
+      }
+      out[(size_t)ga * M + m] = (T)v;
+    }
+  }
+}

@@ -1,0 +1,151 @@
+// geometry.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
+// Tile geometry, partial-workspace layout and launch arguments shared by the Gram kernels and
+// the finalize kernels; wave-uniform helpers.
+#pragma once
+
+// ----------------------------------------------------------------------------------
+// geometry
+// ----------------------------------------------------------------------------------
+constexpr int TILE = 128;     // columns per panel; a workgroup owns a TILE x TILE output tile
+constexpr int STAGE_ROWS = 16;  // rows staged in LDS per pipeline stage (4 MFMA k-steps)
+constexpr int PITCH = 144;    // LDS row pitch of a panel, in elements (see bank note below)
+constexpr int YT = 32;        // Y columns handled per diagonal work item (2 MFMA col tiles)
+constexpr int YPITCH = 48;    // LDS row pitch of the Y tile, in elements
+constexpr int NTHREADS = 512; // 8 waves, two per SIMD
+constexpr int PANEL_ELEMS = STAGE_ROWS * PITCH;             // 2304
+constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + STAGE_ROWS;     // A panel, B panel | Y tile, w
+constexpr int TARGET_WG_1 = 256;  // resident workgroups (both Gram kernels: one 8-wave workgroup per CU)
+constexpr int TARGET_WG_2 = 256;
+// LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
+// f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
+// the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
+// ds_read_b32 (32 banks): lanes 0-15 cover 64 B; pitch must be = 64 mod 128: 144*4 = 576.
+// Same for the Y tile: 48*8 = 384 = 256+128, 48*4 = 192 = 128+64.
+
+template <typename T> struct MF;
+template <> struct MF<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // v_mfma_f64_16x16x4_f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg
+  static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct MF<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // v_mfma_f32_16x16x4_f32 C/D map: col = lane&15, row = 4*(lane>>4) + reg
+  static __device__ __forceinline__ int drow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+struct Geom {
+  int K, M;
+  int P;        // column panels = ceil(K/128)
+  int Kp;       // P*128
+  int Yc;       // Y chunks of 32 columns (>= 1 even when M == 0)
+  int Mp;       // Yc*32
+  int nTiles;   // P(P+1)/2 upper-triangular tiles
+  int nT;       // work items per unit
+  int diag_only;  // 1: only diagonal items (XTY / statistics only), no G tiles
+  size_t tile_elems, h_elems;   // per unit, in elements of T
+  size_t stat_len;              // per unit, float64 entries
+  size_t unit_bytes;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+Geom make_geom(int K, int M, int esize, int diag_only) {
+  Geom g;
+  g.K = K; g.M = M;
+  g.P = (K + TILE - 1) / TILE;
+  g.Kp = g.P * TILE;
+  g.Yc = M > 0 ? (M + YT - 1) / YT : 1;
+  g.Mp = g.Yc * YT;
+  g.nTiles = g.P * (g.P + 1) / 2;
+  g.diag_only = diag_only;
+  g.nT = diag_only ? g.P * g.Yc : g.nTiles + g.P * (g.Yc - 1);
+  g.tile_elems = diag_only ? 0 : (size_t)g.nTiles * TILE * TILE;
+  g.h_elems = (size_t)g.P * TILE * g.Mp;
+  g.stat_len = 2 * (size_t)g.Kp + 2 * (size_t)g.Mp + 4;
+  g.unit_bytes = align_up(g.tile_elems * esize, 256) + align_up(g.h_elems * esize, 256) +
+                 align_up(g.stat_len * 8, 256);
+  return g;
+}
+
+template <typename T> struct WgramArgs {
+  const T *X, *Y, *w;
+  const int64_t *idx;   // nullptr: rows are offs[seg]..offs[seg+1] themselves
+  const int64_t *offs;  // device; nullptr: one segment [0, N)
+  int64_t N;
+  int64_t seg0;         // first segment of this batch
+  int n_seg, splits;
+  Geom g;
+  long n_items, items_per_xcd;
+  char *ws;             // unit u at ws + u*unit_bytes
+  // fused single-split fold update (wgram4_kernel<.., FUSED>): finish in the epilogue
+  const double *fstats; // per fold of the batch: means / stds / sw_train (fold_stats_kernel)
+  const void *G, *H;    // full-data matrices
+  void *out_XTX, *out_XTY;
+  unsigned flags;
+  int dbg;              // diagnostic ablations (env CVM_DEBUG): 1 no global loads after the
+                        // first stage, 2 no MFMA, 4 no VALU column sums; results are wrong
+};
+
+template <typename T> __device__ __forceinline__ T *unit_tiles(char *ws, const Geom &g, long u) {
+  return (T *)(ws + (size_t)u * g.unit_bytes);
+}
+template <typename T> __device__ __forceinline__ T *unit_h(char *ws, const Geom &g, long u) {
+  return (T *)(ws + (size_t)u * g.unit_bytes + ((g.tile_elems * sizeof(T) + 255) / 256 * 256));
+}
+template <typename T> __device__ __forceinline__ double *unit_stats(char *ws, const Geom &g, long u) {
+  return (double *)(ws + (size_t)u * g.unit_bytes + ((g.tile_elems * sizeof(T) + 255) / 256 * 256) +
+                    ((g.h_elems * sizeof(T) + 255) / 256 * 256));
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename P> __device__ __forceinline__ P *unip(P *p) { return (P *)uni64((long long)p); }
+// by-value copy of the launch arguments with every field forced into scalar registers; a
+// body function that reads them through the caller's reference reloads them with flat
+// loads (and a full vmcnt wait) at every use
+template <typename T> __device__ __forceinline__ WgramArgs<T> scalarize(const WgramArgs<T> &r) {
+  WgramArgs<T> a;
+  a.X = unip(r.X); a.Y = unip(r.Y); a.w = unip(r.w); a.idx = unip(r.idx); a.offs = unip(r.offs);
+  a.N = uni64(r.N); a.seg0 = uni64(r.seg0); a.n_seg = uni(r.n_seg); a.splits = uni(r.splits);
+  a.g.K = uni(r.g.K); a.g.M = uni(r.g.M); a.g.P = uni(r.g.P); a.g.Kp = uni(r.g.Kp);
+  a.g.Yc = uni(r.g.Yc); a.g.Mp = uni(r.g.Mp); a.g.nTiles = uni(r.g.nTiles); a.g.nT = uni(r.g.nT);
+  a.g.diag_only = uni(r.g.diag_only);
+  a.g.tile_elems = (size_t)uni64((long long)r.g.tile_elems);
+  a.g.h_elems = (size_t)uni64((long long)r.g.h_elems);
+  a.g.stat_len = (size_t)uni64((long long)r.g.stat_len);
+  a.g.unit_bytes = (size_t)uni64((long long)r.g.unit_bytes);
+  a.n_items = uni64(r.n_items); a.items_per_xcd = uni64(r.items_per_xcd);
+  a.ws = unip(r.ws); a.dbg = uni(r.dbg);
+  a.fstats = unip(r.fstats); a.G = unip(r.G); a.H = unip(r.H);
+  a.out_XTX = unip(r.out_XTX); a.out_XTY = unip(r.out_XTY); a.flags = (unsigned)uni((int)r.flags);
+  return a;
+}
+
+__device__ __forceinline__ void decode_tile(int t, int P, int &ti, int &tj) {
+  // row-major upper triangle: (0,0),(0,1)..(0,P-1),(1,1)...
+  int i = 0, rem = t;
+  while (rem >= P - i) { rem -= P - i; ++i; }
+  ti = i; tj = i + rem;
+}
+__host__ __device__ __forceinline__ int tile_id(int i, int j, int P) {
+  return i * P - i * (i - 1) / 2 + (j - i);
+}
+
+// rows of segment `seg` handled by split `sp`
+__device__ __forceinline__ void split_range(int64_t n, int splits, int sp, int64_t &r0, int64_t &r1) {
+  int64_t per = (n + splits - 1) / splits;
+  per = (per + STAGE_ROWS - 1) / STAGE_ROWS * STAGE_ROWS;
+  r0 = (int64_t)sp * per; if (r0 > n) r0 = n;
+  r1 = r0 + per; if (r1 > n) r1 = n;
+}

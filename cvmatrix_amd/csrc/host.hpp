@@ -1,0 +1,475 @@
+// host.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
+// Host side: planning (row splits, batches), launches, the implementation of every C entry point.
+#pragma once
+
+// ----------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, const char *detail = "") {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return code;
+}
+#define HIP_OK(expr)                                                             \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) return fail(CVM_ELAUNCH, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- optional per-launch timing of the Gram kernel (bench.py's roofline figure) --------
+struct TimedLaunch { hipEvent_t a, b; int kind; };
+bool g_timing = false;
+TimedLaunch g_timed[8192];
+int g_ntimed = 0;
+int g_timing_kind = 0;   // 0: fit stage, 1: fold stage
+
+struct Plan {
+  Geom g;
+  int splits;
+  int64_t folds_per_batch;
+  size_t fstat_bytes_per_fold;
+};
+
+// Row splits per segment.  Model: TARGET_WG workgroups are resident at a time and take
+// equal time, so W = items*splits workgroups cost ceil(W/TARGET_WG) rounds; pick the split
+// count with the best fill, lightly preferring fewer splits (less partial traffic).
+int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g, int TARGET_WG) {
+  const int64_t items = (n_seg > 0 ? n_seg : 1) * g.nT;
+  int64_t cap = max_rows / 64;                       // >= 64 rows per split
+  const int64_t mem_cap = (int64_t)(((size_t)3 << 30) / ((size_t)(n_seg > 0 ? n_seg : 1) * g.unit_bytes));
+  if (cap > mem_cap) cap = mem_cap;
+  if (cap > 64) cap = 64;
+  if (cap < 1) cap = 1;
+  // estimated launch time in 16-row stages: rounds of workgroups x (stages of one split + a
+  // fixed per-workgroup cost: prologue, epilogue, partial store ~ 6 stages); fewest splits on
+  // near-ties (less partial traffic; one split per fold also lets the float64 kernel finish
+  // folds in its epilogue)
+  int best = 1;
+  double best_score = 1e300;
+  for (int64_t s = 1; s <= cap; ++s) {
+    const int64_t W = items * s;
+    const int64_t rounds = (W + TARGET_WG - 1) / TARGET_WG;
+    const int64_t stages = ((max_rows + s - 1) / s + STAGE_ROWS - 1) / STAGE_ROWS;
+    const double score = (double)rounds * (double)(stages + 6) + 0.5 * (double)s;
+    if (score < best_score) { best_score = score; best = (int)s; }
+  }
+  return best;
+}
+
+// which Gram kernel variant a problem gets (pointers from torch are 256-byte aligned; a
+// misaligned X falls back to the register path at launch, only the split heuristic differs)
+int target_wg(int K, int M, int esize) {
+  return (esize == 8 && ((size_t)K * esize) % 16 == 0 && M % 2 == 0) ? TARGET_WG_2 : TARGET_WG_1;
+}
+
+int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsigned flags,
+              size_t ws_bytes, bool fold_mode, Plan &p) {
+  const int esize = dtype == CVM_F64 ? 8 : 4;
+  const int diag_only = fold_mode && !(flags & CVM_RET_XTX);
+  p.g = make_geom(K, M, esize, diag_only);
+  p.splits = choose_splits(n_folds, max_rows, p.g, target_wg(K, M, esize));
+  p.fstat_bytes_per_fold = fold_mode ? align_up(fstat_len(K, M) * 8, 256) : 0;
+  for (;;) {
+    const size_t per_fold = (size_t)p.splits * p.g.unit_bytes + p.fstat_bytes_per_fold;
+    int64_t nb = (int64_t)(ws_bytes / per_fold);
+    if (nb >= 1) { p.folds_per_batch = nb < n_folds ? nb : n_folds; return CVM_OK; }
+    if (p.splits == 1) return CVM_EWORKSPACE;
+    p.splits = (p.splits + 1) / 2;
+  }
+}
+
+// can this problem take the float64 LDS-DMA kernel (wgram4_kernel)?
+template <typename T> bool wgram4_ok(const WgramArgs<T> &a, bool aligned) {
+  static const bool force_fallback = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
+  return sizeof(T) == 8 && aligned && (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) &&
+         ((uintptr_t)a.w % 8 == 0) && !force_fallback;
+}
+
+template <typename T>
+int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st,
+                 bool fused = false) {
+  const long per_xcd = (a.n_items + 7) / 8;
+  WgramArgs<T> args = a;
+  args.items_per_xcd = per_xcd;
+  // CVM_FORCE_FALLBACK=1 sends float64 problems through the general (register-staged)
+  // kernel too -- used by the tests to cover both kernels.  The ablation switches of
+  // CVM_DEBUG (wrong results by design) exist in the -DCVM_STAMPS diagnostic build only.
+#ifdef CVM_STAMPS
+  static const int dbg_env = getenv("CVM_DEBUG") ? atoi(getenv("CVM_DEBUG")) : 0;
+#else
+  static const int dbg_env = 0;
+#endif
+  args.dbg = dbg_env;
+  const dim3 grid((unsigned)(per_xcd * 8)), block(NTHREADS);
+  const size_t lds = 2 * BUF_ELEMS * sizeof(T) + 3 * STAGE_ROWS * sizeof(int64_t);
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+#define CVM_LAUNCH(W, GA, AL)                                                                 \
+  do {                                                                                     \
+    static unsigned long long attr_done = 0;   /* one bit per device */                   \
+    if (!((attr_done >> (dev & 63)) & 1ull)) {                                             \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram_kernel<T, W, GA, AL>,                 \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+      attr_done |= 1ull << (dev & 63);                                                     \
+    }                                                                                      \
+    hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL>), grid, block, lds, st, args);          \
+  } while (0)
+  TimedLaunch *tl = nullptr;
+  if (g_timing && g_ntimed < 8192) {
+    tl = &g_timed[g_ntimed];
+    if (!tl->a) { HIP_OK(hipEventCreate(&tl->a)); HIP_OK(hipEventCreate(&tl->b)); }
+    tl->kind = g_timing_kind;
+    HIP_OK(hipEventRecord(tl->a, st));
+  }
+  constexpr bool CAN_DMA = sizeof(T) == 8;
+  const bool fast = wgram4_ok<T>(a, aligned) && !(dbg_env & 16);
+  if (fused && !(fast && gather)) return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
+  if (fast) {
+    if constexpr (CAN_DMA) {
+      const dim3 block4(NT4);
+#define CVM_LAUNCH4(W, GA)                                                                  \
+  do {                                                                                      \
+    static unsigned long long attr_done = 0;                                                \
+    if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<W, GA>,                        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4_BYTES)); \
+      attr_done |= 1ull << (dev & 63);                                                      \
+    }                                                                                       \
+    hipLaunchKernelGGL((wgram4_kernel<W, GA>), grid, block4, LDS4_BYTES, st, args);         \
+  } while (0)
+      if (fused) {
+#define CVM_LAUNCH4F(W)                                                                     \
+  do {                                                                                      \
+    static unsigned long long attr_done = 0;                                                \
+    if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<W, true, true>,                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4_BYTES)); \
+      attr_done |= 1ull << (dev & 63);                                                      \
+    }                                                                                       \
+    hipLaunchKernelGGL((wgram4_kernel<W, true, true>), grid, block4, LDS4_BYTES, st, args); \
+  } while (0)
+        if (weighted) CVM_LAUNCH4F(true); else CVM_LAUNCH4F(false);
+#undef CVM_LAUNCH4F
+      } else if (weighted) { if (gather) CVM_LAUNCH4(true, true); else CVM_LAUNCH4(true, false); }
+      else { if (gather) CVM_LAUNCH4(false, true); else CVM_LAUNCH4(false, false); }
+#undef CVM_LAUNCH4
+    }
+  } else if (weighted) {
+    if (gather) { if (aligned) CVM_LAUNCH(true, true, true); else CVM_LAUNCH(true, true, false); }
+    else { if (aligned) CVM_LAUNCH(true, false, true); else CVM_LAUNCH(true, false, false); }
+  } else {
+    if (gather) { if (aligned) CVM_LAUNCH(false, true, true); else CVM_LAUNCH(false, true, false); }
+    else { if (aligned) CVM_LAUNCH(false, false, true); else CVM_LAUNCH(false, false, false); }
+  }
+#undef CVM_LAUNCH
+  if (tl) { HIP_OK(hipEventRecord(tl->b, st)); ++g_ntimed; }
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+
+bool rows_aligned(const void *X, int K, int esize) {
+  return ((uintptr_t)X % 16 == 0) && (((size_t)K * esize) % 16 == 0);
+}
+
+template <typename T>
+int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
+                  void *G, void *H, double *gstats, int32_t *neg_flag, void *ws, size_t ws_bytes,
+                  hipStream_t st) {
+  Plan p;
+  int rc = make_plan(1, N, K, M, dtype, CVM_RET_XTX | CVM_RET_XTY, ws_bytes, false, p);
+  if (rc != CVM_OK) return fail(rc, "cvm_gram_fit: workspace too small%s");
+  WgramArgs<T> a;
+  memset(&a, 0, sizeof(a));
+  a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+  a.idx = nullptr; a.offs = nullptr; a.N = N; a.seg0 = 0;
+  a.n_seg = 1; a.splits = p.splits; a.g = p.g;
+  a.n_items = (long)p.splits * p.g.nT; a.items_per_xcd = 0;
+  a.ws = (char *)ws;
+  g_timing_kind = 0;
+  rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st);
+  if (rc != CVM_OK) return rc;
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = p.g; f.splits = p.splits; f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
+  f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
+  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
+  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
+                     dim3(APPLY_THREADS), 0, st, f);
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+
+template <typename T>
+int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
+                    int64_t n_folds, int K, int M, unsigned flags, double ddof, double resolution,
+                    const void *G, const void *H, const double *gstats, void *out_XTX, void *out_XTY,
+                    void *out_muX, void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
+                    void *ws, size_t ws_bytes, hipStream_t st) {
+  const size_t per_fold = fstat_len(K, M) * 8;
+  int64_t nb_max = (int64_t)(ws_bytes / per_fold);
+  if (nb_max < 1) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
+  if (nb_max > 32768) nb_max = 32768;   // grid.y
+  SmallArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = X; a.Y = Y; a.w = w; a.idx = idx; a.offs = offsets; a.K = K; a.M = M;
+  a.G = G; a.H = H; a.gstats = gstats; a.fstats = (double *)ws;
+  a.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
+  a.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
+  a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY;
+  a.out_fold = out_fold; a.ddof = ddof; a.resolution = resolution; a.flags = flags;
+  a.P64 = (K + ST - 1) / ST; a.nT64 = a.P64 * (a.P64 + 1) / 2;
+  for (int64_t f0 = 0; f0 < n_folds; f0 += nb_max) {
+    const int64_t nb = (n_folds - f0 < nb_max) ? n_folds - f0 : nb_max;
+    a.seg0 = f0;
+    const dim3 gs((unsigned)nb), ga((unsigned)(a.nT64 + a.P64), (unsigned)nb);
+    if (w) {
+      hipLaunchKernelGGL((small_stats_kernel<T, true>), gs, dim3(256), 0, st, a);
+      if (a.out_XTX || a.out_XTY) hipLaunchKernelGGL((small_apply_kernel<T, true>), ga, dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((small_stats_kernel<T, false>), gs, dim3(256), 0, st, a);
+      if (a.out_XTX || a.out_XTY) hipLaunchKernelGGL((small_apply_kernel<T, false>), ga, dim3(256), 0, st, a);
+    }
+    HIP_OK(hipGetLastError());
+  }
+  return CVM_OK;
+}
+
+// statistics-only fold stage: colstats_kernel + fold_stats_kernel, no Gram launch
+template <typename T>
+int fold_statistics_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
+                         const int64_t *offsets, int64_t n_folds, int64_t max_rows, int K, int M,
+                         unsigned flags, double ddof, double resolution, const double *gstats,
+                         void *out_muX, void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
+                         void *ws, size_t ws_bytes, hipStream_t st) {
+  Geom g = make_geom(K, M, sizeof(T), 1);
+  g.tile_elems = 0; g.h_elems = 0;
+  g.unit_bytes = align_up(g.stat_len * 8, 256);
+  const size_t fst = align_up(fstat_len(K, M) * 8, 256);
+  // rows per unit: short enough for >1000 workgroups in flight at the benchmark shapes, long
+  // enough that the units' statistics vectors stay a few per cent of the bytes streamed
+  int64_t splits = (max_rows + CVM_COL_ROWS - 1) / CVM_COL_ROWS;
+  if (splits < 1) splits = 1;
+  if (splits > 1024) splits = 1024;
+  while (splits > 1 && (size_t)splits * g.unit_bytes + fst > ws_bytes) splits /= 2;
+  const size_t per_fold = (size_t)splits * g.unit_bytes + fst;
+  if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
+  int64_t per_batch = (int64_t)(ws_bytes / per_fold);
+  if (per_batch > 32768) per_batch = 32768;
+  const bool aligned = rows_aligned(X, K, sizeof(T));
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nxb = (K + COL_THREADS * VEC - 1) / (COL_THREADS * VEC);
+  for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
+    const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
+    ColArgs c;
+    c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0; c.splits = (int)splits;
+    c.g = g; c.ws = (char *)ws;
+    const dim3 grid((unsigned)(nxb + 1), (unsigned)(nb * splits));
+    if (w) {
+      if (aligned) hipLaunchKernelGGL((colstats_kernel<T, true, true>), grid, dim3(COL_THREADS), 0, st, c);
+      else hipLaunchKernelGGL((colstats_kernel<T, true, false>), grid, dim3(COL_THREADS), 0, st, c);
+    } else {
+      if (aligned) hipLaunchKernelGGL((colstats_kernel<T, false, true>), grid, dim3(COL_THREADS), 0, st, c);
+      else hipLaunchKernelGGL((colstats_kernel<T, false, false>), grid, dim3(COL_THREADS), 0, st, c);
+    }
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.g = g; f.splits = (int)splits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
+    f.fstats = (double *)((char *)ws + (size_t)nb * splits * g.unit_bytes);
+    f.offs = offsets; f.w = w; f.gstats = gstats;
+    f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+    f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+    hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)), dim3(256), 0, st, f);
+    HIP_OK(hipGetLastError());
+  }
+  return CVM_OK;
+}
+
+template <typename T>
+int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
+                     const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                     int K, int M, int dtype, unsigned flags, double ddof, double resolution,
+                     const void *G, const void *H, const double *gstats, void *out_XTX,
+                     void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                     double *out_fold, void *ws, size_t ws_bytes, hipStream_t st) {
+  int64_t max_rows = 0;
+  for (int64_t f = 0; f < n_folds; ++f) {
+    const int64_t n = host_offsets[f + 1] - host_offsets[f];
+    if (n < 0) return fail(CVM_EINVAL, "cvm_fold_update: offsets must be non-decreasing%s");
+    if (n > max_rows) max_rows = n;
+  }
+  if (max_rows <= SMALL_ROWS)
+    return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, K, M, flags, ddof, resolution, G, H, gstats,
+                              out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
+  const bool want_xtx = (flags & CVM_RET_XTX) && out_XTX, want_xty = (flags & CVM_RET_XTY) && out_XTY;
+  if (!want_xtx && !want_xty)   // statistics only: stream the rows once, no Gram launch
+    return fold_statistics_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution,
+                                   gstats, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
+  Plan p;
+  // (planned against an unlimited workspace first: the fused route below needs far less than
+  //  the partials the general route plans for)
+  int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, (size_t)1 << 60, true, p);
+  const bool aligned = rows_aligned(X, K, sizeof(T));
+  {
+    // Folds too small to be split over workgroups (one unit per fold): finish in the Gram
+    // kernel's epilogue instead of writing partials for apply_kernel to read back.  The fold
+    // statistics the epilogue needs come from the streaming kernel first.
+    static const bool no_fused = getenv("CVM_NO_FUSED") && atoi(getenv("CVM_NO_FUSED")) != 0;
+    WgramArgs<T> probe;
+    memset(&probe, 0, sizeof(probe));
+    probe.Y = (const T *)Y; probe.w = (const T *)w; probe.g = p.g;
+    if (p.splits == 1 && want_xtx && !no_fused && wgram4_ok<T>(probe, aligned)) {
+      Geom gs = make_geom(K, M, sizeof(T), 1);
+      gs.tile_elems = 0; gs.h_elems = 0;
+      gs.unit_bytes = align_up(gs.stat_len * 8, 256);
+      const size_t fst = align_up(fstat_len(K, M) * 8, 256);
+      int64_t csplits = (max_rows + CVM_COL_ROWS - 1) / CVM_COL_ROWS;
+      if (csplits < 1) csplits = 1;
+      while (csplits > 1 && (size_t)csplits * gs.unit_bytes + fst > ws_bytes) csplits /= 2;
+      const size_t per_fold = (size_t)csplits * gs.unit_bytes + fst;
+      if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
+      int64_t per_batch = (int64_t)(ws_bytes / per_fold);
+      if (per_batch > 16384) per_batch = 16384;
+      constexpr int VEC = 16 / (int)sizeof(T);
+      const int nxb = (K + COL_THREADS * VEC - 1) / (COL_THREADS * VEC);
+      for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
+        const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
+        ColArgs c;
+        c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0; c.splits = (int)csplits;
+        c.g = gs; c.ws = (char *)ws;
+        const dim3 cgrid((unsigned)(nxb + 1), (unsigned)(nb * csplits));
+        if (w) hipLaunchKernelGGL((colstats_kernel<T, true, true>), cgrid, dim3(COL_THREADS), 0, st, c);
+        else hipLaunchKernelGGL((colstats_kernel<T, false, true>), cgrid, dim3(COL_THREADS), 0, st, c);
+        FinArgs f;
+        memset(&f, 0, sizeof(f));
+        f.g = gs; f.splits = (int)csplits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
+        f.fstats = (double *)((char *)ws + (size_t)nb * csplits * gs.unit_bytes);
+        f.offs = offsets; f.w = w; f.gstats = gstats;
+        f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+        f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+        hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)),
+                           dim3(256), 0, st, f);
+        WgramArgs<T> a;
+        memset(&a, 0, sizeof(a));
+        a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+        a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
+        a.n_seg = (int)nb; a.splits = 1; a.g = p.g;
+        a.n_items = (long)nb * p.g.nT; a.items_per_xcd = 0;
+        a.ws = nullptr;
+        a.fstats = f.fstats; a.G = G; a.H = H;
+        a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
+        g_timing_kind = 1;
+        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, true);
+        if (rc != CVM_OK) return rc;
+      }
+      return CVM_OK;
+    }
+  }
+  rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
+  if (rc != CVM_OK) return fail(rc, "cvm_fold_update: workspace cannot hold one fold%s");
+  for (int64_t f0 = 0; f0 < n_folds; f0 += p.folds_per_batch) {
+    const int64_t nb = (n_folds - f0 < p.folds_per_batch) ? n_folds - f0 : p.folds_per_batch;
+    char *units = (char *)ws;
+    double *fstats = (double *)((char *)ws + (size_t)nb * p.splits * p.g.unit_bytes);
+    WgramArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+    a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
+    a.n_seg = (int)nb; a.splits = p.splits; a.g = p.g;
+    a.n_items = (long)nb * p.splits * p.g.nT; a.items_per_xcd = 0;
+    a.ws = units;
+    g_timing_kind = 1;
+    rc = launch_wgram<T>(a, w != nullptr, true, aligned, st);
+    if (rc != CVM_OK) return rc;
+    FinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.g = p.g; f.splits = p.splits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = units;
+    f.fstats = (double *)((char *)fstats);
+    f.offs = offsets; f.w = w; f.G = G; f.H = H; f.gstats = gstats;
+    f.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
+    f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
+    f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+    f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+    // fstats rows are fstat_len doubles apart inside the 256-byte aligned slots? keep dense
+    hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)), dim3(256), 0, st, f);
+    if (f.out_XTX || f.out_XTY) {
+      hipLaunchKernelGGL((apply_kernel<T, true>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, (unsigned)nb),
+                         dim3(APPLY_THREADS), 0, st, f);
+    }
+    HIP_OK(hipGetLastError());
+  }
+  return CVM_OK;
+}
+
+// One-sweep cross-validation: when the folds partition the rows, the
+// full-data matrices are the ordered sum of the folds' validation matrices, G = sum_f G_Vf.
+// sweep_fit runs the Gram kernel ONCE over all folds (gathered), sums every unit's partials
+// into G, H, gstats and leaves the partials in the workspace; sweep_folds then only runs
+// the finalize kernels on them.  Half the flops of fit + fold update.
+template <typename T>
+int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
+                   const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                   int K, int M, int dtype, void *G, void *H, double *gstats, int32_t *neg_flag,
+                   void *ws, size_t ws_bytes, hipStream_t st, int64_t *splits_out) {
+  int64_t max_rows = 0;
+  for (int64_t f = 0; f < n_folds; ++f) {
+    const int64_t n = host_offsets[f + 1] - host_offsets[f];
+    if (n < 0) return fail(CVM_EINVAL, "cvm_sweep_fit: offsets must be non-decreasing%s");
+    if (n > max_rows) max_rows = n;
+  }
+  if (host_offsets[n_folds] - host_offsets[0] != N)
+    return fail(CVM_EINVAL, "cvm_sweep_fit: the folds must cover each of the N rows exactly once%s");
+  Plan p;
+  const unsigned flags = CVM_RET_XTX | CVM_RET_XTY;
+  int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
+  if (rc != CVM_OK || p.folds_per_batch < n_folds)
+    return fail(CVM_EWORKSPACE, "cvm_sweep_fit: the workspace must hold the partials of all folds%s");
+  WgramArgs<T> a;
+  memset(&a, 0, sizeof(a));
+  a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+  a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = 0;
+  a.n_seg = (int)n_folds; a.splits = p.splits; a.g = p.g;
+  a.n_items = (long)n_folds * p.splits * p.g.nT; a.items_per_xcd = 0;
+  a.ws = (char *)ws;
+  g_timing_kind = 1;
+  rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st);
+  if (rc != CVM_OK) return rc;
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = p.g; f.splits = (int)(n_folds * p.splits);   // every unit of every fold, fold-major
+  f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
+  f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
+  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
+  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
+                     dim3(APPLY_THREADS), 0, st, f);
+  HIP_OK(hipGetLastError());
+  if (splits_out) *splits_out = p.splits;
+  return CVM_OK;
+}
+
+template <typename T>
+int sweep_folds_impl(const int64_t *offsets, int64_t n_folds, int K, int M, int dtype, unsigned flags,
+                     double ddof, double resolution, int weighted, const void *G, const void *H,
+                     const double *gstats, void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX,
+                     void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
+                     int64_t splits, hipStream_t st) {
+  const Geom g = make_geom(K, M, sizeof(T), 0);
+  const size_t units = (size_t)n_folds * (size_t)splits * g.unit_bytes;
+  if (units + (size_t)n_folds * fstat_len(K, M) * 8 > ws_bytes)
+    return fail(CVM_EWORKSPACE, "cvm_sweep_folds: workspace smaller than the one cvm_sweep_fit filled%s");
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = g; f.splits = (int)splits; f.n_seg = (int)n_folds; f.seg0 = 0; f.ws = (const char *)ws;
+  f.fstats = (double *)((char *)ws + units);
+  f.offs = offsets; f.w = weighted ? (const void *)G : nullptr;   // non-null = weighted
+  f.G = G; f.H = H; f.gstats = gstats;
+  f.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
+  f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
+  f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+  f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+  hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)n_folds, (unsigned)fold_stats_chunks(K, M, n_folds)), dim3(256), 0, st, f);
+  if (f.out_XTX || f.out_XTY)
+    hipLaunchKernelGGL((apply_kernel<T, true>), dim3(g.nTiles * APPLY_SUB + g.P, (unsigned)n_folds),
+                       dim3(APPLY_THREADS), 0, st, f);
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}

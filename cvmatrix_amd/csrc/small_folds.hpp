@@ -1,0 +1,201 @@
+// small_folds.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
+// Direct HBM-bound kernels for folds of at most 32 rows.
+#pragma once
+
+// ----------------------------------------------------------------------------------
+// Small folds (at most SMALL_ROWS validation rows: leave-one-out and its neighbours).
+// The Gram of a handful of rows is no MFMA problem: the fold update is a stream over
+// K x (K+M) outputs (read G, H once, write XTX, XTY once) -- HBM-bound.  Two kernels, no
+// partials in between:
+//   small_stats_kernel  column sums of the fold's rows, sequential in row order for sw, sX,
+//                       qX, sY, qY alike (constant-one columns stay exact), then the same
+//                       mean / std arithmetic as fold_stats_kernel
+//   small_apply_kernel  one 64x64 upper tile per workgroup: the fold's rows (A side weighted)
+//                       go to LDS, every thread accumulates a 4x4 block of the rank-n update
+//                       in float64, applies total - update, centring and scaling in the
+//                       reference's order (cvmatrix.py:1001-1010) and the tile is written
+//                       twice -- as is and transposed through LDS -- with coalesced stores.
+// ----------------------------------------------------------------------------------
+constexpr int SMALL_ROWS = 32;
+struct SmallArgs {
+  const void *X, *Y, *w;
+  const int64_t *idx, *offs;
+  int64_t seg0;
+  int K, M;
+  const void *G, *H;
+  const double *gstats;
+  double *fstats;                      // [fold of batch][fstat_len]
+  void *out_XTX, *out_XTY, *out_muX, *out_sdX, *out_muY, *out_sdY;
+  double *out_fold;
+  double ddof, resolution;
+  unsigned flags;
+  int P64, nT64;
+};
+
+template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_stats_kernel(const SmallArgs a) {
+  const int f = blockIdx.x;
+  const int K = a.K, M = a.M;
+  const int64_t o0 = a.offs[a.seg0 + f];
+  const int n = (int)(a.offs[a.seg0 + f + 1] - o0);
+  const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
+  __shared__ int64_t rows[SMALL_ROWS];
+  __shared__ double wl[SMALL_ROWS];
+  if (threadIdx.x < n) {
+    const int64_t r = a.idx[o0 + threadIdx.x];
+    rows[threadIdx.x] = r;
+    wl[threadIdx.x] = WEIGHTED ? (double)W[r] : 1.0;
+  }
+  __syncthreads();
+  double swv = 0, nzv = 0;
+  for (int r = 0; r < n; ++r) { swv += wl[r]; nzv += (wl[r] != 0.0) ? 1.0 : 0.0; }
+  const double gsw = a.gstats[2 * K + 2 * M], gnz = a.gstats[2 * K + 2 * M + 1];
+  const double swt = gsw - swv, nzt = gnz - nzv;
+  const double divisor = (nzt - a.ddof) * swt / nzt;
+  double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
+    fs[2 * K + 2 * M] = swt;
+    if (a.out_fold) {
+      double *o = a.out_fold + 4 * (a.seg0 + f);
+      o[0] = swt; o[1] = nzt; o[2] = swv; o[3] = nzv;
+    }
+  }
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const bool rXTY = a.flags & CVM_RET_XTY;
+  const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
+  const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < K + M; c += gridDim.y * blockDim.x) {
+    const bool isX = c < K;
+    const int cc = isX ? c : c - K;
+    if (isX ? !(want_muX) : !(want_muY)) continue;
+    double sv = 0, qv = 0;
+    for (int r = 0; r < n; ++r) {
+      const T xv = isX ? X[rows[r] * (int64_t)K + cc] : Y[rows[r] * (int64_t)M + cc];
+      if (sizeof(T) == 8) {
+        const T pv = WEIGHTED ? (T)((T)wl[r] * xv) : xv;
+        sv += (double)pv; qv += (double)(pv * xv);
+      } else {
+        const double pv = wl[r] * (double)xv;
+        sv += pv; qv += pv * (double)xv;
+      }
+    }
+    const double gs = isX ? a.gstats[cc] : a.gstats[2 * K + cc];
+    const double gq = isX ? a.gstats[K + cc] : a.gstats[2 * K + M + cc];
+    const double st_ = gs - sv;          // cvmatrix.py:1020
+    const double mu = st_ / swt;         // cvmatrix.py:1043
+    double sd = 1.0;
+    if (isX ? want_sdX : want_sdY) {
+      const double qt = gq - qv;
+      double var = (-2 * mu * st_ + swt * (mu * mu) + qt) / divisor;   // 1119-1123
+      var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
+      sd = sqrt(var);
+      if (sd <= a.resolution) sd = 1.0;  // 1128
+    }
+    fs[isX ? cc : 2 * K + cc] = mu;
+    fs[isX ? K + cc : 2 * K + M + cc] = sd;
+    T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
+    const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
+    if (omu) omu[o] = (T)mu;
+    if (osd && (isX ? want_sdX : want_sdY)) osd[o] = (T)sd;
+  }
+}
+
+template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_apply_kernel(const SmallArgs a) {
+  const int f = blockIdx.y;
+  const int x = blockIdx.x;
+  const int K = a.K, M = a.M;
+  const int tid = threadIdx.x;
+  const int64_t o0 = a.offs[a.seg0 + f];
+  const int n = (int)(a.offs[a.seg0 + f + 1] - o0);
+  const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
+  const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+  const double swt = fs[2 * K + 2 * M];
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const size_t fo = (size_t)(a.seg0 + f);
+  // As: w * x, columns of the tile's rows; Bs: x (or y), columns of the tile's columns;
+  // Ts: the finished tile for the transposed store -- it reuses the As/Bs space (33 KB per
+  // workgroup instead of 66: four workgroups per CU keep more loads and stores in flight)
+  __shared__ __attribute__((aligned(16))) double sm[ST * (ST + 1)];
+  double (*As)[ST] = reinterpret_cast<double (*)[ST]>(sm);
+  double (*Bs)[ST] = reinterpret_cast<double (*)[ST]>(sm + SMALL_ROWS * ST);
+  double (*Ts)[ST + 1] = reinterpret_cast<double (*)[ST + 1]>(sm);
+  __shared__ int64_t rows[SMALL_ROWS];
+  __shared__ double wl[SMALL_ROWS];
+  if (tid < n) {
+    const int64_t r = a.idx[o0 + tid];
+    rows[tid] = r;
+    wl[tid] = WEIGHTED ? (double)W[r] : 1.0;
+  }
+  __syncthreads();
+  if (x < a.nT64) {
+    if (!a.out_XTX) return;
+    int ti, tj;
+    decode_tile(x, a.P64, ti, tj);
+    const int a0 = ti * ST, b0 = tj * ST;
+    const int ty = tid >> 4, tx = tid & 15;      // rows 4ty.., columns 4tx..
+    for (int e = tid; e < n * ST; e += 256) {
+      const int r = e / ST, c = e - r * ST;
+      const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
+      const T xb = (b0 + c < K) ? X[rows[r] * (int64_t)K + b0 + c] : (T)0;
+      As[r][c] = (sizeof(T) == 8) ? (double)(WEIGHTED ? (T)((T)wl[r] * xa) : xa) : wl[r] * (double)xa;
+      Bs[r][c] = (double)xb;
+    }
+    __syncthreads();
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    for (int r = 0; r < n; ++r) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = As[r][4 * ty + i]; bv[i] = Bs[r][4 * tx + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+    __syncthreads();   // every thread is done with As/Bs: Ts may overwrite them
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
+    __syncthreads();
+    T *out = (T *)a.out_XTX + fo * (size_t)K * K;
+    finish_store_tile<T, true>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256);
+  } else {
+    if (!a.out_XTY || M == 0) return;
+    const int ti = x - a.nT64;
+    const int a0 = ti * ST;
+    const T *Ht = (const T *)a.H;
+    T *out = (T *)a.out_XTY + fo * (size_t)K * M;
+    for (int e = tid; e < n * ST; e += 256) {
+      const int r = e / ST, c = e - r * ST;
+      const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
+      As[r][c] = (sizeof(T) == 8) ? (double)(WEIGHTED ? (T)((T)wl[r] * xa) : xa) : wl[r] * (double)xa;
+    }
+    for (int m0 = 0; m0 < M; m0 += ST) {
+      __syncthreads();
+      for (int e = tid; e < n * ST; e += 256) {
+        const int r = e / ST, c = e - r * ST;
+        Bs[r][c] = (m0 + c < M) ? (double)Y[rows[r] * (int64_t)M + m0 + c] : 0.0;
+      }
+      __syncthreads();
+      const int mw = (M - m0 < ST) ? M - m0 : ST;
+      for (int e = tid; e < ST * mw; e += 256) {
+        const int la = e / mw, lm = e - la * mw;
+        const int ga = a0 + la, gm = m0 + lm;
+        if (ga >= K) continue;
+        double acc = 0;
+        for (int r = 0; r < n; ++r) acc += As[r][la] * Bs[r][lm];
+        double v = (double)Ht[(size_t)ga * M + gm] - acc;
+        if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + gm]);
+        if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + gm]);
+        else if (sX) v = v / fs[K + ga];
+        else if (sY) v = v / fs[2 * K + M + gm];
+        out[(size_t)ga * M + gm] = (T)v;
+      }
+    }
+  }
+}

@@ -1,0 +1,551 @@
+// wgram4.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
+// wgram4_kernel: the float64 LDS-DMA Gram kernel (4 compute + 4 loader waves), with the fused
+// single-split epilogue.
+#pragma once
+
+// ----------------------------------------------------------------------------------
+// wgram4_kernel: the fast path (float64, 16-byte aligned rows, even M).
+//
+// Same work decomposition, LDS stage image and partial layout as wgram_kernel, but the
+// eight waves of a workgroup (one workgroup per CU) are specialised:
+//   waves 0-3  COMPUTE, one per SIMD.  Wave (wr,wc) owns the 64x64 block (wr,wc) of the
+//              128x128 tile: 4x4 MFMA tiles, 16 accumulators (128 VGPRs), 16 MFMAs per 8
+//              LDS fragment reads.  They never touch global memory inside the loop, so no
+//              vector-memory instruction ever blocks their issue (a 1 KiB load costs its
+//              wave 200-450 cycles of issue on a busy CU: tools/dma_issue.hip).
+//              On a diagonal tile the strictly-lower block (1,0) is not computed; its wave
+//              (the "H wave") computes panel_i^T W Y[:, 32c..32c+32) (8x2 MFMA tiles).
+//              Waves 0 and 3 also sum the X columns of their A fragments, wave 1 (panel 0)
+//              the Y columns, sw and nz -- on the VALU, in the shadow of their MFMAs.
+//   waves 4-7  LOADERS.  Loader d owns stage rows d, d+4, d+8, d+12 and moves, per row, the
+//              X panel rows, the Y tile row (diagonal tiles) and the weight global -> LDS
+//              by LDS-DMA (global_load_lds: one wave instruction = one 1 KiB panel row,
+//              gathered by row number; rows past the end read a zero line).  They run
+//              THREE stages ahead of the compute waves through a ring of four LDS stage
+//              buffers behind a hand-counted s_waitcnt vmcnt, and contain no VALU
+//              instruction at all (see the loader section for why).
+// One s_barrier per 16-row stage joins all eight waves.
+// ----------------------------------------------------------------------------------
+constexpr int NT4 = 512;
+constexpr int NBUF4 = 4;        // LDS stage buffers
+constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;
+
+// The body is instantiated once per wave role and kept out of line: inlined together, the
+// register allocator has to give all roles one common assignment of the 128 accumulator
+// registers and spills hundreds of values; as separate functions every role fits.
+//   ROLER 0/1/2: compute wave without sums / with X column sums / with Y column sums
+//   ROLER 3: loader wave
+__host__ __device__ inline size_t fstat_len(int K, int M);
+__device__ __forceinline__ void fused_finish_block(double (*Ts)[65], const double *rs, bool diagb, int a0,
+                                                   int b0, int K, const double *Gt, double *out,
+                                                   double swt, bool cX, bool sX, int lane);
+constexpr int WAVE_LDS_DOUBLES = 64 * 65 + 256;   // a wave's 64x64 block + row/column means and stds
+
+template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
+__device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
+  typedef double T;
+  typedef MF<double>::acc_t acc_t;
+#ifdef CVM_STAMPS
+  const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
+#endif
+  const WgramArgs<double> a = scalarize(a_ref);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const Geom &g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all & 3;
+
+  const long b = blockIdx.x;
+  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
+  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+  const long u = item / g.nT;
+  const int it = (int)(item - u * g.nT);
+  const int seg = (int)(u / a.splits);
+  const int sp = (int)(u - (long)seg * a.splits);
+  int ti, tj, yc;
+  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
+  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
+  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  const bool diag = (ti == tj);
+  const int wr = wave >> 1, wc = wave & 1;
+  const bool h_wave = diag && wave == 2;
+  const bool do_g = !g.diag_only && yc == 0;
+
+  int64_t seg_begin, seg_rows;
+  if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
+  else { seg_begin = 0; seg_rows = a.N; }
+  int64_t r0, r1;
+  split_range(seg_rows, a.splits, sp, r0, r1);
+  // wave-uniform by construction; the 64-bit division above runs on the VALU, so say so
+  r0 = uni64(r0); r1 = uni64(r1); seg_begin = uni64(seg_begin);
+  const int nstages = uni((int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS));
+  const int colA0 = uni(ti * TILE), colB0 = uni(tj * TILE);
+
+  if (ROLER == 3) {
+    // ---- loader waves 4..7 ----------------------------------------------------------------
+    // Loader d owns stage rows d, d+4, d+8, d+12 and issues, per row, three LDS-DMA
+    // instructions: the X panel A row (1 KiB), the X panel B row (off-diagonal tile) or the
+    // Y tile row (diagonal tile, 16 lanes), and the row's weight (2 lanes x 4 B): exactly 12
+    // per stage, whatever the tile.  Everything per piece is SCALAR (row number by s_load,
+    // row base by SALU, LDS address in M0) plus a loop-invariant per-lane VGPR offset: while
+    // the compute wave of the same SIMD streams f64 MFMAs a VALU instruction of another
+    // wave waits up to a whole MFMA (64 cycles) for an issue slot (measured: 580 cycles per
+    // piece with ~8 VALU instructions in it, 180 without the MFMAs running).  The loads are
+    // inline asm (saddr form) so that no vector instruction and no compiler-chosen wait
+    // enters the loop and the vmcnt count below is exact.
+    // Columns past K (or M) are clamped to the last valid pair: they only feed output
+    // columns >= K that nothing reads.  Rows past the end read a zero line.
+    const int d = wave_all - 4;
+    const char *zero_src = reinterpret_cast<const char *>(unip(g_zero_line));
+    const char *one_src = reinterpret_cast<const char *>(unip(g_one_line));
+    int oa = 2 * lane, ob = 2 * lane, oy = 2 * (lane & 15);
+    if (colA0 + oa > g.K - 2) oa = g.K - 2 - colA0;
+    if (colB0 + ob > g.K - 2) ob = g.K - 2 - colB0;
+    if (oa < 0) oa = 0;
+    if (ob < 0) ob = 0;
+    const int ycol0 = yc * YT;
+    if (g.M > 0) { if (ycol0 + oy > g.M - 2) oy = g.M - 2 - ycol0; if (oy < 0) oy = 0; } else oy = 0;
+    const unsigned va = 8u * (unsigned)oa, vb = 8u * (unsigned)ob, vy = 8u * (unsigned)oy, vw = 4u * (unsigned)lane;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem_raw);
+    auto dma16_all = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma16_lo16 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep; unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma4_lo2 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep; unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dword %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    // wave-uniform row numbers of stage t, row slots d + 4j.  Gathered ones come by four
+    // scalar loads in ONE asm statement that also waits for them (an asm load's destination
+    // counts as written when the statement ends; a later, separate wait would let the
+    // compiler copy the registers before the data has landed).
+    // (32-bit row positions: a 64-bit compare would be a VALU instruction, and a VALU
+    //  instruction of this wave waits ~700 cycles for a slot between the other wave's MFMAs:
+    //  tools/dma_vs_mfma.hip)
+    const int r0i = uni((int)r0), r1i = uni((int)r1);
+    auto row_numbers = [&](int t, int64_t (&rn)[4], bool (&ok)[4]) {
+      int rr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rr[j] = r0i + t * STAGE_ROWS + d + 4 * j;
+        ok[j] = rr[j] < r1i;
+      }
+      if (!GATHER) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rn[j] = seg_begin + rr[j];
+        return;
+      }
+      const int64_t *p0 = a.idx + seg_begin + (ok[0] ? rr[0] : 0);
+      const int64_t *p1 = a.idx + seg_begin + (ok[1] ? rr[1] : 0);
+      const int64_t *p2 = a.idx + seg_begin + (ok[2] ? rr[2] : 0);
+      const int64_t *p3 = a.idx + seg_begin + (ok[3] ? rr[3] : 0);
+      int64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+      if (r1i > 0) {   // (segment not empty: the clamped addresses are valid)
+        asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\t"
+                     "s_load_dwordx2 %2, %6, 0x0\n\ts_load_dwordx2 %3, %7, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3)
+                     : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
+      }
+      rn[0] = v0; rn[1] = v1; rn[2] = v2; rn[3] = v3;
+    };
+    auto issue_stage = [&](int t, const int64_t (&rn)[4], const bool (&ok)[4]) {
+      const unsigned bufb = lds0 + (unsigned)((t % NBUF4) * BUF_ELEMS) * 8u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lrow = d + 4 * j;
+        const bool valid = ok[j];
+        const char *xrow = reinterpret_cast<const char *>(a.X + rn[j] * (int64_t)g.K);
+        dma16_all(valid ? xrow + 8 * (int64_t)colA0 : zero_src, va, bufb + (unsigned)(lrow * PITCH) * 8u);
+        if (!diag) {
+          dma16_all(valid ? xrow + 8 * (int64_t)colB0 : zero_src, vb,
+                    bufb + (unsigned)(PANEL_ELEMS + lrow * PITCH) * 8u);
+        } else {
+          const char *yrow = (valid && g.M > 0)
+              ? reinterpret_cast<const char *>(a.Y + rn[j] * (int64_t)g.M + ycol0) : zero_src;
+          dma16_lo16(yrow, vy, bufb + (unsigned)(PANEL_ELEMS + lrow * YPITCH) * 8u);
+        }
+        const char *wsrc = valid ? (WEIGHTED ? reinterpret_cast<const char *>(a.w + rn[j]) : one_src) : zero_src;
+        dma4_lo2(wsrc, vw, bufb + (unsigned)(2 * PANEL_ELEMS + lrow) * 8u);
+      }
+    };
+    // 12 LDS-DMA instructions per stage; ONE stage may stay in flight across a barrier, so
+    // that at barrier B_s stage s+2 is in LDS: the compute waves may then read the first
+    // fragments of stage s+1 before they reach B_s
+    auto wait_one_stage_in_flight = [&]() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); };
+    int64_t rn[4];
+    bool ok[4];
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      row_numbers(t, rn, ok);
+      issue_stage(t, rn, ok);
+    }
+    wait_one_stage_in_flight();                       // stages 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();                     // B_a (two barriers in every role's prologue)
+    __builtin_amdgcn_s_barrier();                     // B_-1
+#ifdef CVM_STAMPS
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
+#endif
+#pragma unroll 1
+    for (int s = 0; s < nstages; ++s) {
+#ifdef CVM_STAMPS
+      STAMP(t0);
+#endif
+      row_numbers(s + 3, rn, ok);
+      issue_stage(s + 3, rn, ok);                     // buffer (s+3)%4 was last read in stage s-1
+#ifdef CVM_STAMPS
+      STAMP(t1);
+#endif
+      wait_one_stage_in_flight();                     // stage s+2 has landed
+#ifdef CVM_STAMPS
+      STAMP(t2);
+#endif
+#ifdef CVM_STAMPS
+      if (!(a.dbg & 4))
+#endif
+      __builtin_amdgcn_s_barrier();                   // B_s
+#ifdef CVM_STAMPS
+      STAMP(t3);
+      t_a += t1 - t0; t_b += t2 - t1; t_c += t3 - t2;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing in flight at wave exit
+    if (FUSEDR) __builtin_amdgcn_s_barrier();       // the compute waves reuse the ring in their epilogue
+#ifdef CVM_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave_all) * 4;
+      o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = (unsigned long long)nstages;
+    }
+#endif
+    return;
+  }
+
+  // ---- compute waves ----------------------------------------------------------------------
+  const int stat_role = ROLER;
+  acc_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (acc_t){0, 0, 0, 0};
+  double st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};
+
+  const int lk = lane >> 4, lc = lane & 15;
+  const int a_col = h_wave ? 0 : 64 * wr;
+  const int b_col = h_wave ? 0 : 64 * wc;
+  const int a_off = a_col + lc;
+  const int b_off = h_wave ? PANEL_ELEMS + lc : (diag ? 0 : PANEL_ELEMS) + b_col + lc;
+
+  __syncthreads();   // B_a
+  __syncthreads();   // B_-1: stage 0 is in buffer 0
+
+#ifdef CVM_STAMPS
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
+  unsigned long long c_loop0, c_loop1;
+  STAMP(c_loop0);
+#endif
+  constexpr bool HW = HWR, MFM = MFMR;
+  constexpr int ROLE = ROLER;
+  // the X-summing waves are exactly the diagonal 64x64 blocks of a diagonal tile: nothing reads
+  // the strictly-lower 16x16 tiles of such a block (the finalize kernels mirror the upper ones),
+  // so they are not computed -- 10 MFMAs per k-step instead of 16.  (Not wall time: the block's
+  // wave waits for the others at the stage barrier; but the kernel is power-limited and the
+  // clock rises, about 1 % measured.  Dropping the padded second column tile of the H wave the
+  // same way made the gathered variant 1.7 % slower -- code placement -- and was not kept.)
+  constexpr bool TRI = (ROLE == 1) && !HW;
+  constexpr int NA = HW ? 8 : 4, NB = HW ? 2 : 4;
+  // Fragments of the NEXT k-step are read while the current one computes, across the
+  // stage barrier too (the loaders guarantee stage s+1 is in LDS before stage s starts);
+  // the next k-step's weighting (and column sums) sit in the middle of the current
+  // k-step's MFMAs, so no MFMA ever waits for LDS or for a VALU result.
+  T af[2][NA], bf[2][NB], yf[2][2], wv[2], raw[4];
+  auto read_frags = [&](const T *buf, int ks, int slot) {
+    const int r = 4 * ks + lk;
+    if (MFM || ROLE == 1) {
+#pragma unroll
+      for (int m = 0; m < NA; ++m) af[slot][m] = buf[a_off + r * PITCH + 16 * m];
+    }
+    if (MFM) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) bf[slot][n] = buf[b_off + r * (HW ? YPITCH : PITCH) + 16 * n];
+    }
+    if (ROLE == 2) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) yf[slot][n] = buf[PANEL_ELEMS + r * YPITCH + 16 * n + lc];
+    }
+    wv[slot] = buf[2 * PANEL_ELEMS + r];
+  };
+  // column sums and weighting of one k-step's fragments (slot c); see wgram_kernel for the
+  // summation order (same row classes, same combine)
+  auto prepare = [&](int c) {
+    if (ROLE == 1) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        raw[m] = af[c][m];
+        const T pv = WEIGHTED ? (T)(af[c][m] * wv[c]) : af[c][m];
+        st_s[m] += pv; st_q[m] += (T)(pv * raw[m]);
+        af[c][m] = pv;
+      }
+    } else {
+      if (ROLE == 2) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const T yv = yf[c][n];
+          const T pv = WEIGHTED ? (T)(yv * wv[c]) : yv;
+          st_s[n] += pv; st_q[n] += (T)(pv * yv);
+        }
+        st_s[2] += wv[c];
+        st_s[3] += (wv[c] != (T)0) ? 1.0 : 0.0;
+        st_q[3] += (wv[c] < (T)0) ? 1.0 : 0.0;
+      }
+      if (MFM && WEIGHTED) {
+        if (HW) {   // H wave: 2 Y fragments instead of 8 X fragments
+#pragma unroll
+          for (int n = 0; n < NB; ++n) bf[c][n] *= wv[c];
+        } else {
+#pragma unroll
+          for (int m = 0; m < NA; ++m) af[c][m] *= wv[c];
+        }
+      }
+    }
+  };
+  if (MFM || ROLE != 0) {
+    read_frags(smem, 0, 0);
+    prepare(0);
+  }
+  // (unrolling this loop over the four LDS buffers to make every LDS address an immediate
+  //  was tried: the role functions grow to 11-15 KB each, the instruction cache thrashes and
+  //  the kernel loses 25 %)
+#pragma unroll 1
+  for (int s = 0; s < nstages; ++s) {
+#ifdef CVM_STAMPS
+    STAMP(t0);
+    STAMP(t1);
+    if (a.dbg & 2) { __syncthreads(); continue; }   // diagnostic: loaders alone
+#endif
+    const T *buf = smem + (s % NBUF4) * BUF_ELEMS;
+    const T *nbuf = smem + ((s + 1) % NBUF4) * BUF_ELEMS;
+    if (MFM || ROLE != 0) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MFM) {
+#pragma unroll
+          for (int m = 0; m < NA / 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              if (!TRI || m <= n) acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prepare(c ^ 1);   // the other slot: its LDS reads were issued half a k-step ago
+        __builtin_amdgcn_sched_barrier(0);
+        if (MFM) {
+#pragma unroll
+          for (int m = NA / 2; m < NA; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              if (!TRI || m <= n) acc[m * NB + n] = MF<T>::mfma(af[c][m], bf[c][n], acc[m * NB + n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef CVM_STAMPS
+    STAMP(t2);
+    if (!(a.dbg & 4))   // diagnostic: free-running waves (wrong results)
+#endif
+    __syncthreads();   // B_s
+#ifdef CVM_STAMPS
+    STAMP(t3);
+    t_a += t1 - t0; t_b += t2 - t1; t_c += t3 - t2;
+#endif
+  }
+#ifdef CVM_STAMPS
+  STAMP(c_loop1);
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+    o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = (unsigned long long)nstages;
+  }
+#endif
+
+  if (FUSEDR) {
+    // ---- fused single-split epilogue: no partials, no apply kernel --------------------------
+    // The fold's statistics are already in a.fstats (colstats_kernel + fold_stats_kernel ran
+    // first); every wave finishes its own block: total - update, rank-1 centring, outer-std
+    // scaling (cvmatrix.py:1001-1010), mirrored store through the wave's slice of the ring.
+    __syncthreads();   // all loaders have drained their LDS-DMA
+    const int K = g.K, M = g.M;
+    const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
+    const double swt = fs[2 * K + 2 * M];
+    const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+    const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+    const size_t fo = (size_t)(a.seg0 + seg);
+    if (h_wave) {
+      if (a.out_XTY && M > 0) {
+        double *out = (double *)a.out_XTY + fo * (size_t)K * M;
+        const double *Ht = (const double *)a.H;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = ti * TILE + 16 * m + MF<T>::drow(lane, r), col = yc * YT + 16 * n + lc;
+              if (row < K && col < M) {
+                double v = Ht[(size_t)row * M + col] - acc[m * 2 + n][r];
+                if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
+                if (sX && sY) v = v / (fs[K + row] * fs[2 * K + M + col]);
+                else if (sX) v = v / fs[K + row];
+                else if (sY) v = v / fs[2 * K + M + col];
+                out[(size_t)row * M + col] = v;
+              }
+            }
+      }
+    } else if (do_g && MFM && a.out_XTX) {
+      const int a0 = ti * TILE + 64 * wr, b0 = tj * TILE + 64 * wc;
+      if (a0 < K && b0 < K) {
+        double *slice = smem + (size_t)wave * WAVE_LDS_DOUBLES;
+        double (*Ts)[65] = reinterpret_cast<double (*)[65]>(slice);
+        double *rs = slice + 64 * 65;
+        rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
+        rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
+        rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
+        rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              Ts[16 * m + MF<T>::drow(lane, r)][16 * n + lc] = acc[m * 4 + n][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fused_finish_block(Ts, rs, diag && wr == wc, a0, b0, K, (const double *)a.G,
+                           (double *)a.out_XTX + fo * (size_t)K * K, swt, cX, sX, lane);
+      }
+    }
+    return;
+  }
+
+  auto comb = [&](double v) -> double {
+    const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
+    return ((v + v1) + v2) + v3;
+  };
+  if (stat_role == 1) {
+    double *st = unit_stats<T>(a.ws, g, u);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double sv = comb(st_s[m]), qv = comb(st_q[m]);
+      if (lk == 0) {
+        st[ti * TILE + a_col + 16 * m + lc] = sv;
+        st[g.Kp + ti * TILE + a_col + 16 * m + lc] = qv;
+      }
+    }
+  } else if (stat_role == 2) {
+    double *st = unit_stats<T>(a.ws, g, u);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const double sv = comb(st_s[n]), qv = comb(st_q[n]);
+      if (lk == 0) {
+        st[2 * g.Kp + yc * YT + 16 * n + lc] = sv;
+        st[2 * g.Kp + g.Mp + yc * YT + 16 * n + lc] = qv;
+      }
+    }
+    const double swv = comb(st_s[2]), nzv = comb(st_s[3]), ngv = comb(st_q[3]);
+    if (yc == 0 && lane == 0) {
+      st[2 * g.Kp + 2 * g.Mp + 0] = swv;
+      st[2 * g.Kp + 2 * g.Mp + 1] = nzv;
+      st[2 * g.Kp + 2 * g.Mp + 2] = ngv;
+    }
+  }
+  if (h_wave) {
+    if (g.M > 0) {
+      T *hp = unit_h<T>(a.ws, g, u) + (size_t)ti * TILE * g.Mp + yc * YT;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            hp[(size_t)(16 * m + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] = acc[m * 2 + n][r];
+    }
+  } else if (do_g) {
+    T *tp = unit_tiles<T>(a.ws, g, u) + (size_t)it * TILE * TILE;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc] = acc[m * 4 + n][r];
+  }
+#ifdef CVM_STAMPS
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long c_exit = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned long long *o = g_stamps3 + ((size_t)blockIdx.x * 8 + wave) * 2;
+      o[0] = c_loop0 - c_entry; o[1] = c_exit - c_loop1;
+    }
+  }
+#endif
+}
+
+template <bool WEIGHTED, bool GATHER, bool FUSED = false>
+__global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> a) {
+  // role of this wave (same decode as in the body)
+  const Geom &g = a.g;
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave_all & 3;
+  const long b = blockIdx.x;
+  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
+  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+#ifdef CVM_STAMPS
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), q0 = __builtin_amdgcn_s_memrealtime();
+  auto fin = [&]() {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
+      unsigned long long *o = g_stamps2 + ((size_t)blockIdx.x * 8 + wave_all) * 4;
+      o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
+    }
+  };
+  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3, FUSED>(a); fin(); return; }
+#else
+  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3, FUSED>(a); return; }
+#endif
+  const int it = (int)(item % g.nT);
+  int ti, tj, yc;
+  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
+  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
+  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  const bool diag = (ti == tj);
+  const bool do_g = !g.diag_only && yc == 0;
+  if (FUSED) {   // statistics come from colstats_kernel: no summing roles
+    if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0, true>(a);
+    else if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0, true>(a);
+    else wgram4_body<WEIGHTED, GATHER, false, false, 0, true>(a);
+#ifdef CVM_STAMPS
+    fin();
+#endif
+    return;
+  }
+  const int role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
+  if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0>(a);
+  else if (role == 1) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 1>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 1>(a); }
+  else if (role == 2) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 2>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 2>(a); }
+  else { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 0>(a); }
+#ifdef CVM_STAMPS
+  fin();
+#endif
+}
