@@ -130,5 +130,39 @@ def test_cabi_library_exports_every_declared_symbol():
     assert b"null pointer" in loaded.cvm_last_error()
 
 
+def test_launch_planning_is_host_logic():
+    """The row-split planner (cvm_plan_fold, pure host code): it fills the 256 CUs with as few
+    splits as the launch-time estimate allows -- C3's 10 folds x 10 tiles get 5 splits (two rounds
+    of workgroups), the fit stage one round, and many mid-size folds one unit per fold (the
+    route that finishes folds in the Gram kernel's epilogue)."""
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    lib = _lib.load()
+    info = (ctypes.c_int64 * 8)()
+
+    def plan(n_folds, rows, K, M, dtype=_lib.CVM_F64, flags=0x3F, ws=1 << 40):
+        assert lib.cvm_plan_fold(n_folds, rows, K, M, dtype, flags, ws, info) == 0
+        return dict(splits=info[0], wgs=info[1], panels=info[2], items=info[3], batch=info[4],
+                    mfma_per_4_rows=info[5])
+
+    c3 = plan(10, 10000, 512, 16)
+    assert c3["splits"] == 5 and c3["wgs"] == 500 and c3["batch"] == 10
+    # executed MFMAs per 4 rows: 6 off-diagonal tiles x 64, 4 diagonal x (16 + 10 + 10), 4 x 16 for XTY
+    assert c3["mfma_per_4_rows"] == 6 * 64 + 4 * 36 + 4 * 16
+    fit = plan(1, 100000, 512, 16, flags=0x3F | 0x80000000)
+    assert fit["wgs"] <= 256 and fit["wgs"] >= 240                 # one round, nearly full
+    for P in (100, 300, 1000):
+        assert plan(P, 100000 // P, 512, 16)["splits"] == 1
+    # a workspace that holds three folds' partials: three folds per batch, same splits or fewer
+    per_fold = lib.cvm_fold_workspace_bytes(1, 10000, 10000, 512, 16, _lib.CVM_F64, 0x3F)
+    small = plan(10, 10000, 512, 16, ws=int(per_fold) * 1)
+    assert 1 <= small["batch"] <= 10 and small["splits"] >= 1
+    # float32 / odd shapes take the general kernel: no skipped tiles in its count
+    f32 = plan(20, 10000, 4096, 1, dtype=_lib.CVM_F32)
+    assert f32["panels"] == 32 and f32["mfma_per_4_rows"] == (528 - 32) * 64 + 32 * 48 + 32 * 16
+
+
 def test_package_metadata():
     assert cvmatrix_amd.__all__ == ["CVMatrix", "Partitioner", "FoldBatch"]
