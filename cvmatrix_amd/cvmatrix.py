@@ -125,6 +125,7 @@ class CVMatrix:
         self._sum_w = None
         self._n_total = self._nz_total = None
         self._gstats = None
+        self._globals = None
         self._w_host = None
         self._nz_mask = None
         self._ws = None
@@ -206,11 +207,7 @@ class CVMatrix:
             else:
                 self.weights, self._w_host, self._w_checked = None, None, None
             M = self.M or 0
-            self.XTX = torch.empty((self.K, self.K), dtype=self._tdt, device=self.device)
-            self.XTY = (torch.empty((self.K, M), dtype=self._tdt, device=self.device)
-                        if self.Y is not None else None)
-            self._gstats = torch.empty(lib.cvm_gstats_len(self.K, M), dtype=torch.float64,
-                                       device=self.device)
+            self._alloc_globals(lib.cvm_gstats_len(self.K, M))
             neg = torch.zeros(1, dtype=torch.int32, device=self.device)
             if folds is not None:
                 self._fit_sweep(lib, folds, neg)
@@ -231,6 +228,26 @@ class CVMatrix:
                 self._w_host = self.weights.reshape(-1).cpu().numpy()
                 self._w_checked = self._weights_key(weights)
             self._publish_stats()
+
+    def _alloc_globals(self, n_gstats: int) -> None:
+        """``XTX``, ``XTY`` and the float64 statistics vector as views of ONE contiguous
+        buffer ``[G | H | gstats]`` (float64 problems): the multi-GPU exchange is then a single
+        collective on that buffer with nothing to pack.  float32 problems keep separate
+        tensors (the statistics stay float64)."""
+        K, M, dev = self.K, self.M or 0, self.device
+        hasY = self.Y is not None
+        if self._tdt == torch.float64:
+            nG, nH = K * K, (K * M if hasY else 0)
+            flat = torch.empty(nG + nH + n_gstats, dtype=torch.float64, device=dev)
+            self._globals = flat
+            self.XTX = flat[:nG].view(K, K)
+            self.XTY = flat[nG:nG + nH].view(K, M) if hasY else None
+            self._gstats = flat[nG + nH:]
+        else:
+            self._globals = None
+            self.XTX = torch.empty((K, K), dtype=self._tdt, device=dev)
+            self.XTY = torch.empty((K, M), dtype=self._tdt, device=dev) if hasY else None
+            self._gstats = torch.empty(n_gstats, dtype=torch.float64, device=dev)
 
     def _fit_sweep(self, lib, folds, neg) -> None:
         """One-sweep fit: Gram kernel over all folds once, full-data matrices = their sum

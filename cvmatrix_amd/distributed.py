@@ -62,15 +62,24 @@ def unpack_globals(buf: torch.Tensor, G: torch.Tensor, H: Optional[torch.Tensor]
         o += n
 
 
-def allreduce_globals(G, H, gstats, group=None) -> None:
-    """Sum the per-rank partial [G | H | gstats] in place on every rank."""
+def allreduce_globals(G, H, gstats, group=None, flat: Optional[torch.Tensor] = None) -> None:
+    """Sum the per-rank partial [G | H | gstats] in place on every rank.  ``flat``: the
+    contiguous buffer the three tensors are views of (CVMatrix allocates them that way for
+    float64): the collective then runs on it directly, nothing is packed or copied back."""
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return
     buf = pack_globals(G, H, gstats)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     unpack_globals(buf, G, H, gstats)
 
 
-def broadcast_globals(G, H, gstats, src: int = 0, group=None) -> None:
+def broadcast_globals(G, H, gstats, src: int = 0, group=None,
+                      flat: Optional[torch.Tensor] = None) -> None:
     """Replicate rank `src`'s [G | H | gstats] on every rank."""
+    if flat is not None:
+        dist.broadcast(flat, src=src, group=group)
+        return
     buf = pack_globals(G, H, gstats)
     dist.broadcast(buf, src=src, group=group)
     unpack_globals(buf, G, H, gstats)
@@ -105,7 +114,7 @@ class ShardedCVMatrix(CVMatrix):
             return super().fit(X, Y, weights, folds=folds)
         if self.mode == "row_sharded":
             super().fit(X, Y, weights, folds=folds)   # folds: this rank's rows, partitioned
-            allreduce_globals(self.XTX, self.XTY, self._gstats, self.group)
+            allreduce_globals(self.XTX, self.XTY, self._gstats, self.group, flat=self._globals)
             # the global counts depend on the weights and the row counts only: when the same
             # (unmodified) device tensors are fitted again, skip the device read-back
             key = (self._weights_key(weights), self.N, self.world)
@@ -122,7 +131,8 @@ class ShardedCVMatrix(CVMatrix):
                 super().fit(X, Y, weights)
             else:
                 self._fit_without_gram(X, Y, weights)
-            broadcast_globals(self.XTX, self.XTY, self._gstats, self.src, self.group)
+            broadcast_globals(self.XTX, self.XTY, self._gstats, self.src, self.group,
+                              flat=self._globals)
 
     def _sync_totals(self) -> None:
         """Global sample / non-zero-weight counts for the host-side validity checks
@@ -160,9 +170,5 @@ class ShardedCVMatrix(CVMatrix):
             else:
                 self.weights, self._w_host = None, None
             M = self.M or 0
-            self.XTX = torch.empty((self.K, self.K), dtype=self._tdt, device=self.device)
-            self.XTY = (torch.empty((self.K, M), dtype=self._tdt, device=self.device)
-                        if Y is not None else None)
-            self._gstats = torch.empty(lib.cvm_gstats_len(self.K, M), dtype=torch.float64,
-                                       device=self.device)
+            self._alloc_globals(lib.cvm_gstats_len(self.K, M))
         self._publish_stats()

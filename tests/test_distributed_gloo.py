@@ -107,6 +107,18 @@ def _worker(rank, world, port, tmp):
             np.testing.assert_allclose(b, d, rtol=1e-10, atol=1e-10)
             for s, t in zip(sa, sc):
                 np.testing.assert_allclose(s, t, rtol=1e-10)
+        # ---- the same exchange on ONE contiguous buffer (how CVMatrix lays out float64 globals:
+        #      XTX, XTY, gstats are views of it; nothing is packed, one collective) ----------
+        Gl, Hl, gsl = _globals_from_oracle(X[rows], Y[rows], w[rows])
+        flat = torch.empty(K * K + K * M + gsl.numel(), dtype=torch.float64)
+        Gv, Hv, gv = flat[:K * K].view(K, K), flat[K * K:K * K + K * M].view(K, M), flat[K * K + K * M:]
+        Gv.copy_(Gl); Hv.copy_(Hl); gv.copy_(gsl)
+        allreduce_globals(Gv, Hv, gv, flat=flat)
+        assert torch.equal(Gv, G) and torch.equal(Hv, H) and torch.equal(gv, gs)
+        if rank != 0:
+            flat.zero_()
+        broadcast_globals(Gv, Hv, gv, src=0, flat=flat)
+        assert torch.equal(Gv, G) and torch.equal(gv, gs)
         # ---- replicated fit: rank 0 computes, broadcast ---------------------------------
         if rank == 0:
             G2, H2, gs2 = Gf.clone(), Hf.clone(), gsf.clone()
