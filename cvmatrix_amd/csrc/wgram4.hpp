@@ -502,6 +502,165 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 #endif
 }
 
+// ----------------------------------------------------------------------------------
+// Compute waves of a DIAGONAL tile (panel x same panel, first Y chunk), balanced: the upper
+// triangle of the tile's 8x8 grid of 16x16 MFMA tiles has 36 tiles; wave W takes grid rows W
+// and 7-W (8-W and W+1 tiles: 9 for every wave) plus the XTY tiles of those two row-tiles, so
+// all four waves issue 9 + 2*NBY MFMAs per k-step (11 with M <= 16) instead of 16 -- and share
+// the column sums (two row-tiles each).  Its operands: the raw fragments of column tiles
+// W..7 (the B side), of which those of rows W and 7-W, weighted, are the A side.
+// Nothing below the diagonal tiles is computed: the finalize kernels mirror the upper ones.
+//   YSTAT: this wave also sums the Y columns, sw and nz (wave 3 of panel 0)
+// ----------------------------------------------------------------------------------
+template <bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT>
+__device__ __noinline__ void wgram4_diag_body(const WgramArgs<double> &a_ref) {
+  typedef double T;
+  typedef MF<double>::acc_t acc_t;
+  const WgramArgs<double> a = scalarize(a_ref);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const Geom &g = a.g;
+  const int lane = threadIdx.x & 63;
+  const long b = blockIdx.x;
+  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
+  const long u = item / g.nT;
+  const int it = (int)(item - u * g.nT);
+  const int seg = (int)(u / a.splits);
+  const int sp = (int)(u - (long)seg * a.splits);
+  int ti, tj;
+  decode_tile(it, g.P, ti, tj);                   // diagonal: ti == tj, Y chunk 0
+  int64_t seg_begin, seg_rows;
+  if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
+  else { seg_begin = 0; seg_rows = a.N; }
+  int64_t r0, r1;
+  split_range(seg_rows, a.splits, sp, r0, r1);
+  r0 = uni64(r0); r1 = uni64(r1);
+  const int nstages = uni((int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS));
+
+  constexpr int R0 = W, R1 = 7 - W;      // this wave's two grid rows
+  constexpr int NB0 = 8 - W;             // column tiles W..7: B fragments held
+  constexpr int NG = 9;                  // G tiles: NB0 of row R0, W + 1 of row R1
+  acc_t acc[NG], acch[2 * NBY];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) acc[i] = (acc_t){0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 2 * NBY; ++i) acch[i] = (acc_t){0, 0, 0, 0};
+  double st_s[2] = {0, 0}, st_q[2] = {0, 0};
+  double sy[NBY], qy[NBY], sw_ = 0, nz_ = 0, ng_ = 0;
+#pragma unroll
+  for (int n = 0; n < NBY; ++n) sy[n] = qy[n] = 0;
+
+  const int lk = lane >> 4, lc = lane & 15;
+  __syncthreads();   // B_a
+  __syncthreads();   // B_-1: stage 0 is in buffer 0
+
+  T bf[2][NB0], aw[2][2], yf[2][NBY], wv[2];
+  auto read_frags = [&](const T *buf, int ks, int slot) {
+    const int r = 4 * ks + lk;
+#pragma unroll
+    for (int j = 0; j < NB0; ++j) bf[slot][j] = buf[r * PITCH + 16 * (W + j) + lc];
+#pragma unroll
+    for (int n = 0; n < NBY; ++n) yf[slot][n] = buf[PANEL_ELEMS + r * YPITCH + 16 * n + lc];
+    wv[slot] = buf[2 * PANEL_ELEMS + r];
+  };
+  // weighting and column sums of one k-step's fragments: same row classes and combine order
+  // as everywhere else (a constant-one column gives s == q == sw bit for bit)
+  auto prepare = [&](int c) {
+    const T x0 = bf[c][0], x1 = bf[c][R1 - W];
+    const T p0 = WEIGHTED ? (T)(x0 * wv[c]) : x0, p1 = WEIGHTED ? (T)(x1 * wv[c]) : x1;
+    st_s[0] += p0; st_q[0] += (T)(p0 * x0);
+    st_s[1] += p1; st_q[1] += (T)(p1 * x1);
+    aw[c][0] = p0; aw[c][1] = p1;
+    if (YSTAT) {
+#pragma unroll
+      for (int n = 0; n < NBY; ++n) {
+        const T yv = yf[c][n];
+        const T pv = WEIGHTED ? (T)(yv * wv[c]) : yv;
+        sy[n] += pv; qy[n] += (T)(pv * yv);
+      }
+      sw_ += wv[c];
+      nz_ += (wv[c] != (T)0) ? 1.0 : 0.0;
+      ng_ += (wv[c] < (T)0) ? 1.0 : 0.0;
+    }
+  };
+  read_frags(smem, 0, 0);
+  prepare(0);
+#pragma unroll 1
+  for (int s = 0; s < nstages; ++s) {
+    const T *buf = smem + (s % NBUF4) * BUF_ELEMS;
+    const T *nbuf = smem + ((s + 1) % NBUF4) * BUF_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks & 1;
+      if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NB0; ++j) acc[j] = MF<T>::mfma(aw[c][0], bf[c][j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      prepare(c ^ 1);   // the other slot: its LDS reads were issued most of a k-step ago
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < W + 1; ++j) acc[NB0 + j] = MF<T>::mfma(aw[c][1], bf[c][R1 - W + j], acc[NB0 + j]);
+#pragma unroll
+      for (int n = 0; n < NBY; ++n) {
+        acch[n] = MF<T>::mfma(aw[c][0], yf[c][n], acch[n]);
+        acch[NBY + n] = MF<T>::mfma(aw[c][1], yf[c][n], acch[NBY + n]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // B_s
+  }
+
+  auto comb = [&](double v) -> double {
+    const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
+    return ((v + v1) + v2) + v3;
+  };
+  double *st = unit_stats<T>(a.ws, g, u);
+  {
+    const double s0 = comb(st_s[0]), q0 = comb(st_q[0]), s1 = comb(st_s[1]), q1 = comb(st_q[1]);
+    if (lk == 0) {
+      st[ti * TILE + 16 * R0 + lc] = s0; st[g.Kp + ti * TILE + 16 * R0 + lc] = q0;
+      st[ti * TILE + 16 * R1 + lc] = s1; st[g.Kp + ti * TILE + 16 * R1 + lc] = q1;
+    }
+  }
+  if (YSTAT) {
+#pragma unroll
+    for (int n = 0; n < NBY; ++n) {
+      const double sv = comb(sy[n]), qv = comb(qy[n]);
+      if (lk == 0) { st[2 * g.Kp + 16 * n + lc] = sv; st[2 * g.Kp + g.Mp + 16 * n + lc] = qv; }
+    }
+    if (NBY == 1 && lk == 0) { st[2 * g.Kp + 16 + lc] = 0.0; st[2 * g.Kp + g.Mp + 16 + lc] = 0.0; }
+    const double swv = comb(sw_), nzv = comb(nz_), ngv = comb(ng_);
+    if (lane == 0) {
+      st[2 * g.Kp + 2 * g.Mp + 0] = swv;
+      st[2 * g.Kp + 2 * g.Mp + 1] = nzv;
+      st[2 * g.Kp + 2 * g.Mp + 2] = ngv;
+    }
+  }
+  if (g.M > 0) {
+    T *hp = unit_h<T>(a.ws, g, u) + (size_t)ti * TILE * g.Mp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          hp[(size_t)(16 * (i ? R1 : R0) + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] =
+              (n < NBY) ? acch[i * NBY + (n < NBY ? n : 0)][r] : 0.0;
+  }
+  T *tp = unit_tiles<T>(a.ws, g, u) + (size_t)it * TILE * TILE;
+#pragma unroll
+  for (int j = 0; j < NB0; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      tp[(16 * R0 + MF<T>::drow(lane, r)) * TILE + 16 * (W + j) + lc] = acc[j][r];
+#pragma unroll
+  for (int j = 0; j < W + 1; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      tp[(16 * R1 + MF<T>::drow(lane, r)) * TILE + 16 * (R1 + j) + lc] = acc[NB0 + j][r];
+}
+
 template <bool WEIGHTED, bool GATHER, bool FUSED = false>
 __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> a) {
   // role of this wave (same decode as in the body)
@@ -535,6 +694,26 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
     if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0, true>(a);
     else if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0, true>(a);
     else wgram4_body<WEIGHTED, GATHER, false, false, 0, true>(a);
+#ifdef CVM_STAMPS
+    fin();
+#endif
+    return;
+  }
+  if (diag && do_g) {
+    // diagonal tile, first Y chunk: the four balanced waves (see wgram4_diag_body)
+    const bool wide = g.M > 16, ys = (ti == 0);
+#define CVM_DIAG(WV)                                                                         \
+    do {                                                                                     \
+      if (wide) wgram4_diag_body<WEIGHTED, GATHER, WV, 2, false>(a);                         \
+      else wgram4_diag_body<WEIGHTED, GATHER, WV, 1, false>(a);                              \
+    } while (0)
+    if (wave == 0) CVM_DIAG(0);
+    else if (wave == 1) CVM_DIAG(1);
+    else if (wave == 2) CVM_DIAG(2);
+    else if (!ys) CVM_DIAG(3);
+    else if (wide) wgram4_diag_body<WEIGHTED, GATHER, 3, 2, true>(a);
+    else wgram4_diag_body<WEIGHTED, GATHER, 3, 1, true>(a);
+#undef CVM_DIAG
 #ifdef CVM_STAMPS
     fin();
 #endif
