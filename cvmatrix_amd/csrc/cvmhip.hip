@@ -207,11 +207,16 @@ int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtyp
   info[4] = p.folds_per_batch;
   // MFMA instructions issued per 4 rows of one unit (executed work, incl. padding)
   int64_t per4 = 0;
-  // a diagonal tile runs 3 blocks of 16; the float64 LDS-DMA kernel skips the strictly-lower
-  // tiles of its two diagonal blocks (16 + 10 + 10) unless it finishes folds in its epilogue
+  // MFMAs per k-step: an off-diagonal tile 4 waves x 16; a diagonal tile in the float64 LDS-DMA
+  // kernel 36 (the upper triangle of its 8 x 8 grid) + 8 per 16 live columns of the first Y
+  // chunk; in the general kernel, or when folds are finished in the epilogue, 3 blocks of 16 +
+  // 16 for XTY
   const bool tri = dtype == CVM_F64 && ((size_t)K * 8) % 16 == 0 && M % 2 == 0 && !(fold_mode && p.splits == 1);
   if (!p.g.diag_only) per4 += (int64_t)(p.g.nTiles - p.g.P) * 64 + (int64_t)p.g.P * (tri ? 36 : 48);
-  if (M > 0) per4 += (int64_t)p.g.P * p.g.Yc * 16;   // two H waves x 8
+  if (M > 0) {
+    if (tri && !p.g.diag_only) per4 += (int64_t)p.g.P * (M > 16 ? 16 : 8) + (int64_t)p.g.P * (p.g.Yc - 1) * 16;
+    else per4 += (int64_t)p.g.P * p.g.Yc * 16;
+  }
   info[5] = per4;
   return CVM_OK;
 }

@@ -149,8 +149,9 @@ def test_launch_planning_is_host_logic():
 
     c3 = plan(10, 10000, 512, 16)
     assert c3["splits"] == 5 and c3["wgs"] == 500 and c3["batch"] == 10
-    # executed MFMAs per 4 rows: 6 off-diagonal tiles x 64, 4 diagonal x (16 + 10 + 10), 4 x 16 for XTY
-    assert c3["mfma_per_4_rows"] == 6 * 64 + 4 * 36 + 4 * 16
+    # executed MFMAs per 4 rows: 6 off-diagonal tiles x 64, 4 diagonal x 36 (upper triangle of the
+    # tile's 8 x 8 grid of MFMA tiles), 4 x 8 for XTY (M = 16: one column tile)
+    assert c3["mfma_per_4_rows"] == 6 * 64 + 4 * 36 + 4 * 8
     fit = plan(1, 100000, 512, 16, flags=0x3F | 0x80000000)
     assert fit["wgs"] <= 256 and fit["wgs"] >= 240                 # one round, nearly full
     for P in (100, 300, 1000):

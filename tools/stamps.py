@@ -42,7 +42,8 @@ print("per-WG (wave 0): shader cycles mean %.0f, 100MHz ticks mean %.1f -> clock
 t0 = b2[:, :, 2].min(); t1 = b2[:, :, 3].max()
 print("kernel span (first WG start -> last WG end) %.1f us; WG duration mean %.1f us, max %.1f us" % ((t1 - t0) / 100, ticks.mean() / 100, ticks.max() / 100))
 st_ = np.sort((b2[:, 0, 2] - t0) / 100)
-print("WG start times us: round 1 last %.1f; round 2 first %.1f mean %.1f last %.1f" % (st_[255], st_[256], st_[256:].mean(), st_[-1]))
+if len(st_) > 256:
+    print("WG start times us: round 1 last %.1f; round 2 first %.1f mean %.1f last %.1f" % (st_[255], st_[256], st_[256:].mean(), st_[-1]))
 en_ = (b2[:, 0, 3] - t0) / 100
 print("WG end times us: quantiles", np.round(np.quantile(en_, [0, .25, .5, .75, 1]), 1))
 buf3 = (C.c_ulonglong * (1024 * 8 * 2))()
@@ -50,3 +51,15 @@ lib.cvm_debug_stamps3(buf3)
 b3 = np.frombuffer(buf3, dtype=np.uint64).reshape(1024, 8, 2).astype(np.float64)
 b3 = b3[b3[:, 0, 0] > 0]
 print("compute waves: prologue cycles by wave", np.round(b3[:, :4, 0].mean(0)), "epilogue", np.round(b3[:, :4, 1].mean(0)))
+# diagonal vs off-diagonal workgroups (C3 shape: 10 tiles per unit, diagonal ones are 0, 4, 7, 9)
+buf2b = np.frombuffer(buf2, dtype=np.uint64).reshape(1024, 8, 4).astype(np.float64)
+n_items = 500
+ipx = (n_items + 7) // 8
+blk = np.arange(1024)
+item = (blk & 7) * ipx + (blk >> 3)
+valid = ((blk >> 3) < ipx) & (item < n_items) & (buf2b[:, 0, 2] > 0)
+it = item % 10
+isd = np.isin(it, [0, 4, 7, 9])
+for nm, m_ in (("diagonal", valid & isd), ("off-diagonal", valid & ~isd)):
+    c = buf2b[m_, 0, 0]
+    print(f"{nm:13s} workgroups {m_.sum():4d}: mean {c.mean():9.0f} shader cycles = {c.mean() / 125:6.0f} per 16-row stage")
