@@ -282,21 +282,37 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
     constexpr int LPR = ST / VW;
     typedef T vld_t __attribute__((ext_vector_type(VW)));
     const int tid = threadIdx.x;
-    for (int q = tid; q < ST * LPR; q += APPLY_THREADS) {
+    // every thread owns NQ 16-byte pieces of the sub-tile; the splits are summed in order, the
+    // pieces of one split loaded together (NQ independent loads in flight: a fit with 25 splits
+    // is otherwise one long chain of dependent latencies on 44 workgroups)
+    constexpr int NQ = ST * LPR / APPLY_THREADS;
+    double v[NQ][VW];
+    const char *pp[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = tid + j * APPLY_THREADS;
       const int lr = q / LPR, lc = (q - lr * LPR) * VW;
       const size_t off = (size_t)t * TILE * TILE + (size_t)(si * ST + lr) * TILE + sj * ST + lc;
-      const char *pp = ws0 + off * sizeof(T);
-      double v[VW];
+      pp[j] = ws0 + off * sizeof(T);
 #pragma unroll
-      for (int e = 0; e < VW; ++e) v[e] = 0;
-#pragma unroll 4
-      for (int p = 0; p < a.splits; ++p) {
-        const vld_t qv = *reinterpret_cast<const vld_t *>(pp + (size_t)p * g.unit_bytes);
+      for (int e = 0; e < VW; ++e) v[j][e] = 0;
+    }
+#pragma unroll 2
+    for (int p = 0; p < a.splits; ++p) {
+      vld_t qv[NQ];
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[e] += (double)qv[e];
-      }
+      for (int j = 0; j < NQ; ++j) qv[j] = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)p * g.unit_bytes);
 #pragma unroll
-      for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = v[e];
+      for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[j][e];
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = tid + j * APPLY_THREADS;
+      const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = v[j][e];
     }
     __syncthreads();
     T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
