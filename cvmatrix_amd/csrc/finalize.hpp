@@ -204,7 +204,8 @@ __device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool dia
 // The same finishing step for ONE WAVE inside wgram4_kernel<.., FUSED> (float64, K even): the raw
 // update of a 64x64 block is in Ts, the row/column means and stds in rs[0..255].  A wave has no
 // other wave to hide its latency behind, so the G loads go out eight rows at a time.
-__device__ __forceinline__ void fused_finish_block(double (*Ts)[65], const double *rs, bool diagb, int a0,
+template <int TP>
+__device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const double *rs, bool diagb, int a0,
                                                    int b0, int K, const double *Gt, double *out,
                                                    double swt, bool cX, bool sX, int lane) {
   typedef double v2 __attribute__((ext_vector_type(2)));

@@ -36,7 +36,8 @@ constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;
 //   ROLER 0/1/2: compute wave without sums / with X column sums / with Y column sums
 //   ROLER 3: loader wave
 __host__ __device__ inline size_t fstat_len(int K, int M);
-__device__ __forceinline__ void fused_finish_block(double (*Ts)[65], const double *rs, bool diagb, int a0,
+template <int TP>
+__device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const double *rs, bool diagb, int a0,
                                                    int b0, int K, const double *Gt, double *out,
                                                    double swt, bool cX, bool sX, int lane);
 constexpr int WAVE_LDS_DOUBLES = 64 * 65 + 256;   // a wave's 64x64 block + row/column means and stds
@@ -431,7 +432,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
               Ts[16 * m + MF<T>::drow(lane, r)][16 * n + lc] = acc[m * 4 + n][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        fused_finish_block(Ts, rs, diag && wr == wc, a0, b0, K, (const double *)a.G,
+        fused_finish_block<65>(Ts, rs, diag && wr == wc, a0, b0, K, (const double *)a.G,
                            (double *)a.out_XTX + fo * (size_t)K * K, swt, cX, sX, lane);
       }
     }
@@ -512,7 +513,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 // Nothing below the diagonal tiles is computed: the finalize kernels mirror the upper ones.
 //   YSTAT: this wave also sums the Y columns, sw and nz (wave 3 of panel 0)
 // ----------------------------------------------------------------------------------
-template <bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT>
+template <bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT, bool FUSEDR = false>
 __device__ __noinline__ void wgram4_diag_body(const WgramArgs<double> &a_ref) {
   typedef double T;
   typedef MF<double>::acc_t acc_t;
@@ -568,10 +569,12 @@ __device__ __noinline__ void wgram4_diag_body(const WgramArgs<double> &a_ref) {
   auto prepare = [&](int c) {
     const T x0 = bf[c][0], x1 = bf[c][R1 - W];
     const T p0 = WEIGHTED ? (T)(x0 * wv[c]) : x0, p1 = WEIGHTED ? (T)(x1 * wv[c]) : x1;
-    st_s[0] += p0; st_q[0] += (T)(p0 * x0);
-    st_s[1] += p1; st_q[1] += (T)(p1 * x1);
+    if (!FUSEDR) {   // (the fused route gets its statistics from colstats_kernel)
+      st_s[0] += p0; st_q[0] += (T)(p0 * x0);
+      st_s[1] += p1; st_q[1] += (T)(p1 * x1);
+    }
     aw[c][0] = p0; aw[c][1] = p1;
-    if (YSTAT) {
+    if (YSTAT && !FUSEDR) {
 #pragma unroll
       for (int n = 0; n < NBY; ++n) {
         const T yv = yf[c][n];
@@ -609,6 +612,69 @@ __device__ __noinline__ void wgram4_diag_body(const WgramArgs<double> &a_ref) {
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();   // B_s
+  }
+
+  if (FUSEDR) {
+    // ---- fused epilogue (one unit per fold): the four waves put their tiles of the upper
+    // triangle into one 128 x 128 image in the LDS ring, then waves 0, 1 and 3 finish the
+    // 64 x 64 blocks (0,0), (0,1) and (1,1) as in wgram4_body; every wave finishes the XTY
+    // rows of its two row-tiles itself.
+    __syncthreads();   // all loaders have drained their LDS-DMA
+    const int K = g.K, M = g.M;
+    const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
+    const double swt = fs[2 * K + 2 * M];
+    const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+    const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+    const size_t fo = (size_t)(a.seg0 + seg);
+    if (a.out_XTY && M > 0) {
+      double *out = (double *)a.out_XTY + fo * (size_t)K * M;
+      const double *Ht = (const double *)a.H;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < NBY; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = ti * TILE + 16 * (i ? R1 : R0) + MF<T>::drow(lane, r), col = 16 * n + lc;
+            if (row < K && col < M) {
+              double v = Ht[(size_t)row * M + col] - acch[i * NBY + n][r];
+              if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
+              if (sX && sY) v = v / (fs[K + row] * fs[2 * K + M + col]);
+              else if (sX) v = v / fs[K + row];
+              else if (sY) v = v / fs[2 * K + M + col];
+              out[(size_t)row * M + col] = v;
+            }
+          }
+    }
+    if (a.out_XTX) {
+      constexpr int TP = TILE + 1;
+      double (*Td)[TP] = reinterpret_cast<double (*)[TP]>(smem);
+#pragma unroll
+      for (int j = 0; j < NB0; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Td[16 * R0 + MF<T>::drow(lane, r)][16 * (W + j) + lc] = acc[j][r];
+#pragma unroll
+      for (int j = 0; j < W + 1; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Td[16 * R1 + MF<T>::drow(lane, r)][16 * (R1 + j) + lc] = acc[NB0 + j][r];
+      __syncthreads();   // (the loader waves have ended or are ending: only live waves count)
+      if (W != 2) {
+        const int si = W == 3 ? 1 : 0, sj = W == 0 ? 0 : 1;
+        const int a0 = ti * TILE + 64 * si, b0 = ti * TILE + 64 * sj;
+        if (a0 < K && b0 < K) {
+          double *rs = smem + (size_t)TILE * TP + (size_t)W * 256;
+          rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
+          rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
+          rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
+          rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          fused_finish_block<TP>(reinterpret_cast<double (*)[TP]>(&Td[64 * si][64 * sj]), rs, si == sj, a0, b0, K,
+                                 (const double *)a.G, (double *)a.out_XTX + fo * (size_t)K * K, swt, cX, sX, lane);
+        }
+      }
+    }
+    return;
   }
 
   auto comb = [&](double v) -> double {
@@ -690,6 +756,24 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
   else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
   const bool diag = (ti == tj);
   const bool do_g = !g.diag_only && yc == 0;
+  if (FUSED && diag && do_g) {
+    // diagonal tile of the fused route: the balanced waves with the fused epilogue
+    const bool wide = g.M > 16;
+#define CVM_DIAGF(WV)                                                                        \
+    do {                                                                                     \
+      if (wide) wgram4_diag_body<WEIGHTED, GATHER, WV, 2, false, true>(a);                   \
+      else wgram4_diag_body<WEIGHTED, GATHER, WV, 1, false, true>(a);                        \
+    } while (0)
+    if (wave == 0) CVM_DIAGF(0);
+    else if (wave == 1) CVM_DIAGF(1);
+    else if (wave == 2) CVM_DIAGF(2);
+    else CVM_DIAGF(3);
+#undef CVM_DIAGF
+#ifdef CVM_STAMPS
+    fin();
+#endif
+    return;
+  }
   if (FUSED) {   // statistics come from colstats_kernel: no summing roles
     if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0, true>(a);
     else if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0, true>(a);
