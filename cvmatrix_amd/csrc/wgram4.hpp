@@ -8,15 +8,18 @@
 //
 // Same work decomposition, LDS stage image and partial layout as wgram_kernel, but the
 // eight waves of a workgroup (one workgroup per CU) are specialised:
-//   waves 0-3  COMPUTE, one per SIMD.  Wave (wr,wc) owns the 64x64 block (wr,wc) of the
-//              128x128 tile: 4x4 MFMA tiles, 16 accumulators (128 VGPRs), 16 MFMAs per 8
-//              LDS fragment reads.  They never touch global memory inside the loop, so no
+//   waves 0-3  COMPUTE, one per SIMD.  They never touch global memory inside the loop, so no
 //              vector-memory instruction ever blocks their issue (a 1 KiB load costs its
 //              wave 200-450 cycles of issue on a busy CU: tools/dma_issue.hip).
-//              On a diagonal tile the strictly-lower block (1,0) is not computed; its wave
-//              (the "H wave") computes panel_i^T W Y[:, 32c..32c+32) (8x2 MFMA tiles).
-//              Waves 0 and 3 also sum the X columns of their A fragments, wave 1 (panel 0)
-//              the Y columns, sw and nz -- on the VALU, in the shadow of their MFMAs.
+//              Off-diagonal tile (wgram4_body): wave (wr,wc) owns the 64x64 block (wr,wc) of
+//              the 128x128 tile: 4x4 MFMA tiles, 16 accumulators (128 VGPRs), 16 MFMAs per 8
+//              LDS fragment reads.
+//              Diagonal tile, first Y chunk (wgram4_diag_body): the upper triangle of the
+//              tile's 8x8 grid of MFMA tiles shared out evenly, 9 tiles + the XTY tiles and
+//              the column sums of two row-tiles per wave: 11 MFMAs per k-step.
+//              XTY-only items (further Y chunks, or calls that want no XTX) keep the older
+//              roles of wgram4_body: wave 2 computes panel_i^T W Y[:, 32c..32c+32) (8x2 MFMA
+//              tiles), waves 0 and 3 sum the X columns, wave 1 (panel 0) the Y columns.
 //   waves 4-7  LOADERS.  Loader d owns stage rows d, d+4, d+8, d+12 and moves, per row, the
 //              X panel rows, the Y tile row (diagonal tiles) and the weight global -> LDS
 //              by LDS-DMA (global_load_lds: one wave instruction = one 1 KiB panel row,
