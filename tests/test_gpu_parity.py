@@ -721,3 +721,60 @@ def test_fused_route_with_small_workspace_and_many_folds(amd):
         assert_normwise(x2[i], rx, TOL, f"loocv{i}")
         assert_normwise(y2[i], ry, TOL, f"loocv{i}")
         assert_stats(tuple(s[i] for s in st2), rst, TOL, f"loocv{i}")
+
+
+# ---------------------------------------------------------------- randomized shape sweep
+def _sweep_cases():
+    rng = np.random.default_rng(20260101)
+    cases = []
+    Ks = [2, 16, 62, 64, 66, 126, 128, 130, 190, 256, 258, 320, 386, 514]
+    Ms = [0, 2, 4, 14, 16, 18, 32, 34, 66]
+    for i in range(36):
+        K = int(rng.choice(Ks))
+        M = int(rng.choice(Ms))
+        route = ("small", "fused", "units")[i % 3]
+        cases.append((i, K, M, route))
+    return cases
+
+
+@pytest.mark.parametrize("i,K,M,route", _sweep_cases())
+def test_random_shape_sweep_float64_fast_path(amd, i, K, M, route):
+    """Even K and M (the float64 LDS-DMA kernel and its balanced diagonal waves / fused
+    epilogue) at panel, block and MFMA-tile edges, through the three fold-size routes
+    (<= 32 rows; many folds of one unit each; a few large folds split into units), ragged
+    folds, zero weights, a random flag set; three folds per case against the oracle."""
+    rng = np.random.default_rng(1000 + i)
+    flags = tuple(bool(b) for b in rng.integers(0, 2, size=4))
+    if route == "small":
+        N, sizes = 1500, rng.integers(1, 33, size=40)
+    elif route == "fused":
+        N, sizes = 12000, rng.integers(33, 160, size=110)
+    else:
+        N, sizes = 9000, rng.integers(600, 2500, size=4)
+    X = rng.standard_normal((N, K)) + 0.3
+    Y = rng.random((N, M)) if M else None
+    w = rng.random(N)
+    w[rng.choice(N, N // 20, replace=False)] = 0
+    perm = rng.permutation(N)
+    cuts = np.cumsum(sizes)
+    folds = [perm[a:b] for a, b in zip(np.concatenate([[0], cuts[:-1]]), cuts)]
+    weights = w if i % 4 else None
+    m = amd.CVMatrix(*flags, ddof=int(i % 2))
+    o = OracleCVMatrix(*flags, ddof=int(i % 2))
+    m.fit(X, Y, weights)
+    o.fit(X, Y, weights)
+    assert_normwise(m.XTX, o.XTX, TOL, "fit XTX")
+    if M:
+        (bx, by), bst = m.training_XTX_XTY_batched(folds)
+    else:
+        bx, bst = m.training_XTX_batched(folds)
+    for f in (0, len(folds) // 2, len(folds) - 1):
+        if M:
+            (rx, ry), rst = o.training_XTX_XTY(folds[f])
+            assert_normwise(by[f], ry, TOL, f"fold{f} XTY")
+        else:
+            rx, rst = o.training_XTX(folds[f])
+        assert_normwise(bx[f], rx, TOL, f"fold{f} XTX")
+        assert_stats(tuple(None if s is None else s[f] for s in bst), rst, TOL, f"fold{f}")
+        t = bx[f]
+        assert bool((t == t.T).all()), "XTX must be exactly symmetric"
