@@ -128,6 +128,7 @@ class CVMatrix:
         self._globals = None
         self._w_host = None
         self._nz_mask = None
+        self._stage_bufs = None
         self._ws = None
         self._sweep = None
         self._sweep_ws = None
@@ -407,12 +408,46 @@ class CVMatrix:
                 nz_val = csum[host_offsets[1:]] - csum[host_offsets[:-1]]
         else:
             nz_val = sizes.copy()
-        # one host->device copy for both arrays: [offsets | idx]
-        packed = np.concatenate([host_offsets, idx])
+        # one host->device copy for both arrays, [offsets | idx], through a pinned staging
+        # buffer and asynchronous on the stream: a pageable copy would hold the host until the
+        # device has drained the stream, and the per-fold call pattern (one small copy per
+        # call) would run host and device in turns instead of side by side
+        n_off, n_all = host_offsets.size, host_offsets.size + idx.size
+        if sizes.size and int(sizes.max()) <= 32:
+            # tiny folds (leave-one-out style calls): the device work per call is shorter than
+            # the host's; the plain copy costs the host less than staging does
+            with torch.cuda.device(self.device):
+                d_all = torch.from_numpy(np.concatenate([host_offsets, idx])).to(self.device)
+            return FoldBatch(d_all[n_off:], d_all[:n_off], host_offsets, nz_val, labels, idx, self.N)
         with torch.cuda.device(self.device):
-            d_all = torch.from_numpy(packed).to(self.device)
-        d_off, d_idx = d_all[:host_offsets.size], d_all[host_offsets.size:]
+            stage = self._staging(n_all)
+            view = stage.numpy()
+            view[:n_off] = host_offsets
+            view[n_off:n_all] = idx
+            d_all = torch.empty(n_all, dtype=torch.int64, device=self.device)
+            d_all.copy_(stage[:n_all], non_blocking=True)
+            self._stage_events[self._stage_next - 1].record()
+        d_off, d_idx = d_all[:n_off], d_all[n_off:]
         return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N)
+
+    def _staging(self, n: int) -> torch.Tensor:
+        """Next pinned int64 staging buffer of a small ring (reused once the copy that last
+        read it has completed)."""
+        ring = 8
+        if self._stage_bufs is None:
+            self._stage_bufs, self._stage_events, self._stage_next = [None] * ring, [None] * ring, 0
+        k = self._stage_next % ring
+        self._stage_next = k + 1
+        ev = self._stage_events[k]
+        if ev is not None:
+            ev.synchronize()
+        buf = self._stage_bufs[k]
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 4096), dtype=torch.int64, pin_memory=True)
+            self._stage_bufs[k] = buf
+        if ev is None:
+            self._stage_events[k] = torch.cuda.Event()
+        return buf
 
     def _validate(self, batch: FoldBatch, need_stats: bool, need_std: bool) -> None:
         """The reference's data-dependent raises, in its order (zero check first, weighted
