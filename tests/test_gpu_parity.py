@@ -778,3 +778,22 @@ def test_random_shape_sweep_float64_fast_path(amd, i, K, M, route):
         assert_stats(tuple(None if s is None else s[f] for s in bst), rst, TOL, f"fold{f}")
         t = bx[f]
         assert bool((t == t.T).all()), "XTX must be exactly symmetric"
+
+
+def test_c_abi_from_plain_c(amd, tmp_path):
+    """examples/cabi_client.c: the library driven from plain C11 through include/cvmhip.h
+    (HIP runtime allocations, no Python objects, no torch): fit stage + fold stage, checked in
+    the program itself against a direct float64 computation from the training rows."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_client")
+    libdir = os.path.join(root, "cvmatrix_amd")
+    cmd = ["gcc", "-std=c11", "-O2", os.path.join(root, "examples", "cabi_client.c"),
+           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-L" + libdir, "-lcvmhip",
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm",
+           "-o", exe]
+    subprocess.run(cmd, check=True, timeout=300, capture_output=True)
+    out = subprocess.run([exe], check=False, timeout=300, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
