@@ -24,6 +24,7 @@ EXPORTS = (
     "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_plan_fold",
     "cvm_timing_enable", "cvm_timing_read",
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds",
+    "cvm_partition_workspace_bytes", "cvm_partition_labels",
 )
 
 _lib = None
@@ -65,6 +66,10 @@ def load():
     lib.cvm_sweep_folds.restype = C.c_int
     lib.cvm_sweep_folds.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int, u32, dbl, dbl, C.c_int,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, vp]
+    lib.cvm_partition_workspace_bytes.restype = sz
+    lib.cvm_partition_workspace_bytes.argtypes = [i64, C.c_int]
+    lib.cvm_partition_labels.restype = C.c_int
+    lib.cvm_partition_labels.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp, vp, sz, vp]
     lib.cvm_timing_enable.restype = C.c_int
     lib.cvm_timing_enable.argtypes = [C.c_int]
     lib.cvm_timing_read.restype = C.c_int

@@ -32,6 +32,7 @@ namespace {
 #include "colstats.hpp"
 #include "small_folds.hpp"
 #include "host.hpp"
+#include "partition.hpp"
 
 }  // namespace
 
@@ -167,6 +168,17 @@ int cvm_sweep_folds(const int64_t *offsets, int64_t n_folds, int K, int M, int d
                                    gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold,
                                    ws, ws_bytes, splits, (hipStream_t)stream);
   return fail(CVM_EINVAL, "cvm_sweep_folds: dtype must be CVM_F32 or CVM_F64%s");
+}
+
+size_t cvm_partition_workspace_bytes(int64_t N, int n_labels) { return partition_workspace_bytes(N, n_labels); }
+
+int cvm_partition_labels(const int64_t *labels, int64_t N, int n_labels, int64_t *idx_out,
+                         int64_t *offsets_out, int64_t *first_out, int32_t *err_flag, void *ws,
+                         size_t ws_bytes, void *stream) {
+  if (!labels || !idx_out || !offsets_out || !first_out || !err_flag || !ws || N < 0)
+    return fail(CVM_EINVAL, "cvm_partition_labels: bad argument%s");
+  return partition_impl(labels, N, n_labels, idx_out, offsets_out, first_out, err_flag, ws, ws_bytes,
+                        (hipStream_t)stream);
 }
 
 int cvm_timing_enable(int on) {

@@ -430,6 +430,62 @@ class CVMatrix:
         d_off, d_idx = d_all[:n_off], d_all[n_off:]
         return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N)
 
+    def prepare_folds_from_labels(self, labels, n_labels: Optional[int] = None) -> FoldBatch:
+        """Device-side ``Partitioner``: one integer fold label per row (NumPy array or tensor,
+        values in ``[0, n_labels)``, at most 4096 labels) -> a ``FoldBatch`` built by
+        ``cvm_partition_labels`` without the host ever grouping the rows.  Folds are ordered by
+        first appearance of their label, like the reference's ``folds_dict``
+        (partitioner.py:101-107); ``batch.labels`` lists the labels in that order."""
+        if self.X is None:
+            raise RuntimeError("call fit() first")
+        lib = _lib.load()
+        dev = self.device
+        with torch.cuda.device(dev):
+            if isinstance(labels, torch.Tensor):
+                lab = labels.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+            else:
+                lab = torch.from_numpy(np.ascontiguousarray(np.asarray(labels).reshape(-1),
+                                                            dtype=np.int64)).to(dev)
+            if lab.numel() != self.N:
+                raise ValueError("one fold label per row is needed")
+            L = int(n_labels) if n_labels is not None else int(lab.max().item()) + 1
+            idx = torch.empty(self.N, dtype=torch.int64, device=dev)
+            offs = torch.empty(L + 1, dtype=torch.int64, device=dev)
+            first = torch.empty(L, dtype=torch.int64, device=dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws = torch.empty(int(lib.cvm_partition_workspace_bytes(self.N, L)), dtype=torch.uint8,
+                             device=dev)
+            rc = lib.cvm_partition_labels(lab.data_ptr(), self.N, L, idx.data_ptr(), offs.data_ptr(),
+                                          first.data_ptr(), err.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), self._stream())
+            _lib.check(rc, "cvm_partition_labels")
+            h_offs, h_first = offs.cpu().numpy(), first.cpu().numpy()
+            if int(err.item()) != 0:
+                raise ValueError(f"fold labels must be integers in [0, {L})")
+            present = np.flatnonzero(h_first < self.N)
+            order = present[np.argsort(h_first[present], kind="stable")]     # first-seen order
+            sizes = (h_offs[1:] - h_offs[:-1])[order]
+            host_offsets = np.zeros(order.size + 1, dtype=np.int64)
+            np.cumsum(sizes, out=host_offsets[1:])
+            if np.array_equal(order, np.arange(L)):
+                d_idx, d_off = idx, offs                    # already in fold order
+            else:
+                # gather the folds' segments into first-seen order on the device
+                seg_start = torch.from_numpy(h_offs[:-1][order].copy()).to(dev)
+                new_off = torch.from_numpy(host_offsets).to(dev)
+                pos = torch.arange(self.N, dtype=torch.int64, device=dev)
+                f_of = torch.searchsorted(new_off[1:], pos, right=True)
+                d_idx = idx[seg_start[f_of] + (pos - new_off[f_of])]
+                d_off = new_off
+            if self.weights is not None:
+                nzmask = (self.weights.reshape(-1) != 0).to(torch.int64)
+                csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                  torch.cumsum(nzmask[d_idx], 0)])
+                nz_val = (csum[d_off[1:]] - csum[d_off[:-1]]).cpu().numpy()
+            else:
+                nz_val = sizes.copy()
+        return FoldBatch(d_idx, d_off, host_offsets, nz_val, [int(v) for v in order], None, self.N)
+
     def _staging(self, n: int) -> torch.Tensor:
         """Next pinned int64 staging buffer of a small ring (reused once the copy that last
         read it has completed)."""

@@ -797,3 +797,35 @@ def test_c_abi_from_plain_c(amd, tmp_path):
     subprocess.run(cmd, check=True, timeout=300, capture_output=True)
     out = subprocess.run([exe], check=False, timeout=300, capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("N,L", [(50000, 37), (4096, 4096), (1000, 1), (70001, 300)])
+def test_device_partitioner_matches_host_partitioner(amd, N, L):
+    """cvm_partition_labels (CVMatrix.prepare_folds_from_labels): the same folds, in the same
+    first-seen order with ascending indices, as the host Partitioner builds from the labels
+    (cvmatrix/partitioner.py:89-107) -- and the same fold update from either."""
+    import torch
+
+    rng = np.random.default_rng(N + L)
+    labels = rng.integers(0, L, size=N) if L < N else rng.permutation(N)
+    K, M = 24, 2
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    w[rng.choice(N, N // 10, replace=False)] = 0
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    part = amd.Partitioner(labels)
+    hb = m.prepare_folds(part)
+    for src in (labels, torch.from_numpy(labels).to(m.device)):
+        db = m.prepare_folds_from_labels(src, n_labels=L)
+        assert db.labels == [int(k) for k in part.folds_dict]
+        assert np.array_equal(db.host_offsets, hb.host_offsets)
+        assert bool((db.idx == hb.idx).all()) and bool((db.offsets == hb.offsets).all())
+        assert np.array_equal(db.nz_val, hb.nz_val)
+    if 1 < L <= 300:
+        (a, b), sa = m.training_XTX_XTY_batched(hb)
+        (c, d), sc = m.training_XTX_XTY_batched(db)
+        assert bool((a == c).all()) and bool((b == d).all())
+    with pytest.raises(ValueError):
+        bad = labels.copy()
+        bad[3] = L
+        m.prepare_folds_from_labels(bad, n_labels=L)
