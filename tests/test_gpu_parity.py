@@ -829,3 +829,65 @@ def test_device_partitioner_matches_host_partitioner(amd, N, L):
         bad = labels.copy()
         bad[3] = L
         m.prepare_folds_from_labels(bad, n_labels=L)
+
+
+def _sharded_worker(rank, world, port, tmp, mode):
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cvmatrix_amd import CVMatrix
+        from cvmatrix_amd.distributed import ShardedCVMatrix
+
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(9)
+        N, K, M, P = 8000, 130, 4, 8
+        X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+        w[::13] = 0.0
+        full = CVMatrix()
+        full.fit(X, Y, w)
+        if mode == "row_sharded":
+            rows = np.arange(N).reshape(world, N // world)[rank]
+            sh = ShardedCVMatrix(mode="row_sharded")
+            sh.fit(X[rows], Y[rows], w[rows])
+            local = [np.arange(i, rows.size, P // world) for i in range(P // world)]
+            glob = [rows[v] for v in local]
+        else:
+            sh = ShardedCVMatrix(mode="replicated")
+            sh.fit(X, Y, w)
+            all_folds = [np.arange(i, N, P) for i in range(P)]
+            mine = sh.my_folds([len(v) for v in all_folds])
+            local = glob = [all_folds[f] for f in mine]
+        assert torch.allclose(sh.XTX, full.XTX, rtol=1e-12, atol=1e-12)
+        assert torch.allclose(sh.XTY, full.XTY, rtol=1e-12, atol=1e-12)
+        (a, b), sa = sh.training_XTX_XTY_batched(local)
+        (c, d), sc = full.training_XTX_XTY_batched(glob)
+        assert torch.allclose(a, c, rtol=1e-10, atol=1e-10) and torch.allclose(b, d, rtol=1e-10, atol=1e-10)
+        for s, t in zip(sa, sc):
+            assert torch.allclose(s, t, rtol=1e-10, atol=1e-12)
+        open(os.path.join(tmp, f"ok_{mode}_{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["row_sharded", "replicated"])
+def test_two_ranks_share_one_gpu(amd, tmp_path, mode):
+    """ShardedCVMatrix with two processes (gloo rendezvous, both on cuda:0): row-sharded fit +
+    one all-reduce of the contiguous [G | H | gstats] buffer, or replicated fit + one broadcast;
+    every rank's folds equal the single-process result.  (On the 8-GPU node the same code runs
+    with backend "nccl" = RCCL, one rank per GPU.)"""
+    import os
+
+    import torch.multiprocessing as mp
+
+    port = 29600 + (os.getpid() % 1500) + (7 if mode == "replicated" else 0)
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    assert (tmp_path / f"ok_{mode}_0").exists() and (tmp_path / f"ok_{mode}_1").exists()
