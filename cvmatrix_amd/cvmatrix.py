@@ -209,7 +209,7 @@ class CVMatrix:
                 self.weights, self._w_host, self._w_checked = None, None, None
             M = self.M or 0
             self._alloc_globals(lib.cvm_gstats_len(self.K, M))
-            neg = torch.zeros(1, dtype=torch.int32, device=self.device)
+            neg = torch.empty(1, dtype=torch.int32, device=self.device)   # always written by fit_stats_kernel
             if folds is not None:
                 self._fit_sweep(lib, folds, neg)
             else:
