@@ -117,10 +117,10 @@ def main():
         torch.cuda.synchronize()
 
     # the GPU needs ~30 ms of work to reach its steady clocks: bring it there whatever --warmup says
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.08:
+    # (a fixed number of steps, the same on every rank: the step contains a collective when N > 1)
+    for _ in range(75 if args.workload in ("C2", "C3") else 3):
         out = step()
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = step()
     fence()
