@@ -254,9 +254,12 @@ __device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const doubl
 // ordered sum of the split partials (16-byte loads, four in flight, added in split order)
 // staged in LDS, then finish_store_tile: total - partial, rank-1 centring, outer-std scaling
 // and the mirrored store.  HBM-bound.
-constexpr int APPLY_THREADS = 256;
+constexpr int APPLY_THREADS = 256;        // fold mode: one workgroup per (fold, sub-tile), plenty of them
+constexpr int APPLY_THREADS_FIT = 1024;   // fit mode: 44 workgroups at K = 512 -- more threads each
 constexpr int APPLY_SUB = 4;   // 64x64 sub-tiles per 128x128 tile
-template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) void apply_kernel(const FinArgs a) {
+template <typename T, bool FOLD>
+__global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void apply_kernel(const FinArgs a) {
+  constexpr int NTHR = FOLD ? APPLY_THREADS : APPLY_THREADS_FIT;
   const Geom &g = a.g;
   const int f = blockIdx.y;
   const int x = blockIdx.x;
@@ -286,12 +289,12 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
     // every thread owns NQ 16-byte pieces of the sub-tile; the splits are summed in order, the
     // pieces of one split loaded together (NQ independent loads in flight: a fit with 25 splits
     // is otherwise one long chain of dependent latencies on 44 workgroups)
-    constexpr int NQ = ST * LPR / APPLY_THREADS;
+    constexpr int NQ = ST * LPR / NTHR;
     double v[NQ][VW];
     const char *pp[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-      const int q = tid + j * APPLY_THREADS;
+      const int q = tid + j * NTHR;
       const int lr = q / LPR, lc = (q - lr * LPR) * VW;
       const size_t off = (size_t)t * TILE * TILE + (size_t)(si * ST + lr) * TILE + sj * ST + lc;
       pp[j] = ws0 + off * sizeof(T);
@@ -310,7 +313,7 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-      const int q = tid + j * APPLY_THREADS;
+      const int q = tid + j * NTHR;
       const int lr = q / LPR, lc = (q - lr * LPR) * VW;
 #pragma unroll
       for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = v[j][e];
@@ -318,14 +321,14 @@ template <typename T, bool FOLD> __global__ __launch_bounds__(APPLY_THREADS) voi
     __syncthreads();
     T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
     finish_store_tile<T, FOLD>(Ts, ti == tj && si == sj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX,
-                               tid, APPLY_THREADS);
+                               tid, NTHR);
   } else {
     if (!a.out_XTY || M == 0) return;
     const int ti = x - g.nTiles * APPLY_SUB;
     T *out = (T *)a.out_XTY + (FOLD ? fo * (size_t)K * M : 0);
     const T *Ht = (const T *)a.H;
     const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
-    for (int e = threadIdx.x; e < TILE * M; e += APPLY_THREADS) {
+    for (int e = threadIdx.x; e < TILE * M; e += NTHR) {
       const int ra = e / M, m = e - ra * M;
       const int ga = ti * TILE + ra;
       if (ga >= K) continue;

@@ -194,7 +194,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
   hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
   hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
-                     dim3(APPLY_THREADS), 0, st, f);
+                     dim3(APPLY_THREADS_FIT), 0, st, f);
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
@@ -440,7 +440,7 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
   hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
   hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
-                     dim3(APPLY_THREADS), 0, st, f);
+                     dim3(APPLY_THREADS_FIT), 0, st, f);
   HIP_OK(hipGetLastError());
   if (splits_out) *splits_out = p.splits;
   return CVM_OK;
