@@ -223,7 +223,9 @@ int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtyp
   // kernel 36 (the upper triangle of its 8 x 8 grid) + 8 per 16 live columns of the first Y
   // chunk; in the general kernel, or when folds are finished in the epilogue, 3 blocks of 16 +
   // 16 for XTY
-  const bool tri = dtype == CVM_F64 && ((size_t)K * 8) % 16 == 0 && M % 2 == 0 && !(fold_mode && p.splits == 1);
+  const int es_ = dtype == CVM_F64 ? 8 : 4;
+  const bool tri = ((size_t)K * es_) % 16 == 0 && (es_ == 4 || M % 2 == 0) &&
+                   !(es_ == 8 && fold_mode && p.splits == 1);
   if (!p.g.diag_only) per4 += (int64_t)(p.g.nTiles - p.g.P) * 64 + (int64_t)p.g.P * (tri ? 36 : 48);
   if (M > 0) {
     if (tri && !p.g.diag_only) per4 += (int64_t)p.g.P * (M > 16 ? 16 : 8) + (int64_t)p.g.P * (p.g.Yc - 1) * 16;

@@ -59,9 +59,9 @@ int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g, int TARGET_WG)
 // which Gram kernel variant a problem gets (pointers from torch are 256-byte aligned; a
 // misaligned X falls back to the register path at launch, only the split heuristic differs)
 int target_wg(int K, int M, int esize) {
-  return (esize == 8 && ((size_t)K * esize) % 16 == 0 && M % 2 == 0) ? TARGET_WG_2 : TARGET_WG_1;
+  const bool fastshape = ((size_t)K * esize) % 16 == 0 && (esize == 4 || M % 2 == 0);
+  return fastshape ? TARGET_WG_2 : TARGET_WG_1;
 }
-
 int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsigned flags,
               size_t ws_bytes, bool fold_mode, Plan &p) {
   const int esize = dtype == CVM_F64 ? 8 : 4;
@@ -81,8 +81,10 @@ int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsign
 // can this problem take the float64 LDS-DMA kernel (wgram4_kernel)?
 template <typename T> bool wgram4_ok(const WgramArgs<T> &a, bool aligned) {
   static const bool force_fallback = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
-  return sizeof(T) == 8 && aligned && (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) &&
-         ((uintptr_t)a.w % 8 == 0) && !force_fallback;
+  if (force_fallback || !aligned) return false;   // aligned: X and its rows on 16-byte boundaries
+  if (sizeof(T) == 8)   // the Y tile rows go by 16-byte pieces too: M even, Y 16-byte aligned
+    return (a.g.M % 2 == 0) && ((uintptr_t)a.Y % 16 == 0) && ((uintptr_t)a.w % 8 == 0);
+  return ((uintptr_t)a.Y % 4 == 0) && ((uintptr_t)a.w % 4 == 0);   // float32: Y and w by dwords
 }
 
 template <typename T>
@@ -121,39 +123,29 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     tl->kind = g_timing_kind;
     HIP_OK(hipEventRecord(tl->a, st));
   }
-  constexpr bool CAN_DMA = sizeof(T) == 8;
   const bool fast = wgram4_ok<T>(a, aligned) && !(dbg_env & 16);
-  if (fused && !(fast && gather)) return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
+  if (fused && !(fast && gather && sizeof(T) == 8))
+    return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
   if (fast) {
-    if constexpr (CAN_DMA) {
-      const dim3 block4(NT4);
-#define CVM_LAUNCH4(W, GA)                                                                  \
+    const dim3 block4(NT4);
+    const size_t lds4 = lds4_bytes<T>();
+#define CVM_LAUNCH4(W, GA, FU)                                                              \
   do {                                                                                      \
     static unsigned long long attr_done = 0;                                                \
     if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
-      HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<W, GA>,                        \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4_BYTES)); \
+      HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<T, W, GA, FU>,                 \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));   \
       attr_done |= 1ull << (dev & 63);                                                      \
     }                                                                                       \
-    hipLaunchKernelGGL((wgram4_kernel<W, GA>), grid, block4, LDS4_BYTES, st, args);         \
+    hipLaunchKernelGGL((wgram4_kernel<T, W, GA, FU>), grid, block4, lds4, st, args);        \
   } while (0)
-      if (fused) {
-#define CVM_LAUNCH4F(W)                                                                     \
-  do {                                                                                      \
-    static unsigned long long attr_done = 0;                                                \
-    if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
-      HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<W, true, true>,                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4_BYTES)); \
-      attr_done |= 1ull << (dev & 63);                                                      \
-    }                                                                                       \
-    hipLaunchKernelGGL((wgram4_kernel<W, true, true>), grid, block4, LDS4_BYTES, st, args); \
-  } while (0)
-        if (weighted) CVM_LAUNCH4F(true); else CVM_LAUNCH4F(false);
-#undef CVM_LAUNCH4F
-      } else if (weighted) { if (gather) CVM_LAUNCH4(true, true); else CVM_LAUNCH4(true, false); }
-      else { if (gather) CVM_LAUNCH4(false, true); else CVM_LAUNCH4(false, false); }
+    if (fused) {
+      if constexpr (sizeof(T) == 8) {
+        if (weighted) CVM_LAUNCH4(true, true, true); else CVM_LAUNCH4(false, true, true);
+      }
+    } else if (weighted) { if (gather) CVM_LAUNCH4(true, true, false); else CVM_LAUNCH4(true, false, false); }
+    else { if (gather) CVM_LAUNCH4(false, true, false); else CVM_LAUNCH4(false, false, false); }
 #undef CVM_LAUNCH4
-    }
   } else if (weighted) {
     if (gather) { if (aligned) CVM_LAUNCH(true, true, true); else CVM_LAUNCH(true, true, false); }
     else { if (aligned) CVM_LAUNCH(true, false, true); else CVM_LAUNCH(true, false, false); }
@@ -317,7 +309,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     WgramArgs<T> probe;
     memset(&probe, 0, sizeof(probe));
     probe.Y = (const T *)Y; probe.w = (const T *)w; probe.g = p.g;
-    if (p.splits == 1 && want_xtx && !no_fused && wgram4_ok<T>(probe, aligned)) {
+    if (sizeof(T) == 8 && p.splits == 1 && want_xtx && !no_fused && wgram4_ok<T>(probe, aligned)) {
       Geom gs = make_geom(K, M, sizeof(T), 1);
       gs.tile_elems = 0; gs.h_elems = 0;
       gs.unit_bytes = align_up(gs.stat_len * 8, 256);

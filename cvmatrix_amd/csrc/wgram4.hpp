@@ -1,10 +1,10 @@
 // wgram4.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
-// wgram4_kernel: the float64 LDS-DMA Gram kernel (4 compute + 4 loader waves), with the fused
-// single-split epilogue.
+// wgram4_kernel<T>: the LDS-DMA Gram kernel (4 compute + 4 loader waves) for float64 and float32,
+// with the fused single-split epilogue (float64).
 #pragma once
 
 // ----------------------------------------------------------------------------------
-// wgram4_kernel: the fast path (float64, 16-byte aligned rows, even M).
+// wgram4_kernel: the fast path (16-byte aligned rows; float64: even M; float32: K % 4 == 0).
 //
 // Same work decomposition, LDS stage image and partial layout as wgram_kernel, but the
 // eight waves of a workgroup (one workgroup per CU) are specialised:
@@ -31,7 +31,8 @@
 // ----------------------------------------------------------------------------------
 constexpr int NT4 = 512;
 constexpr int NBUF4 = 4;        // LDS stage buffers
-constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;
+constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;   // float64; float32 uses half of it
+template <typename T> constexpr size_t lds4_bytes() { return (size_t)NBUF4 * BUF_ELEMS * sizeof(T); }
 
 // The body is instantiated once per wave role and kept out of line: inlined together, the
 // register allocator has to give all roles one common assignment of the 128 accumulator
@@ -45,14 +46,13 @@ __device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const doubl
                                                    double swt, bool cX, bool sX, int lane);
 constexpr int WAVE_LDS_DOUBLES = 64 * 65 + 256;   // a wave's 64x64 block + row/column means and stds
 
-template <bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
-__device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
-  typedef double T;
-  typedef MF<double>::acc_t acc_t;
+template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
+__device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
+  typedef typename MF<T>::acc_t acc_t;
 #ifdef CVM_STAMPS
   const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
 #endif
-  const WgramArgs<double> a = scalarize(a_ref);
+  const WgramArgs<T> a = scalarize(a_ref);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const Geom &g = a.g;
@@ -103,15 +103,22 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
     // columns >= K that nothing reads.  Rows past the end read a zero line.
     const int d = wave_all - 4;
     const char *zero_src = reinterpret_cast<const char *>(unip(g_zero_line));
-    const char *one_src = reinterpret_cast<const char *>(unip(g_one_line));
-    int oa = 2 * lane, ob = 2 * lane, oy = 2 * (lane & 15);
-    if (colA0 + oa > g.K - 2) oa = g.K - 2 - colA0;
-    if (colB0 + ob > g.K - 2) ob = g.K - 2 - colB0;
+    constexpr unsigned ES = sizeof(T);
+    constexpr int EPL = 16 / (int)ES;          // elements per lane of a 16-byte piece
+    const char *one_src = reinterpret_cast<const char *>(ES == 8 ? (const void *)unip(g_one_line)
+                                                                : (const void *)unip(g_one_line_f));
+    // float64: 64 lanes x 16 B = one 1 KiB panel row, the Y tile row by 16 lanes x 16 B (M even),
+    // the weight by 2 lanes x 4 B; float32: 32 lanes x 16 B = one 512 B panel row, the Y tile row
+    // by 32 lanes x 4 B (any M), the weight by 1 lane x 4 B
+    int oa = EPL * lane, ob = EPL * lane, oy = ES == 8 ? 2 * (lane & 15) : (lane & 31);
+    if (colA0 + oa > g.K - EPL) oa = g.K - EPL - colA0;
+    if (colB0 + ob > g.K - EPL) ob = g.K - EPL - colB0;
     if (oa < 0) oa = 0;
     if (ob < 0) ob = 0;
     const int ycol0 = yc * YT;
-    if (g.M > 0) { if (ycol0 + oy > g.M - 2) oy = g.M - 2 - ycol0; if (oy < 0) oy = 0; } else oy = 0;
-    const unsigned va = 8u * (unsigned)oa, vb = 8u * (unsigned)ob, vy = 8u * (unsigned)oy, vw = 4u * (unsigned)lane;
+    const int ylast = ES == 8 ? g.M - 2 : g.M - 1;
+    if (g.M > 0) { if (ycol0 + oy > ylast) oy = ylast - ycol0; if (oy < 0) oy = 0; } else oy = 0;
+    const unsigned va = ES * (unsigned)oa, vb = ES * (unsigned)ob, vy = ES * (unsigned)oy, vw = 4u * (unsigned)lane;
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem_raw);
     auto dma16_all = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
       unsigned keep;
@@ -123,6 +130,24 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
       unsigned keep; unsigned long long ex;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
                    "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma16_lo32 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep; unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffffffff\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma4_lo32 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep; unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffffffff\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dword %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto dma4_lo1 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
+      unsigned keep; unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dword %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
     };
     auto dma4_lo2 = [&](const char *sbase, unsigned voff, unsigned lds_addr) {
@@ -166,23 +191,28 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
       rn[0] = v0; rn[1] = v1; rn[2] = v2; rn[3] = v3;
     };
     auto issue_stage = [&](int t, const int64_t (&rn)[4], const bool (&ok)[4]) {
-      const unsigned bufb = lds0 + (unsigned)((t % NBUF4) * BUF_ELEMS) * 8u;
+      const unsigned bufb = lds0 + (unsigned)((t % NBUF4) * BUF_ELEMS) * ES;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int lrow = d + 4 * j;
         const bool valid = ok[j];
         const char *xrow = reinterpret_cast<const char *>(a.X + rn[j] * (int64_t)g.K);
-        dma16_all(valid ? xrow + 8 * (int64_t)colA0 : zero_src, va, bufb + (unsigned)(lrow * PITCH) * 8u);
+        const char *pa = valid ? xrow + (int64_t)ES * colA0 : zero_src;
+        if (ES == 8) dma16_all(pa, va, bufb + (unsigned)(lrow * PITCH) * ES);
+        else dma16_lo32(pa, va, bufb + (unsigned)(lrow * PITCH) * ES);
         if (!diag) {
-          dma16_all(valid ? xrow + 8 * (int64_t)colB0 : zero_src, vb,
-                    bufb + (unsigned)(PANEL_ELEMS + lrow * PITCH) * 8u);
+          const char *pb = valid ? xrow + (int64_t)ES * colB0 : zero_src;
+          if (ES == 8) dma16_all(pb, vb, bufb + (unsigned)(PANEL_ELEMS + lrow * PITCH) * ES);
+          else dma16_lo32(pb, vb, bufb + (unsigned)(PANEL_ELEMS + lrow * PITCH) * ES);
         } else {
           const char *yrow = (valid && g.M > 0)
               ? reinterpret_cast<const char *>(a.Y + rn[j] * (int64_t)g.M + ycol0) : zero_src;
-          dma16_lo16(yrow, vy, bufb + (unsigned)(PANEL_ELEMS + lrow * YPITCH) * 8u);
+          if (ES == 8) dma16_lo16(yrow, vy, bufb + (unsigned)(PANEL_ELEMS + lrow * YPITCH) * ES);
+          else dma4_lo32(yrow, vy, bufb + (unsigned)(PANEL_ELEMS + lrow * YPITCH) * ES);
         }
         const char *wsrc = valid ? (WEIGHTED ? reinterpret_cast<const char *>(a.w + rn[j]) : one_src) : zero_src;
-        dma4_lo2(wsrc, vw, bufb + (unsigned)(2 * PANEL_ELEMS + lrow) * 8u);
+        if (ES == 8) dma4_lo2(wsrc, vw, bufb + (unsigned)(2 * PANEL_ELEMS + lrow) * ES);
+        else dma4_lo1(wsrc, vw, bufb + (unsigned)(2 * PANEL_ELEMS + lrow) * ES);
       }
     };
     // 12 LDS-DMA instructions per stage; ONE stage may stay in flight across a barrier, so
@@ -383,7 +413,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
   }
 #endif
 
-  if (FUSEDR) {
+  if constexpr (FUSEDR && sizeof(T) == 8) {
     // ---- fused single-split epilogue: no partials, no apply kernel --------------------------
     // The fold's statistics are already in a.fstats (colstats_kernel + fold_stats_kernel ran
     // first); every wave finishes its own block: total - update, rank-1 centring, outer-std
@@ -516,11 +546,10 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<double> &a_ref) {
 // Nothing below the diagonal tiles is computed: the finalize kernels mirror the upper ones.
 //   YSTAT: this wave also sums the Y columns, sw and nz (wave 3 of panel 0)
 // ----------------------------------------------------------------------------------
-template <bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT, bool FUSEDR = false>
-__device__ __noinline__ void wgram4_diag_body(const WgramArgs<double> &a_ref) {
-  typedef double T;
-  typedef MF<double>::acc_t acc_t;
-  const WgramArgs<double> a = scalarize(a_ref);
+template <typename T, bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT, bool FUSEDR = false>
+__device__ __noinline__ void wgram4_diag_body(const WgramArgs<T> &a_ref) {
+  typedef typename MF<T>::acc_t acc_t;
+  const WgramArgs<T> a = scalarize(a_ref);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const Geom &g = a.g;
@@ -617,7 +646,7 @@ __device__ __noinline__ void wgram4_diag_body(const WgramArgs<double> &a_ref) {
     __syncthreads();   // B_s
   }
 
-  if (FUSEDR) {
+  if constexpr (FUSEDR && sizeof(T) == 8) {
     // ---- fused epilogue (one unit per fold): the four waves put their tiles of the upper
     // triangle into one 128 x 128 image in the LDS ring, then waves 0, 1 and 3 finish the
     // 64 x 64 blocks (0,0), (0,1) and (1,1) as in wgram4_body; every wave finishes the XTY
@@ -730,8 +759,8 @@ __device__ __noinline__ void wgram4_diag_body(const WgramArgs<double> &a_ref) {
       tp[(16 * R1 + MF<T>::drow(lane, r)) * TILE + 16 * (R1 + j) + lc] = acc[NB0 + j][r];
 }
 
-template <bool WEIGHTED, bool GATHER, bool FUSED = false>
-__global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> a) {
+template <typename T, bool WEIGHTED, bool GATHER, bool FUSED = false>
+__global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
   // role of this wave (same decode as in the body)
   const Geom &g = a.g;
   const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -748,9 +777,9 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
       o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
     }
   };
-  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3, FUSED>(a); fin(); return; }
+  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(a); fin(); return; }
 #else
-  if (wave_all >= 4) { wgram4_body<WEIGHTED, GATHER, false, false, 3, FUSED>(a); return; }
+  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(a); return; }
 #endif
   const int it = (int)(item % g.nT);
   int ti, tj, yc;
@@ -764,8 +793,8 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
     const bool wide = g.M > 16;
 #define CVM_DIAGF(WV)                                                                        \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<WEIGHTED, GATHER, WV, 2, false, true>(a);                   \
-      else wgram4_diag_body<WEIGHTED, GATHER, WV, 1, false, true>(a);                        \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false, true>(a);                   \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false, true>(a);                        \
     } while (0)
     if (wave == 0) CVM_DIAGF(0);
     else if (wave == 1) CVM_DIAGF(1);
@@ -778,9 +807,9 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
     return;
   }
   if (FUSED) {   // statistics come from colstats_kernel: no summing roles
-    if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0, true>(a);
-    else if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0, true>(a);
-    else wgram4_body<WEIGHTED, GATHER, false, false, 0, true>(a);
+    if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0, true>(a);
+    else if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0, true>(a);
+    else wgram4_body<T, WEIGHTED, GATHER, false, false, 0, true>(a);
 #ifdef CVM_STAMPS
     fin();
 #endif
@@ -791,15 +820,15 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
     const bool wide = g.M > 16, ys = (ti == 0);
 #define CVM_DIAG(WV)                                                                         \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<WEIGHTED, GATHER, WV, 2, false>(a);                         \
-      else wgram4_diag_body<WEIGHTED, GATHER, WV, 1, false>(a);                              \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false>(a);                         \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false>(a);                              \
     } while (0)
     if (wave == 0) CVM_DIAG(0);
     else if (wave == 1) CVM_DIAG(1);
     else if (wave == 2) CVM_DIAG(2);
     else if (!ys) CVM_DIAG(3);
-    else if (wide) wgram4_diag_body<WEIGHTED, GATHER, 3, 2, true>(a);
-    else wgram4_diag_body<WEIGHTED, GATHER, 3, 1, true>(a);
+    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true>(a);
+    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true>(a);
 #undef CVM_DIAG
 #ifdef CVM_STAMPS
     fin();
@@ -807,10 +836,10 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<double> 
     return;
   }
   const int role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
-  if (diag && wave == 2) wgram4_body<WEIGHTED, GATHER, true, true, 0>(a);
-  else if (role == 1) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 1>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 1>(a); }
-  else if (role == 2) { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 2>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 2>(a); }
-  else { if (do_g) wgram4_body<WEIGHTED, GATHER, false, true, 0>(a); else wgram4_body<WEIGHTED, GATHER, false, false, 0>(a); }
+  if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0>(a);
+  else if (role == 1) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 1>(a); else wgram4_body<T, WEIGHTED, GATHER, false, false, 1>(a); }
+  else if (role == 2) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 2>(a); else wgram4_body<T, WEIGHTED, GATHER, false, false, 2>(a); }
+  else { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0>(a); else wgram4_body<T, WEIGHTED, GATHER, false, false, 0>(a); }
 #ifdef CVM_STAMPS
   fin();
 #endif

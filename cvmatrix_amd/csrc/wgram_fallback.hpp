@@ -21,6 +21,7 @@
 // ----------------------------------------------------------------------------------
 __device__ double g_zero_line[128];  // zero-initialised at code-object load
 __device__ double g_one_line[2] = {1.0, 1.0};
+__device__ float g_one_line_f[4] = {1.0f, 1.0f, 1.0f, 1.0f};
 #ifdef CVM_STAMPS
 // diagnostic build only: per (workgroup, wave) cycle sums of the three phases of a stage
 __device__ unsigned long long g_stamps[1024 * 8 * 4];

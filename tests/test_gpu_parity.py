@@ -891,3 +891,46 @@ def test_two_ranks_share_one_gpu(amd, tmp_path, mode):
     port = 29600 + (os.getpid() % 1500) + (7 if mode == "replicated" else 0)
     mp.spawn(_sharded_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     assert (tmp_path / f"ok_{mode}_0").exists() and (tmp_path / f"ok_{mode}_1").exists()
+
+
+@pytest.mark.parametrize("K,M,route", [(4, 1, "units"), (64, 3, "units"), (132, 1, "units"), (260, 34, "units"),
+                                       (516, 16, "units"), (128, 5, "many"), (388, 0, "many"), (130, 2, "units")])
+def test_float32_shape_sweep(amd, K, M, route):
+    """float32: K a multiple of 4 takes the LDS-DMA kernel (any M: the Y tile rows go by
+    dwords), other K the general kernel (the last case); a few large folds and many mid-size
+    folds; against the float64 oracle on the float32-rounded inputs, error bounded by a small
+    multiple of float32 rounding of the sums involved."""
+    rng = np.random.default_rng(500 + K + M)
+    N = 9000
+    X = (rng.random((N, K)) + 0.1).astype(np.float32)
+    Y = rng.random((N, M)).astype(np.float32) if M else None
+    w = rng.random(N).astype(np.float32)
+    w[rng.choice(N, 300, replace=False)] = 0
+    perm = rng.permutation(N)
+    if route == "units":
+        folds = [perm[:2500], perm[2500:4000], perm[4000:]]
+    else:
+        folds = [perm[i:i + 75] for i in range(0, N, 75)]
+    for flags in [(True,) * 4, (False,) * 4]:
+        m = amd.CVMatrix(*flags, dtype=np.float32)
+        o = OracleCVMatrix(*flags, dtype=np.float64)
+        m.fit(X, Y, w)
+        o.fit(X.astype(np.float64), None if Y is None else Y.astype(np.float64), w.astype(np.float64))
+        assert_normwise(m.XTX.double(), o.XTX, 2e-5, "fit XTX")
+        if M:
+            (bx, by), bst = m.training_XTX_XTY_batched(folds)
+        else:
+            bx, bst = m.training_XTX_batched(folds)
+        for f in (0, len(folds) - 1):
+            if M:
+                (rx, ry), rst = o.training_XTX_XTY(folds[f])
+                assert_normwise(by[f].double(), ry, 3e-4 if flags[0] else 2e-5, f"fold{f} XTY")
+            else:
+                rx, rst = o.training_XTX(folds[f])
+            assert_normwise(bx[f].double(), rx, 3e-4 if flags[0] else 2e-5, f"fold{f} XTX")
+            for a_, b_ in zip(bst, rst):
+                assert (a_ is None) == (b_ is None)
+                if b_ is not None:
+                    np.testing.assert_allclose(to_np(a_[f]).astype(np.float64), b_, rtol=3e-5)
+            t = bx[f]
+            assert bool((t == t.T).all())
