@@ -160,9 +160,12 @@ def test_launch_planning_is_host_logic():
     per_fold = lib.cvm_fold_workspace_bytes(1, 10000, 10000, 512, 16, _lib.CVM_F64, 0x3F)
     small = plan(10, 10000, 512, 16, ws=int(per_fold) * 1)
     assert 1 <= small["batch"] <= 10 and small["splits"] >= 1
-    # float32 / odd shapes take the general kernel: no skipped tiles in its count
+    # float32 with K % 4 == 0 takes the LDS-DMA kernel too (balanced diagonal tiles: 36 + 8) ...
     f32 = plan(20, 10000, 4096, 1, dtype=_lib.CVM_F32)
-    assert f32["panels"] == 32 and f32["mfma_per_4_rows"] == (528 - 32) * 64 + 32 * 48 + 32 * 16
+    assert f32["panels"] == 32 and f32["mfma_per_4_rows"] == (528 - 32) * 64 + 32 * 36 + 32 * 8
+    # ... other shapes the general kernel: no skipped tiles in its count
+    odd = plan(20, 10000, 4094, 1, dtype=_lib.CVM_F32)
+    assert odd["mfma_per_4_rows"] == (528 - 32) * 64 + 32 * 48 + 32 * 16
 
 
 def test_package_metadata():
