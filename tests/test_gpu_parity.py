@@ -868,6 +868,17 @@ def _sharded_worker(rank, world, port, tmp, mode):
             local = glob = [all_folds[f] for f in mine]
         assert torch.allclose(sh.XTX, full.XTX, rtol=1e-12, atol=1e-12)
         assert torch.allclose(sh.XTY, full.XTY, rtol=1e-12, atol=1e-12)
+        if mode == "row_sharded":
+            # one-sweep variant on every rank's own rows (what bench.py times next to the headline):
+            # local validation Grams, all-reduced full-data matrices
+            sw = ShardedCVMatrix(mode="row_sharded")
+            sw.fit(X[rows], Y[rows], w[rows], folds=local)
+            assert torch.allclose(sw.XTX, full.XTX, rtol=1e-12, atol=1e-12)
+            (e, f_), se = sw.training_XTX_XTY_batched(sw.sweep_folds)
+            (c0, d0), sc0 = full.training_XTX_XTY_batched(glob)
+            assert torch.allclose(e, c0, rtol=1e-10, atol=1e-10) and torch.allclose(f_, d0, rtol=1e-10, atol=1e-10)
+            for s, t_ in zip(se, sc0):
+                assert torch.allclose(s, t_, rtol=1e-10, atol=1e-12)
         (a, b), sa = sh.training_XTX_XTY_batched(local)
         (c, d), sc = full.training_XTX_XTY_batched(glob)
         assert torch.allclose(a, c, rtol=1e-10, atol=1e-10) and torch.allclose(b, d, rtol=1e-10, atol=1e-10)
