@@ -130,10 +130,13 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
 // the lower triangle takes the update of its mirror element, so the result is exactly
 // symmetric (G is, and the corrections are products of the same two factors).
 constexpr int ST = 64;                 // tile edge of the finishing code
+// `gpre`: the tile's 16-byte pieces of G already in registers, piece j = q-th with q = tid +
+// j * nthreads (finish_tile_preload below) -- used where `full`; nullptr: load them here.
 template <typename T, bool FOLD>
 __device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool diag, int a0, int b0, int K,
                                                   const T *Gt, T *out, const double *fs, double swt,
-                                                  bool cX, bool sX, int tid, int nthreads) {
+                                                  bool cX, bool sX, int tid, int nthreads,
+                                                  const T (*gpre)[16 / sizeof(T)] = nullptr) {
   constexpr int VW = 16 / sizeof(T);            // elements per 16-byte access
   constexpr int LPR = ST / VW;                  // lanes per row segment
   typedef T vst_t __attribute__((ext_vector_type(VW)));
@@ -141,7 +144,8 @@ __device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool dia
                       (!FOLD || (uintptr_t)Gt % 16 == 0);
   for (int pass = 0; pass < (diag ? 1 : 2); ++pass) {
     const int r0g = pass ? b0 : a0, c0g = pass ? a0 : b0;
-    for (int q = tid; q < ST * LPR; q += nthreads) {
+    int jq = 0;
+    for (int q = tid; q < ST * LPR; q += nthreads, ++jq) {
       const int lr = q / LPR, lc = (q - lr * LPR) * VW;
       const int gr = r0g + lr, gc = c0g + lc;
       if (gr >= K || gc >= K) continue;
@@ -150,7 +154,10 @@ __device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool dia
       if (pass == 0) {
         T gvv[VW];
         if (FOLD) {
-          if (full) {
+          if (full && gpre) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) gvv[e] = gpre[jq][e];
+          } else if (full) {
             const vst_t t = *reinterpret_cast<const vst_t *>(Gt + (size_t)gr * K + gc);
 #pragma unroll
             for (int e = 0; e < VW; ++e) gvv[e] = t[e];
@@ -198,6 +205,29 @@ __device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool dia
       }
     }
     __syncthreads();
+  }
+}
+
+// Issue the loads of a tile's G pieces early (before the work that produces the update): piece
+// j of this thread as finish_store_tile numbers them; pieces outside the matrix or not
+// 16-byte accessible are left for finish_store_tile to load.
+template <typename T, int NQ>
+__device__ __forceinline__ void finish_tile_preload(T (&gpre)[NQ][16 / sizeof(T)], int a0, int b0, int K,
+                                                    const T *Gt, const T *out, int tid, int nthreads) {
+  constexpr int VW = 16 / sizeof(T);
+  constexpr int LPR = ST / VW;
+  typedef T vst_t __attribute__((ext_vector_type(VW)));
+  const bool vec_ok = ((size_t)K * sizeof(T)) % 16 == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)Gt % 16 == 0);
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int q = tid + j * nthreads;
+    const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+    const int gr = a0 + lr, gc = b0 + lc;
+    if (vec_ok && gr < K && gc + VW <= K) {
+      const vst_t t = *reinterpret_cast<const vst_t *>(Gt + (size_t)gr * K + gc);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) gpre[j][e] = t[e];
+    }
   }
 }
 

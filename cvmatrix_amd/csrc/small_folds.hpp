@@ -133,6 +133,11 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
     int ti, tj;
     decode_tile(x, a.P64, ti, tj);
     const int a0 = ti * ST, b0 = tj * ST;
+    // the tile of G first: its latency overlaps the staging of the rows and the update
+    constexpr int NQG = ST * (ST / (16 / (int)sizeof(T))) / 256;
+    T gpre[NQG][16 / sizeof(T)];
+    T *out = (T *)a.out_XTX + fo * (size_t)K * K;
+    finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, out, tid, 256);
     const int ty = tid >> 4, tx = tid & 15;      // rows 4ty.., columns 4tx..
     for (int e = tid; e < n * ST; e += 256) {
       const int r = e / ST, c = e - r * ST;
@@ -162,8 +167,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
 #pragma unroll
       for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
     __syncthreads();
-    T *out = (T *)a.out_XTX + fo * (size_t)K * K;
-    finish_store_tile<T, true>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256);
+    finish_store_tile<T, true>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256, gpre);
   } else {
     if (!a.out_XTY || M == 0) return;
     const int ti = x - a.nT64;
