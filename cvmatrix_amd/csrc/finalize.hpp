@@ -132,8 +132,8 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
 constexpr int ST = 64;                 // tile edge of the finishing code
 // `gpre`: the tile's 16-byte pieces of G already in registers, piece j = q-th with q = tid +
 // j * nthreads (finish_tile_preload below) -- used where `full`; nullptr: load them here.
-template <typename T, bool FOLD>
-__device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool diag, int a0, int b0, int K,
+template <typename T, bool FOLD, typename TS = double>
+__device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, int a0, int b0, int K,
                                                   const T *Gt, T *out, const double *fs, double swt,
                                                   bool cX, bool sX, int tid, int nthreads,
                                                   const T (*gpre)[16 / sizeof(T)] = nullptr) {
@@ -201,7 +201,7 @@ __device__ __forceinline__ void finish_store_tile(double (*Ts)[ST + 1], bool dia
         // park the finished values in place (off the diagonal every raw element is read by
         // this thread only) for the mirrored pass
 #pragma unroll
-        for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = (double)vals[e];
+        for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = (TS)vals[e];
       }
     }
     __syncthreads();

@@ -116,10 +116,13 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   // As: w * x, columns of the tile's rows; Bs: x (or y), columns of the tile's columns;
   // Ts: the finished tile for the transposed store -- it reuses the As/Bs space (33 KB per
   // workgroup instead of 66: four workgroups per CU keep more loads and stores in flight)
-  __shared__ __attribute__((aligned(16))) double sm[ST * (ST + 1)];
-  double (*As)[ST] = reinterpret_cast<double (*)[ST]>(sm);
-  double (*Bs)[ST] = reinterpret_cast<double (*)[ST]>(sm + SMALL_ROWS * ST);
-  double (*Ts)[ST + 1] = reinterpret_cast<double (*)[ST + 1]>(sm);
+  // (float32 problems stage and accumulate the at most 32-term updates in float32: half the LDS,
+  //  twice the workgroups per CU -- their tiles carry half the bytes for the same latencies)
+  typedef typename std::conditional<sizeof(T) == 8, double, float>::type TS;
+  __shared__ __attribute__((aligned(16))) TS sm[ST * (ST + 1)];
+  TS (*As)[ST] = reinterpret_cast<TS (*)[ST]>(sm);
+  TS (*Bs)[ST] = reinterpret_cast<TS (*)[ST]>(sm + SMALL_ROWS * ST);
+  TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm);
   __shared__ int64_t rows[SMALL_ROWS];
   __shared__ double wl[SMALL_ROWS];
   if (tid < n) {
@@ -143,17 +146,17 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
       const int r = e / ST, c = e - r * ST;
       const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
       const T xb = (b0 + c < K) ? X[rows[r] * (int64_t)K + b0 + c] : (T)0;
-      As[r][c] = (sizeof(T) == 8) ? (double)(WEIGHTED ? (T)((T)wl[r] * xa) : xa) : wl[r] * (double)xa;
-      Bs[r][c] = (double)xb;
+      As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
+      Bs[r][c] = (TS)xb;
     }
     __syncthreads();
-    double acc[4][4];
+    TS acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = 0;
     for (int r = 0; r < n; ++r) {
-      double av[4], bv[4];
+      TS av[4], bv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { av[i] = As[r][4 * ty + i]; bv[i] = Bs[r][4 * tx + i]; }
 #pragma unroll
@@ -167,7 +170,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
 #pragma unroll
       for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
     __syncthreads();
-    finish_store_tile<T, true>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256, gpre);
+    finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256, gpre);
   } else {
     if (!a.out_XTY || M == 0) return;
     const int ti = x - a.nT64;
@@ -177,13 +180,13 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
     for (int e = tid; e < n * ST; e += 256) {
       const int r = e / ST, c = e - r * ST;
       const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
-      As[r][c] = (sizeof(T) == 8) ? (double)(WEIGHTED ? (T)((T)wl[r] * xa) : xa) : wl[r] * (double)xa;
+      As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
     }
     for (int m0 = 0; m0 < M; m0 += ST) {
       __syncthreads();
       for (int e = tid; e < n * ST; e += 256) {
         const int r = e / ST, c = e - r * ST;
-        Bs[r][c] = (m0 + c < M) ? (double)Y[rows[r] * (int64_t)M + m0 + c] : 0.0;
+        Bs[r][c] = (m0 + c < M) ? (TS)Y[rows[r] * (int64_t)M + m0 + c] : (TS)0;
       }
       __syncthreads();
       const int mw = (M - m0 < ST) ? M - m0 : ST;
@@ -191,9 +194,9 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
         const int la = e / mw, lm = e - la * mw;
         const int ga = a0 + la, gm = m0 + lm;
         if (ga >= K) continue;
-        double acc = 0;
+        TS acc = 0;
         for (int r = 0; r < n; ++r) acc += As[r][la] * Bs[r][lm];
-        double v = (double)Ht[(size_t)ga * M + gm] - acc;
+        double v = (double)Ht[(size_t)ga * M + gm] - (double)acc;
         if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + gm]);
         if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + gm]);
         else if (sX) v = v / fs[K + ga];
