@@ -25,6 +25,7 @@ EXPORTS = (
     "cvm_timing_enable", "cvm_timing_read",
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds",
     "cvm_partition_workspace_bytes", "cvm_partition_labels",
+    "cvm_pls_workspace_bytes", "cvm_pls_fit", "cvm_pls_plan",
 )
 
 _lib = None
@@ -70,6 +71,13 @@ def load():
     lib.cvm_partition_workspace_bytes.argtypes = [i64, C.c_int]
     lib.cvm_partition_labels.restype = C.c_int
     lib.cvm_partition_labels.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp, vp, sz, vp]
+    lib.cvm_pls_workspace_bytes.restype = sz
+    lib.cvm_pls_workspace_bytes.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cvm_pls_fit.restype = C.c_int
+    lib.cvm_pls_fit.argtypes = [vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp,
+                                vp, vp, vp, sz, vp]
+    lib.cvm_pls_plan.restype = C.c_int
+    lib.cvm_pls_plan.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.cvm_timing_enable.restype = C.c_int
     lib.cvm_timing_enable.argtypes = [C.c_int]
     lib.cvm_timing_read.restype = C.c_int

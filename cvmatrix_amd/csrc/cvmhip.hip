@@ -33,6 +33,7 @@ namespace {
 #include "small_folds.hpp"
 #include "host.hpp"
 #include "partition.hpp"
+#include "pls.hpp"
 
 }  // namespace
 
@@ -179,6 +180,35 @@ int cvm_partition_labels(const int64_t *labels, int64_t N, int n_labels, int64_t
     return fail(CVM_EINVAL, "cvm_partition_labels: bad argument%s");
   return partition_impl(labels, N, n_labels, idx_out, offsets_out, first_out, err_flag, ws, ws_bytes,
                         (hipStream_t)stream);
+}
+
+size_t cvm_pls_workspace_bytes(int64_t n_folds, int K, int M, int A, int dtype) {
+  if (n_folds < 0 || K <= 0 || M <= 0 || M > PLS_MAXM || A <= 0 || A > PLS_MAXA) return 0;
+  return pls_workspace_bytes(n_folds, K, M, A, dtype == CVM_F64 ? 8 : 4, pls_cu_count());
+}
+
+int cvm_pls_fit(const void *XTX, const void *XTY, int64_t n_folds, int K, int M, int A, int dtype,
+                void *B, void *W, void *P, void *Q, void *R, int32_t *n_fit, int32_t *status,
+                void *ws, size_t ws_bytes, void *stream) {
+  if (!XTX || !XTY || !B || !n_fit || !status || !ws) return fail(CVM_EINVAL, "cvm_pls_fit: null pointer%s");
+  if (n_folds < 0 || K <= 0 || M <= 0 || A <= 0) return fail(CVM_EINVAL, "cvm_pls_fit: bad shape%s");
+  if (M > PLS_MAXM) return fail(CVM_EINVAL, "cvm_pls_fit: at most 32 responses%s");
+  if (A > PLS_MAXA) return fail(CVM_EINVAL, "cvm_pls_fit: at most 512 components%s");
+  if (dtype == CVM_F64)
+    return pls_fit_impl<double>(XTX, XTY, n_folds, K, M, A, B, W, P, Q, R, n_fit, status, ws, ws_bytes, (hipStream_t)stream);
+  if (dtype == CVM_F32)
+    return pls_fit_impl<float>(XTX, XTY, n_folds, K, M, A, B, W, P, Q, R, n_fit, status, ws, ws_bytes, (hipStream_t)stream);
+  return fail(CVM_EINVAL, "cvm_pls_fit: dtype must be CVM_F32 or CVM_F64%s");
+}
+
+int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info) {
+  if (!info || n_folds < 0 || K <= 0 || M <= 0 || M > PLS_MAXM || A <= 0 || A > PLS_MAXA)
+    return fail(CVM_EINVAL, "cvm_pls_plan: bad argument%s");
+  PlsPlan p;
+  if (!make_pls_plan(n_folds, K, M, A, dtype == CVM_F64 ? 8 : 4, pls_cu_count(), p))
+    return fail(CVM_EINVAL, "cvm_pls_plan: K too large for the LDS plan%s");
+  info[0] = p.S; info[1] = p.rows; info[2] = p.folds_per_launch; info[3] = p.xres; info[4] = (int64_t)p.lds;
+  return CVM_OK;
 }
 
 int cvm_timing_enable(int on) {

@@ -1,0 +1,93 @@
+"""Improved Kernel PLS (algorithm #2 of Dayal & MacGregor 1997) on the training matrices of a
+batch of folds, on the device -- the step after the cvmatrix hot path.
+
+The reference names its consumer (README.md:23, cvmatrix/partitioner.py:27-31): the ``ikpls``
+package runs this algorithm on every fold's ``(XTX, XTY)``.  Here the matrices stay where
+``CVMatrix.training_XTX_XTY_batched`` wrote them (HBM) and one launch of ``cvm_pls_fit``
+(include/cvmhip.h) fits all folds.  No CPU fallback."""
+
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_RESPONSES = 32
+MAX_COMPONENTS = 512
+
+
+class PLSFit(NamedTuple):
+    """``B`` (F,A,K,M): ``B[f, a]`` = regression coefficients with ``a + 1`` components;
+    ``W, P, R`` (F,K,A) and ``Q`` (F,M,A) when requested, else None; ``n_fit`` (F,) int32:
+    components extracted per fold (less than A only when XTY deflated to zero)."""
+    B: torch.Tensor
+    W: Optional[torch.Tensor]
+    P: Optional[torch.Tensor]
+    Q: Optional[torch.Tensor]
+    R: Optional[torch.Tensor]
+    n_fit: torch.Tensor
+
+
+def pls_plan(n_folds: int, K: int, M: int, A: int, dtype=np.float64) -> dict:
+    """How a problem is cut: row slices per fold, rows per slice, folds per launch, whether the
+    slice of XTX stays in LDS (host logic only: runs without a GPU)."""
+    lib = _lib.load()
+    info = np.zeros(5, dtype=np.int64)
+    code = _lib.CVM_F64 if np.dtype(dtype) == np.float64 else _lib.CVM_F32
+    _lib.check(lib.cvm_pls_plan(n_folds, K, M, A, code, info.ctypes.data), "cvm_pls_plan")
+    return {"slices": int(info[0]), "rows": int(info[1]), "folds_per_launch": int(info[2]),
+            "xtx_in_lds": bool(info[3]), "lds_bytes": int(info[4])}
+
+
+def pls_fit_batched(XTX: torch.Tensor, XTY: torch.Tensor, A: int, *, return_factors: bool = False,
+                    check: bool = True) -> PLSFit:
+    """Fit A-component PLS models on ``XTX`` (F,K,K) / ``XTY`` (F,K,M) device tensors (the
+    outputs of ``training_XTX_XTY_batched``; a single (K,K)/(K,M) pair is taken as F = 1).
+
+    ``check=True`` synchronises once to turn the kernel's status word into an exception."""
+    if not (isinstance(XTX, torch.Tensor) and XTX.is_cuda and isinstance(XTY, torch.Tensor) and XTY.is_cuda):
+        raise TypeError("pls_fit_batched takes device tensors (the batched training matrices).")
+    if XTX.dim() == 2:
+        XTX = XTX.unsqueeze(0)
+        XTY = XTY.unsqueeze(0) if XTY.dim() == 2 else XTY.reshape(1, -1, 1)
+    if XTX.dim() != 3 or XTY.dim() != 3 or XTX.shape[1] != XTX.shape[2] or XTY.shape[:2] != XTX.shape[:2]:
+        raise ValueError("XTX must be (F,K,K) and XTY (F,K,M).")
+    if XTX.dtype != XTY.dtype or XTX.dtype not in (torch.float64, torch.float32):
+        raise ValueError("XTX and XTY must both be float64 or both float32.")
+    F, K, M = XTY.shape
+    A = int(A)
+    if not 1 <= A <= MAX_COMPONENTS:
+        raise ValueError(f"A must be in [1, {MAX_COMPONENTS}].")
+    if not 1 <= M <= MAX_RESPONSES:
+        raise ValueError(f"The device PLS takes at most {MAX_RESPONSES} responses.")
+    XTX = XTX.contiguous()
+    XTY = XTY.contiguous()
+    lib = _lib.load()
+    dev = XTX.device
+    code = _lib.CVM_F64 if XTX.dtype == torch.float64 else _lib.CVM_F32
+    with torch.cuda.device(dev):
+        nbytes = lib.cvm_pls_workspace_bytes(F, K, M, A, code)
+        if nbytes == 0:
+            raise ValueError("K is too large for the device PLS kernel.")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        B = torch.empty((F, A, K, M), dtype=XTX.dtype, device=dev)
+        n_fit = torch.empty((F,), dtype=torch.int32, device=dev)
+        status = torch.empty((1,), dtype=torch.int32, device=dev)
+        W = P = Q = R = None
+        if return_factors:
+            W = torch.empty((F, K, A), dtype=XTX.dtype, device=dev)
+            P = torch.empty_like(W)
+            R = torch.empty_like(W)
+            Q = torch.empty((F, M, A), dtype=XTX.dtype, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.cvm_pls_fit(_lib.ptr(XTX), _lib.ptr(XTY), F, K, M, A, code, _lib.ptr(B), _lib.ptr(W),
+                             _lib.ptr(P), _lib.ptr(Q), _lib.ptr(R), _lib.ptr(n_fit), _lib.ptr(status),
+                             _lib.ptr(ws), nbytes, stream)
+        _lib.check(rc, "cvm_pls_fit")
+        ws.record_stream(torch.cuda.current_stream(dev))
+        if check and int(status.item()) != 0:
+            raise RuntimeError("cvm_pls_fit: workgroups of a fold were not co-resident (barrier timed out).")
+    return PLSFit(B, W, P, Q, R, n_fit)

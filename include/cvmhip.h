@@ -141,6 +141,27 @@ int cvm_partition_labels(const int64_t *labels, int64_t N, int n_labels, int64_t
                          int64_t *offsets_out, int64_t *first_out, int32_t *err_flag, void *ws,
                          size_t ws_bytes, void *stream);
 
+/* The step after the path: Improved Kernel PLS, algorithm #2 of Dayal &
+ * MacGregor (1997), on the training matrices of a batch of folds where cvm_fold_update left them.
+ * It is what the out-of-tree consumer named by the reference runs per fold (reference
+ * README.md:23, cvmatrix/partitioner.py:27-31: `ikpls`, fast cross-validation); the reference
+ * itself holds no PLS code, so there is no reference line to cite beyond those.
+ *   XTX [n_folds][K][K], XTY [n_folds][K][M]   the out_XTX / out_XTY of cvm_fold_update (not modified)
+ *   A                    components, 1 <= A <= 512;  M <= 32
+ *   B   [n_folds][A][K][M]   B[f][a] = regression coefficients with a+1 components (required)
+ *   W, P, R [n_folds][K][A], Q [n_folds][M][A]      weights / loadings / rotations (each may be NULL)
+ *   n_fit  int32[n_folds]    components extracted (< A only if XTY deflated to zero: the rest stay 0)
+ *   status int32[1]          0; 1 if the kernel gave up waiting for a co-resident workgroup
+ * Component signs are those of the dominant eigenvector found by repeated squaring of XTY^T XTY;
+ * B does not depend on them.  Arithmetic in float64 for both dtypes. */
+size_t cvm_pls_workspace_bytes(int64_t n_folds, int K, int M, int A, int dtype);
+int cvm_pls_fit(const void *XTX, const void *XTY, int64_t n_folds, int K, int M, int A, int dtype,
+                void *B, void *W, void *P, void *Q, void *R, int32_t *n_fit, int32_t *status,
+                void *ws, size_t ws_bytes, void *stream);
+/* info[0]=row slices per fold, [1]=rows per slice, [2]=folds per launch, [3]=1 if the slice of XTX
+ * stays in LDS, [4]=LDS bytes per workgroup */
+int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info);
+
 /* Benchmark support: when enabled, a hipEvent pair is recorded on the launch stream around
  * every launch of the Gram kernel (at most 8192 pairs between reads).  cvm_timing_read
  * waits for the recorded events, returns the summed kernel milliseconds and launch counts

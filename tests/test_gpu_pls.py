@@ -1,0 +1,160 @@
+"""GPU (-m gpu): the device PLS (cvm_pls_fit through the C ABI) against the CPU oracle
+(oracle/ikpls_oracle.py, pinned to scikit-learn) and against the scikit-learn coefficients in
+tests/golden/g8_pls.npz.
+
+Tolerance: B relative Frobenius 1e-9 against the oracle for float64 (both sides float64, but the
+dominant eigenvector comes from repeated squaring here and from LAPACK there, and every later
+component inherits the difference), 1e-6 against scikit-learn's NIPALS for M > 1 (its inner
+iteration), 2e-3 for float32 inputs/outputs."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from oracle.cvmatrix_oracle import OracleCVMatrix
+from oracle.ikpls_oracle import ikpls_fit
+
+pytestmark = pytest.mark.gpu
+CASES = ["pls1_small", "pls2_small", "pls2_mid", "pls1_wide", "pls2_m16"]
+
+
+@pytest.fixture(scope="module")
+def pls(hip_device):
+    from cvmatrix_amd import _lib
+    _lib.load()
+    from cvmatrix_amd import pls as mod
+    return mod
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def check_against_oracle(fit, XTX, XTY, A, tol, factors=False):
+    F = XTX.shape[0]
+    B = fit.B.cpu().numpy()
+    nf = fit.n_fit.cpu().numpy()
+    for f in range(F):
+        Bo, Wo, Po, Qo, Ro, n = ikpls_fit(XTX[f].astype(np.float64), XTY[f].astype(np.float64), A)
+        assert nf[f] == n, (f, nf[f], n)
+        for a in range(A):
+            if a < n:
+                assert rel(B[f, a], Bo[a]) <= tol, (f, a, rel(B[f, a], Bo[a]))
+            else:
+                assert np.all(B[f, a] == 0)
+        if factors:
+            for got, ref in ((fit.W, Wo), (fit.P, Po), (fit.R, Ro), (fit.Q, Qo)):
+                got = got[f].cpu().numpy()
+                for a in range(n):
+                    sgn = np.sign(np.dot(got[:, a], ref[:, a])) or 1.0
+                    assert rel(sgn * got[:, a], ref[:, a]) <= 10 * tol, (f, a)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_sklearn_and_oracle(pls, name):
+    g = load_npz("g8_pls.npz")
+    XTX, XTY, Bref = g[f"{name}/XTX"], g[f"{name}/XTY"], g[f"{name}/B"]
+    A = Bref.shape[0]
+    fit = pls.pls_fit_batched(torch.from_numpy(XTX).cuda(), torch.from_numpy(XTY).cuda(), A, return_factors=True)
+    check_against_oracle(fit, XTX[None], XTY[None], A, 1e-9, factors=True)
+    B = fit.B.cpu().numpy()[0]
+    tol = 1e-10 if XTY.shape[1] == 1 else 1e-6
+    for a in range(A):
+        assert rel(B[a], Bref[a]) <= tol, (a, rel(B[a], Bref[a]))
+
+
+def fold_matrices(N, K, M, P, seed, dtype=np.float64, weighted=True):
+    rng = np.random.default_rng(seed)
+    L = rng.standard_normal((N, 5))
+    X = (L @ rng.standard_normal((5, K)) + 0.5 * rng.standard_normal((N, K))).astype(dtype)
+    Y = (L[:, :2] @ rng.standard_normal((2, M)) + 0.1 * rng.standard_normal((N, M))).astype(dtype)
+    w = (rng.random(N) + 0.1).astype(dtype) if weighted else None
+    folds = [np.arange(N)[np.arange(N) % P == f] for f in range(P)]
+    return X, Y, w, folds
+
+
+@pytest.mark.parametrize("N,K,M,P,A", [
+    (400, 24, 3, 4, 8),        # few folds: several slices per fold, XTX slice in LDS
+    (600, 64, 16, 3, 12),
+    (900, 40, 1, 300, 6),      # many folds: one workgroup per fold
+    (500, 33, 5, 7, 9),        # odd K: ragged last slice
+    (300, 200, 2, 2, 10),
+])
+def test_folds_from_cvmatrix_match_oracle(pls, N, K, M, P, A):
+    from cvmatrix_amd import CVMatrix
+    X, Y, w, folds = fold_matrices(N, K, M, P, seed=K + M)
+    m = CVMatrix(True, True, True, True, dtype=np.float64)
+    m.fit(X, Y, w)
+    (XTX, XTY), _ = m.training_XTX_XTY_batched(m.prepare_folds(folds))
+    fit = pls.pls_fit_batched(XTX, XTY, A, return_factors=True)
+
+    check_against_oracle(fit, XTX.cpu().numpy(), XTY.cpu().numpy(), A, 1e-9, factors=True)
+    # and the whole chain against the CPU oracle of the hot path
+    o = OracleCVMatrix(True, True, True, True, dtype=np.float64)
+    o.fit(X, Y, w)
+    (oXTX, oXTY), _ = o.training_XTX_XTY(folds[0])
+    Bo, *_ = ikpls_fit(oXTX, oXTY, A)
+    assert rel(fit.B[0, A - 1].cpu().numpy(), Bo[A - 1]) <= 1e-8
+
+
+def test_sliced_and_unsliced_agree(pls):
+    # the same fold alone (many slices) and inside a batch of 300 copies (one slice each)
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((500, 48)); Y = rng.standard_normal((500, 4))
+    XTX = torch.from_numpy(X.T @ X).cuda(); XTY = torch.from_numpy(X.T @ Y).cuda()
+    one = pls.pls_fit_batched(XTX, XTY, 10)
+    many = pls.pls_fit_batched(XTX.expand(300, -1, -1).contiguous(), XTY.expand(300, -1, -1).contiguous(), 10)
+    a, b = one.B[0].cpu().numpy(), many.B.cpu().numpy()
+    assert np.all(b == b[0:1])                      # every copy bitwise the same
+    assert rel(a, b[0]) <= 1e-11                    # slicing changes summation order only
+
+
+def test_float32(pls):
+    from cvmatrix_amd import CVMatrix
+    X, Y, w, folds = fold_matrices(800, 32, 4, 5, seed=9, dtype=np.float32)
+    m = CVMatrix(True, True, True, True, dtype=np.float32)
+    m.fit(X, Y, w)
+    (XTX, XTY), _ = m.training_XTX_XTY_batched(m.prepare_folds(folds))
+    fit = pls.pls_fit_batched(XTX, XTY, 6)
+    assert fit.B.dtype == torch.float32
+    B = fit.B.cpu().numpy()
+    for f in range(5):
+        Bo, *_ = ikpls_fit(XTX[f].cpu().numpy().astype(np.float64), XTY[f].cpu().numpy().astype(np.float64), 6)
+        for a in range(6):
+            assert rel(B[f, a], Bo[a]) <= 2e-3
+
+
+def test_stops_when_xty_is_exhausted(pls):
+    XTX = torch.eye(6, dtype=torch.float64, device="cuda").repeat(3, 1, 1)
+    XTY = torch.zeros((3, 6, 1), dtype=torch.float64, device="cuda")
+    XTY[:, 0, 0] = 3.0
+    fit = pls.pls_fit_batched(XTX, XTY, 4, return_factors=True)
+    assert fit.n_fit.tolist() == [1, 1, 1]
+    B = fit.B.cpu().numpy()
+    assert np.all(B[:, 1:] == 0) and np.all(B[:, 0, 0, 0] == 3.0)
+
+
+def test_wide_k_streams_xtx(pls):
+    # K large enough that a slice of XTX does not fit in LDS (streamed from HBM per component)
+    rng = np.random.default_rng(21)
+    K = 1536
+    X = rng.standard_normal((400, K)); Y = rng.standard_normal((400, 1))
+    XTX = (X.T @ X); XTY = (X.T @ Y)
+    assert not pls.pls_plan(2, K, 1, 5)["xtx_in_lds"]
+    fit = pls.pls_fit_batched(torch.from_numpy(np.stack([XTX, XTX])).cuda(),
+                              torch.from_numpy(np.stack([XTY, 2 * XTY])).cuda(), 5)
+    check_against_oracle(fit, np.stack([XTX, XTX]), np.stack([XTY, 2 * XTY]), 5, 1e-9)
+
+
+def test_argument_errors(pls):
+    XTX = torch.eye(4, dtype=torch.float64, device="cuda")[None]
+    XTY = torch.ones((1, 4, 2), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        pls.pls_fit_batched(XTX, XTY, 0)
+    with pytest.raises(ValueError):
+        pls.pls_fit_batched(XTX, XTY.float(), 2)
+    with pytest.raises(ValueError):
+        pls.pls_fit_batched(XTX, torch.ones((1, 4, 33), dtype=torch.float64, device="cuda"), 2)
+    with pytest.raises(TypeError):
+        pls.pls_fit_batched(XTX.cpu(), XTY.cpu(), 2)
