@@ -116,6 +116,15 @@ int cvm_debug_stamps(unsigned long long *host_out) {
   HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024 * 8 * 4));
   return CVM_OK;
 }
+int cvm_debug_pls_stamps(unsigned long long *host_out, int reset) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pls_stamps), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_pls_stamps), z, sizeof(z)));
+  }
+  return CVM_OK;
+}
 int cvm_debug_stamps3(unsigned long long *host_out) {
   HIP_OK(hipDeviceSynchronize());
   HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps3), sizeof(unsigned long long) * 1024 * 8 * 2));

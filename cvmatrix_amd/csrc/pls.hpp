@@ -14,7 +14,8 @@
 // summation orders, no float atomics: results do not depend on scheduling.
 #pragma once
 
-constexpr int PLS_THREADS = 256;
+constexpr int PLS_THREADS = 512;
+constexpr int PLS_NW = PLS_THREADS / 64;
 constexpr int PLS_MAXM = 32;        // responses (the M x M eigenproblem lives in LDS)
 constexpr int PLS_MAXA = 512;       // components
 constexpr size_t PLS_LDS_BUDGET = 150 * 1024;
@@ -22,10 +23,10 @@ constexpr size_t PLS_LDS_BUDGET = 150 * 1024;
 struct PlsArgs {
   const void *XTX, *XTY;            // [F][K][K], [F][K][M]
   int K, M, A, S, rows;             // slices per fold, rows per slice
-  int y_in_lds;
-  double *Yw, *Bw;                  // [F][K][M] deflated XTY, running B
-  double *Pw, *Rw;                  // [F][K][A]
-  double *xch;                      // [F][xch_len]
+  int y_in_lds, pr_in_lds;
+  double *Yw, *Bw;                  // [F][K][M] deflated XTY (unless in LDS), running B
+  double *Pw, *Rw;                  // [F][A][K] (unless in LDS)
+  double *xch;                      // [F][xch_len] (S > 1)
   unsigned *cnt;                    // [F] barrier counters (zeroed before the launch)
   int *status;                      // [1]  set to 1 if a barrier timed out
   void *B, *W, *P, *Q, *R;          // outputs ([F][A][K][M]; [F][K][A] x3 and [F][M][A], optional)
@@ -49,73 +50,180 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < PLS_NW; ++w) t += red[w];
+  return t;
 }
 
-// barrier over the S workgroups of one fold; `target` counts arrivals so far
+// Numbers traded between the slices of a fold.  SLICED: device-coherent accesses (sc1: they go
+// past the non-coherent per-XCD L2, so no cache has to be written back or invalidated around the
+// barrier); one slice per fold: the same buffers live in LDS.
+template <bool SLICED> __device__ __forceinline__ void xput(double *p, double v) {
+  if constexpr (SLICED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool SLICED> __device__ __forceinline__ double xget(const double *p) {
+  if constexpr (SLICED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+// barrier over the S workgroups of one fold; `target` counts the arrivals expected so far.
+// Every thread first waits for its own stores to be acknowledged, so the numbers are in place
+// before the arrival is counted.
+template <bool SLICED>
 __device__ __forceinline__ bool fold_barrier(unsigned *cnt, unsigned &target, int S, int *status, int *lflag) {
-  if (S == 1) { __syncthreads(); return true; }
+  if constexpr (!SLICED) { __syncthreads(); return true; }
   target += (unsigned)S;
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long spins = 0;
     int ok = 1;
-    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > (1L << 24)) { ok = 0; break; }      // seconds: the slices were not co-resident
     }
     if (!ok) *status = 1;
     *lflag = ok;
   }
+  asm volatile("" ::: "memory");
   __syncthreads();
-  __threadfence();
   return *lflag != 0;
 }
 
-template <typename T, bool XRES>
+#ifdef CVM_STAMPS
+__device__ unsigned long long g_pls_stamps[16];
+#define PLS_STAMP(i)                                                          \
+  do {                                                                        \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                \
+      const unsigned long long now_ = __builtin_readcyclecounter();           \
+      g_pls_stamps[i] += now_ - stamp_;                                       \
+      stamp_ = now_;                                                          \
+    }                                                                         \
+  } while (0)
+#else
+#define PLS_STAMP(i)
+#endif
+
+// u[i] = sum_k Xrow_i[k] r[k] for ROWS rows at a time per wave: 16-byte loads, ROWS x 4 of them in
+// flight per lane (the stream from HBM/L2 needs the parallelism; from LDS it does no harm)
+template <typename T, int ROWS>
+__device__ __forceinline__ void matvec_rows(const T *__restrict__ x0, size_t ld, int K, const double *__restrict__ rl,
+                                            int lane, double (&acc)[ROWS]) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VW)));
+  const int nch = K / VW;                                      // K % VW == 0 here
+  int ch = lane;
+  for (; ch + 3 * 64 < nch; ch += 4 * 64) {
+    vec_t v[ROWS][4];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[q][u] = *reinterpret_cast<const vec_t *>(x0 + q * ld + (size_t)(ch + u * 64) * VW);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double rv[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) rv[e] = rl[(ch + u * 64) * VW + e];
+#pragma unroll
+      for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc[q] += (double)v[q][u][e] * rv[e];
+    }
+  }
+  for (; ch < nch; ch += 64) {
+    vec_t v[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) v[q] = *reinterpret_cast<const vec_t *>(x0 + q * ld + (size_t)ch * VW);
+    double rv[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) rv[e] = rl[ch * VW + e];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) acc[q] += (double)v[q][e] * rv[e];
+  }
+}
+
+// dst[p] = sum over the S slices of x[t * len + p], p in [0, len): a thread per element, the
+// loads of 16 slices in flight at a time, summed in slice order
+template <bool SLICED>
+__device__ __forceinline__ void xreduce(const double *x, int len, int S, double *dst, int tid) {
+  if constexpr (!SLICED) {
+    for (int p = tid; p < len; p += PLS_THREADS) dst[p] = x[p];
+  } else {
+    for (int p = tid; p < len; p += PLS_THREADS) {
+      double acc = 0.0;
+      for (int t0 = 0; t0 < S; t0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (t0 + u < S) ? xget<true>(&x[(size_t)(t0 + u) * len + p]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
+      dst[p] = acc;
+    }
+  }
+}
+
+template <typename T, bool XRES, bool SLICED>
 __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
+#ifdef CVM_STAMPS
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
+  typedef double v4d __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char pls_smem[];
-  const int K = a.K, M = a.M, A = a.A, S = a.S;
+  const int K = a.K, M = a.M, A = a.A, S = SLICED ? a.S : 1;
   const int f = blockIdx.x / S, s = blockIdx.x - f * S;
-  const int k0 = s * a.rows;
-  const int n = (k0 + a.rows <= K) ? a.rows : (K - k0 > 0 ? K - k0 : 0);
+  const int rows = a.rows;
+  const int k0 = s * rows;
+  const int n = (k0 + rows <= K) ? rows : (K - k0 > 0 ? K - k0 : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int MM = M * M;
+  const int rp = (rows + 1) & ~1;
+  const int yst = a.y_in_lds ? (M | 1) : M;                    // odd pitch in LDS: rows on distinct banks
 
   double *rl = reinterpret_cast<double *>(pls_smem);           // r, all K rows
   double *wl = rl + ((K + 1) & ~1);                            // w, r, u of the slice
-  double *rs = wl + ((a.rows + 1) & ~1);
-  double *us = rs + ((a.rows + 1) & ~1);
-  double *S0 = us + ((a.rows + 1) & ~1);                       // M x M: XTY^T XTY and two squarings
+  double *rs = wl + rp;
+  double *us = rs + rp;
+  double *S0 = us + rp;                                        // M x M: XTY^T XTY and two squarings
   double *Ba = S0 + MM;
   double *Bb = Ba + MM;
-  double *qv = Bb + MM;                                        // M
-  double *cj = qv + PLS_MAXM;                                  // A
-  double *red = cj + ((A + 1) & ~1);                           // 4
-  int *lflag = reinterpret_cast<int *>(red + 4);
-  double *ys = red + 6;                                        // rows x M (optional)
-  T *xs = reinterpret_cast<T *>(ys + (a.y_in_lds ? (size_t)a.rows * M : 0));   // rows x K (XRES)
+  double *ms = Bb + MM;                                        // waves x 256: per-wave MFMA partials
+  double *qx = ms + PLS_NW * 256;                                   // 1 + M: tTt, XTY^T r / q
+  double *cx = qx + PLS_MAXM + 2;                              // 1 + A: |w|^2, P^T w
+  double *red = cx + ((A + 2) & ~1);                           // one per wave
+  int *lflag = reinterpret_cast<int *>(red + PLS_NW);
+  double *xl = red + PLS_NW + 2;                                        // !SLICED: the exchange buffers
+  double *ys = xl + (SLICED ? 0 : (size_t)MM + (1 + A) + (1 + M) + ((MM + A + M) & 1));
+  double *pl = ys + (a.y_in_lds ? (((size_t)rows * yst + 1) & ~(size_t)1) : 0);   // [A][rp] x 2 (optional)
+  T *xs = reinterpret_cast<T *>(pl + (a.pr_in_lds ? 2 * (size_t)A * rp : 0));   // rows x K (XRES)
+  double *qv = qx + 1, *cj = cx + 1;
 
   const T *XTX = (const T *)a.XTX + (size_t)f * K * K;
   const T *XTY = (const T *)a.XTY + (size_t)f * K * M;
-  double *Yg = a.Yw + (size_t)f * K * M + (size_t)k0 * M;
-  double *Y = a.y_in_lds ? ys : Yg;                            // the slice's deflated XTY
+  double *Y = a.y_in_lds ? ys : a.Yw + (size_t)f * K * M + (size_t)k0 * M;   // the slice's deflated XTY
   double *Bw = a.Bw + (size_t)f * K * M + (size_t)k0 * M;
-  double *Pw = a.Pw + (size_t)f * K * A + (size_t)k0 * A;
-  double *Rw = a.Rw + (size_t)f * K * A + (size_t)k0 * A;
-  double *xch = a.xch + (size_t)f * pls_xch_len(K, M, A, S);
+  // the slice's columns of P^T and R^T: component j, row k at [j * pst + k]
+  double *Pp = a.pr_in_lds ? pl : a.Pw + (size_t)f * K * A + k0;
+  double *Rp = a.pr_in_lds ? pl + (size_t)A * rp : a.Rw + (size_t)f * K * A + k0;
+  const size_t pst = a.pr_in_lds ? (size_t)rp : (size_t)K;
+  double *xch = SLICED ? a.xch + (size_t)f * pls_xch_len(K, M, A, S) : xl;
   double *x_S = xch;                                           // [S][MM]
-  double *x_2 = x_S + (size_t)S * MM;                          // [S][1 + A]
-  double *x_r = x_2 + (size_t)S * (1 + A);                     // [K]
-  double *x_4 = x_r + K;                                       // [S][1 + M]
+  double *x_2 = x_S + (size_t)S * MM;                          // [S][1 + c] (room for 1 + A)
+  double *x_4 = x_2 + (size_t)S * (1 + A);                     // [S][1 + M]
+  double *x_r = SLICED ? x_4 + (size_t)S * (1 + M) : rl;       // [K]
   unsigned *cnt = a.cnt + f;
   unsigned target = 0;
+  const bool vec_ok = (K % (16 / (int)sizeof(T))) == 0;
 
   // ---- prologue: working copies of the slice -------------------------------------------
   for (int e = tid; e < n * M; e += PLS_THREADS) {
-    Y[e] = (double)XTY[(size_t)k0 * M + e];
+    const int k = e / M, j = e - k * M;
+    Y[(size_t)k * yst + j] = (double)XTY[(size_t)k0 * M + e];
     Bw[e] = 0.0;
   }
   if (XRES) {
@@ -123,64 +231,141 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
     for (size_t e = tid; e < (size_t)n * K; e += PLS_THREADS) xs[e] = src[e];
   }
   __syncthreads();
+  PLS_STAMP(0);
 
   int fit = 0;
   for (int c = 0; c < A; ++c) {
-    // ---- 1: partial XTY^T XTY of the slice's rows (upper triangle, mirrored) ---------------
     if (M > 1) {
-      for (int p = tid; p < MM; p += PLS_THREADS) {
-        const int i = p / M, j = p - i * M;
-        if (i > j) continue;
-        double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc += Y[(size_t)k * M + i] * Y[(size_t)k * M + j];
-        x_S[(size_t)s * MM + p] = acc;
-        x_S[(size_t)s * MM + (size_t)j * M + i] = acc;
+      // ---- 1: partial XTY^T XTY of the slice's rows ----------------------------------------
+      if (M <= 16) {
+        // one MFMA per 4 rows: A = Y^T (16 x 4), B = Y (4 x 16) are the same register
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const int col = lane & 15, sub = lane >> 4;
+        for (int r0 = 4 * wave; r0 < n; r0 += 4 * PLS_NW) {
+          const int r = r0 + sub;
+          const double y = (col < M && r < n) ? Y[(size_t)r * yst + col] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ms[wave * 256 + (sub + 4 * q) * 16 + col] = acc[q];
+        __syncthreads();
+        {
+          const int i = tid >> 4, j = tid & 15;
+          double msum = 0.0;
+          if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < PLS_NW; ++w) msum += ms[w * 256 + tid];
+          }
+          if (tid < 256 && i < M && j < M)
+            xput<SLICED>(&x_S[(size_t)s * MM + i * M + j], msum);
+        }
+      } else {
+        for (int p = tid; p < MM; p += PLS_THREADS) {
+          const int i = p / M, j = p - i * M;
+          if (i > j) continue;
+          double acc0 = 0.0, acc1 = 0.0;
+          int k = 0;
+          for (; k + 1 < n; k += 2) {
+            acc0 += Y[(size_t)k * yst + i] * Y[(size_t)k * yst + j];
+            acc1 += Y[(size_t)(k + 1) * yst + i] * Y[(size_t)(k + 1) * yst + j];
+          }
+          if (k < n) acc0 += Y[(size_t)k * yst + i] * Y[(size_t)k * yst + j];
+          const double acc = acc0 + acc1;
+          xput<SLICED>(&x_S[(size_t)s * MM + p], acc);
+          if (i != j) xput<SLICED>(&x_S[(size_t)s * MM + j * M + i], acc);
+        }
       }
-      if (!fold_barrier(cnt, target, S, a.status, lflag)) return;
+      PLS_STAMP(1);
+      if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+      PLS_STAMP(2);
       // ---- 2a: dominant eigenvector q of the M x M sum, by repeated squaring -----------------
-      for (int p = tid; p < MM; p += PLS_THREADS) {
-        double acc = 0.0;
-        for (int t = 0; t < S; ++t) acc += x_S[(size_t)t * MM + p];
-        S0[p] = acc;
-      }
+      // B_0 = S / trace; B_{t+1} = B_t^2 / trace(B_t^2): trace(B_t^2) = sum lambda^2 (trace 1
+      // before) reaches 1 when B_t is numerically rank one.
+      xreduce<SLICED>(x_S, MM, S, S0, tid);
       __syncthreads();
       double tr = 0.0;
       for (int i = 0; i < M; ++i) tr += S0[(size_t)i * M + i];
+      double *fin = Ba;                                        // the (nearly) rank-one power of S
       if (tr > 0.0) {
-        for (int p = tid; p < MM; p += PLS_THREADS) Ba[p] = S0[p] / tr;
-        __syncthreads();
-        double *src = Ba, *dst = Bb;
-        for (int it = 0; it < 64; ++it) {
-          for (int p = tid; p < MM; p += PLS_THREADS) {
-            const int i = p / M, j = p - i * M;
-            double acc = 0.0;
-            for (int k = 0; k < M; ++k) acc += src[(size_t)i * M + k] * src[(size_t)k * M + j];
-            dst[p] = acc;
+        if (M <= 16) {
+          // wave 0, matrix in registers: the C/D layout of the 16x16x4 MFMA (row = sub + 4 reg,
+          // col) is, register by register, the layout of its A and B operands for a symmetric
+          // matrix, so a squaring is four MFMAs on the accumulator registers themselves
+          if (wave == 0) {
+            const int col = lane & 15, sub = lane >> 4;
+            v4d m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = sub + 4 * q;
+              m[q] = (row < M && col < M) ? S0[(size_t)row * M + col] / tr : 0.0;
+            }
+            for (int it = 0; it < 64; ++it) {
+              v4d sq = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) sq = __builtin_amdgcn_mfma_f64_16x16x4f64(m[q], m[q], sq, 0, 0, 0);
+              double d = 0.0;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) d += (sub + 4 * q == col) ? sq[q] : 0.0;
+              const double t2 = wave_sum(d);
+              const double inv = 1.0 / t2;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) m[q] = sq[q] * inv;
+              if (1.0 - t2 < 1e-13) break;                     // rank one: lambda2/lambda1 < 5e-14
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = sub + 4 * q;
+              if (row < M && col < M) fin[(size_t)row * M + col] = m[q];
+            }
           }
           __syncthreads();
-          double t2 = 0.0;                                   // trace of the square: sum lambda^2, trace 1 before
-          for (int i = 0; i < M; ++i) t2 += dst[(size_t)i * M + i];
+        } else {
+          for (int p = tid; p < MM; p += PLS_THREADS) Ba[p] = S0[p];
           __syncthreads();
-          for (int p = tid; p < MM; p += PLS_THREADS) dst[p] = dst[p] / t2;
-          __syncthreads();
-          double *tmp = src; src = dst; dst = tmp;
-          if (1.0 - t2 < 1e-15) break;                         // numerically rank one
+          double *src = Ba, *dst = Bb;
+          double scale = 1.0 / tr;                             // src holds B_t / scale
+          for (int it = 0; it < 64; ++it) {
+            const double s2 = scale * scale;
+            for (int p = tid; p < MM; p += PLS_THREADS) {
+              const int i = p / M, j = p - i * M;
+              double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+              int k = 0;
+              for (; k + 3 < M; k += 4) {
+                a0 += src[(size_t)i * M + k] * src[(size_t)k * M + j];
+                a1 += src[(size_t)i * M + k + 1] * src[(size_t)(k + 1) * M + j];
+                a2 += src[(size_t)i * M + k + 2] * src[(size_t)(k + 2) * M + j];
+                a3 += src[(size_t)i * M + k + 3] * src[(size_t)(k + 3) * M + j];
+              }
+              for (; k < M; ++k) a0 += src[(size_t)i * M + k] * src[(size_t)k * M + j];
+              dst[p] = ((a0 + a1) + (a2 + a3)) * s2;           // B_t^2
+            }
+            __syncthreads();
+            double t0 = 0.0, t1 = 0.0;
+            int i = 0;
+            for (; i + 1 < M; i += 2) { t0 += dst[(size_t)i * M + i]; t1 += dst[(size_t)(i + 1) * M + i + 1]; }
+            if (i < M) t0 += dst[(size_t)i * M + i];
+            const double t2 = t0 + t1;
+            scale = 1.0 / t2;
+            double *tmp = src; src = dst; dst = tmp;
+            if (1.0 - t2 < 1e-13) break;
+          }
+          fin = src;
         }
         // the column with the largest diagonal entry, then two power steps with the sum itself
+        double *scr = (fin == Ba) ? Bb : Ba;
         int best = 0;
-        for (int i = 1; i < M; ++i) if (src[(size_t)i * M + i] > src[(size_t)best * M + best]) best = i;
-        if (tid < M) qv[tid] = src[(size_t)tid * M + best];
+        for (int i = 1; i < M; ++i) if (fin[(size_t)i * M + i] > fin[(size_t)best * M + best]) best = i;
+        if (tid < M) qv[tid] = fin[(size_t)tid * M + best];
         __syncthreads();
         for (int polish = 0; polish < 2; ++polish) {
           double v = 0.0;
           if (tid < M) for (int k = 0; k < M; ++k) v += S0[(size_t)tid * M + k] * qv[k];
-          __syncthreads();
-          if (tid < M) dst[tid] = v;
+          if (tid < M) scr[tid] = v;
           __syncthreads();
           double nn = 0.0;
-          for (int k = 0; k < M; ++k) nn += dst[k] * dst[k];
+          for (int k = 0; k < M; ++k) nn += scr[k] * scr[k];
           nn = sqrt(nn);
-          if (tid < M) qv[tid] = nn > 0.0 ? dst[tid] / nn : 0.0;
+          if (tid < M) qv[tid] = nn > 0.0 ? v / nn : 0.0;
           __syncthreads();
         }
       } else {
@@ -188,6 +373,7 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
         __syncthreads();
       }
     }
+    PLS_STAMP(3);
     // ---- 2b: w of the slice (not normalised yet), its partial norm and partial P^T w -------
     double nrm2 = 0.0;
     for (int k = tid; k < n; k += PLS_THREADS) {
@@ -195,149 +381,208 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
       if (M == 1) v = Y[k];
       else {
         v = 0.0;
-        for (int j = 0; j < M; ++j) v += Y[(size_t)k * M + j] * qv[j];
+        for (int j = 0; j < M; ++j) v += Y[(size_t)k * yst + j] * qv[j];
       }
       wl[k] = v;
       nrm2 += v * v;
     }
     nrm2 = block_sum(nrm2, red);
-    if (tid == 0) x_2[(size_t)s * (1 + A)] = nrm2;
-    for (int j = wave; j < c; j += PLS_THREADS / 64) {
-      double acc = 0.0;
-      for (int k = lane; k < n; k += 64) acc += Pw[(size_t)k * A + j] * wl[k];
-      acc = wave_sum(acc);
-      if (lane == 0) x_2[(size_t)s * (1 + A) + 1 + j] = acc;
+    if (tid == 0) xput<SLICED>(&x_2[(size_t)s * (1 + c)], nrm2);
+    for (int j0 = wave * 4; j0 < c; j0 += 4 * PLS_NW) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = lane; k < n; k += 64) {
+        const double wv = wl[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j0 + q < c) acc[q] += Pp[(size_t)(j0 + q) * pst + k] * wv;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0 && j0 + q < c) xput<SLICED>(&x_2[(size_t)s * (1 + c) + 1 + j0 + q], v);
+      }
     }
-    if (!fold_barrier(cnt, target, S, a.status, lflag)) return;
+    PLS_STAMP(4);
+    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+    PLS_STAMP(5);
     // ---- 3: normalise, r = w - R (P^T w) -----------------------------------------------------
-    double nrm = 0.0;
-    for (int t = 0; t < S; ++t) nrm += x_2[(size_t)t * (1 + A)];
-    nrm = sqrt(nrm);
+    xreduce<SLICED>(x_2, 1 + c, S, cx, tid);
+    __syncthreads();
+    const double nrm = sqrt(cx[0]);
     if (!(nrm > a.eps)) break;                                 // nothing left to extract (uniform)
-    for (int j = tid; j < c; j += PLS_THREADS) {
-      double acc = 0.0;
-      for (int t = 0; t < S; ++t) acc += x_2[(size_t)t * (1 + A) + 1 + j];
-      cj[j] = acc / nrm;
-    }
+    for (int j = tid; j < c; j += PLS_THREADS) cj[j] = cj[j] / nrm;
     __syncthreads();
     for (int k = tid; k < n; k += PLS_THREADS) {
       const double w = wl[k] / nrm;
       double corr = 0.0;
-      for (int j = 0; j < c; ++j) corr += Rw[(size_t)k * A + j] * cj[j];
+      for (int j0 = 0; j0 < c; j0 += 8) {
+        double rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rv[u] = (j0 + u < c) ? Rp[(size_t)(j0 + u) * pst + k] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (j0 + u < c) corr += rv[u] * cj[j0 + u];
+      }
       const double r = w - corr;
       wl[k] = w;
       rs[k] = r;
-      Rw[(size_t)k * A + c] = r;
-      x_r[k0 + k] = r;
+      Rp[(size_t)c * pst + k] = r;
+      xput<SLICED>(&x_r[k0 + k], r);
       if (a.W) ((T *)a.W)[((size_t)f * K + k0 + k) * A + c] = (T)w;
       if (a.R) ((T *)a.R)[((size_t)f * K + k0 + k) * A + c] = (T)r;
     }
-    if (!fold_barrier(cnt, target, S, a.status, lflag)) return;
+    PLS_STAMP(6);
+    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+    PLS_STAMP(7);
     // ---- 4: u = XTX[slice, :] r, partial r^T u and partial XTY^T r ---------------------------
-    for (int k = tid; k < K; k += PLS_THREADS) rl[k] = x_r[k];
-    __syncthreads();
-    for (int i0 = wave * 4; i0 < n; i0 += 4 * (PLS_THREADS / 64)) {
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      const int ni = n - i0 < 4 ? n - i0 : 4;
-      if (ni == 4) {
-        for (int k = lane; k < K; k += 64) {
-          const double rv = rl[k];
+    if constexpr (SLICED) {
+      for (int k = tid; k < K; k += PLS_THREADS) rl[k] = xget<true>(&x_r[k]);
+      __syncthreads();
+    }
+    {
+      const T *xb = XRES ? xs : XTX + (size_t)k0 * K;
+      constexpr int NW = PLS_THREADS / 64;
+      int done = 0;
+      if (vec_ok) {
+        done = n & ~3;
+        for (int i0 = wave * 4; i0 < done; i0 += 4 * NW) {
+          double acc[4] = {0.0, 0.0, 0.0, 0.0};
+          matvec_rows<T, 4>(xb + (size_t)i0 * K, (size_t)K, K, rl, lane, acc);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const T xv = XRES ? xs[(size_t)(i0 + q) * K + k] : XTX[(size_t)(k0 + i0 + q) * K + k];
-            acc[q] += (double)xv * rv;
-          }
-        }
-      } else {
-        for (int k = lane; k < K; k += 64) {
-          const double rv = rl[k];
-          for (int q = 0; q < ni; ++q) {
-            const T xv = XRES ? xs[(size_t)(i0 + q) * K + k] : XTX[(size_t)(k0 + i0 + q) * K + k];
-            acc[q] += (double)xv * rv;
+            const double v = wave_sum(acc[q]);
+            if (lane == 0) us[i0 + q] = v;
           }
         }
       }
-      for (int q = 0; q < ni; ++q) {
-        const double v = wave_sum(acc[q]);
-        if (lane == 0) us[i0 + q] = v;
+      // ragged rows (and all rows of an unaligned K): one at a time, scalar loads
+      for (int i = done + wave; i < n; i += NW) {
+        double acc = 0.0;
+        for (int k = lane; k < K; k += 64) acc += (double)xb[(size_t)i * K + k] * rl[k];
+        acc = wave_sum(acc);
+        if (lane == 0) us[i] = acc;
       }
     }
     __syncthreads();
+    PLS_STAMP(8);
     double tt = 0.0;
     for (int k = tid; k < n; k += PLS_THREADS) tt += rs[k] * us[k];
     tt = block_sum(tt, red);
-    if (tid == 0) x_4[(size_t)s * (1 + M)] = tt;
+    if (tid == 0) xput<SLICED>(&x_4[(size_t)s * (1 + M)], tt);
     for (int j = wave; j < M; j += PLS_THREADS / 64) {
       double acc = 0.0;
-      for (int k = lane; k < n; k += 64) acc += Y[(size_t)k * M + j] * rs[k];
+      for (int k = lane; k < n; k += 64) acc += Y[(size_t)k * yst + j] * rs[k];
       acc = wave_sum(acc);
-      if (lane == 0) x_4[(size_t)s * (1 + M) + 1 + j] = acc;
+      if (lane == 0) xput<SLICED>(&x_4[(size_t)s * (1 + M) + 1 + j], acc);
     }
-    if (!fold_barrier(cnt, target, S, a.status, lflag)) return;
+    PLS_STAMP(9);
+    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+    PLS_STAMP(10);
     // ---- 5: p, q, deflation of the slice, B ---------------------------------------------------
-    double tTt = 0.0;
-    for (int t = 0; t < S; ++t) tTt += x_4[(size_t)t * (1 + M)];
-    if (tid < M) {
-      double acc = 0.0;
-      for (int t = 0; t < S; ++t) acc += x_4[(size_t)t * (1 + M) + 1 + tid];
-      const double q = acc / tTt;
-      qv[tid] = q;
-      if (a.Q && s == 0) ((T *)a.Q)[((size_t)f * M + tid) * A + c] = (T)q;
-    }
+    xreduce<SLICED>(x_4, 1 + M, S, qx, tid);
     __syncthreads();
+    const double tTt = qx[0];
+    const double qmine = tid < M ? qv[tid] / tTt : 0.0;
+    if (tid < M) {
+      qv[tid] = qmine;
+      if (a.Q && s == 0) ((T *)a.Q)[((size_t)f * M + tid) * A + c] = (T)qmine;
+    }
     for (int k = tid; k < n; k += PLS_THREADS) {
       const double p = us[k] / tTt;
       us[k] = p;
-      Pw[(size_t)k * A + c] = p;
+      Pp[(size_t)c * pst + k] = p;
       if (a.P) ((T *)a.P)[((size_t)f * K + k0 + k) * A + c] = (T)p;
     }
     __syncthreads();
     T *Bout = (T *)a.B + (((size_t)f * A + c) * K + k0) * M;
-    for (int e = tid; e < n * M; e += PLS_THREADS) {
-      const int k = e / M, j = e - k * M;
-      Y[e] = Y[e] - (us[k] * qv[j]) * tTt;
-      const double b = Bw[e] + rs[k] * qv[j];
-      Bw[e] = b;
-      Bout[e] = (T)b;
+    for (int e0 = tid; e0 < n * M; e0 += 8 * PLS_THREADS) {
+      double bw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * PLS_THREADS;
+        bw[u] = e < n * M ? Bw[e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * PLS_THREADS;
+        if (e < n * M) {
+          const int k = e / M, j = e - k * M;
+          Y[(size_t)k * yst + j] = Y[(size_t)k * yst + j] - (us[k] * qv[j]) * tTt;
+          const double b = bw[u] + rs[k] * qv[j];
+          Bw[e] = b;
+          Bout[e] = (T)b;
+        }
+      }
     }
     __syncthreads();
+    PLS_STAMP(11);
     fit = c + 1;
+  }
+  // components that could not be extracted stay zero
+  for (int c = fit; c < A; ++c) {
+    T *Bout = (T *)a.B + (((size_t)f * A + c) * K + k0) * M;
+    for (int e = tid; e < n * M; e += PLS_THREADS) Bout[e] = (T)0;
+    for (int k = tid; k < n; k += PLS_THREADS) {
+      if (a.W) ((T *)a.W)[((size_t)f * K + k0 + k) * A + c] = (T)0;
+      if (a.R) ((T *)a.R)[((size_t)f * K + k0 + k) * A + c] = (T)0;
+      if (a.P) ((T *)a.P)[((size_t)f * K + k0 + k) * A + c] = (T)0;
+    }
+    if (a.Q && s == 0 && tid < M) ((T *)a.Q)[((size_t)f * M + tid) * A + c] = (T)0;
   }
   if (s == 0 && tid == 0) a.n_fit[f] = fit;
 }
 
 // ---- host ---------------------------------------------------------------------------------
 struct PlsPlan {
-  int S, rows, folds_per_launch, y_in_lds, xres;
+  int S, rows, folds_per_launch, y_in_lds, pr_in_lds, xres;
   size_t lds;
 };
 
-size_t pls_lds_bytes(int K, int M, int A, int rows, int y_in_lds, int xres, int esize) {
-  size_t d = ((K + 1) & ~1) + 3 * (size_t)((rows + 1) & ~1) + 3 * (size_t)M * M + PLS_MAXM + ((A + 1) & ~1) + 6;
-  if (y_in_lds) d += (size_t)rows * M;
+size_t pls_lds_bytes(int K, int M, int A, int rows, int sliced, int y_in_lds, int pr_in_lds, int xres, int esize) {
+  const size_t rp = (rows + 1) & ~1;
+  size_t d = ((K + 1) & ~1) + 3 * rp + 3 * (size_t)M * M + PLS_NW * 256 + (PLS_MAXM + 2) + ((A + 2) & ~1) + PLS_NW + 2;
+  if (!sliced) d += (size_t)M * M + (1 + A) + (1 + M) + ((M * M + A + M) & 1);
+  if (y_in_lds) d += ((size_t)rows * (M | 1) + 1) & ~(size_t)1;
+  if (pr_in_lds) d += 2 * (size_t)A * rp;
   size_t b = d * 8;
   if (xres) b += (size_t)rows * K * esize;
   return b;
 }
 
+// Per component a slice streams rows*K*esize bytes of XTX at what one CU draws from L2/HBM, and,
+// when a fold has several slices, passes the per-fold barrier (3 times for M == 1, else 4).
+constexpr double PLS_CU_BYTES_PER_US = 50e3;    // one CU streaming from L2 / HBM (measured 27-50)
+constexpr double PLS_LDS_BYTES_PER_US = 100e3;  // the slice resident in LDS (short rows: latency)
+constexpr double PLS_BARRIER_US = 6.0;          // measured: ~14k cycles
+
 bool make_pls_plan(int64_t F, int K, int M, int A, int esize, int cus, PlsPlan &p) {
-  // slices: as many as keep every workgroup of a launch resident (folds x S <= CUs); at least as
-  // many as the LDS needs for the per-slice vectors
-  int S = (F >= cus) ? 1 : (int)(cus / (F > 0 ? F : 1));
-  if (S > (K + 7) / 8) S = (K + 7) / 8;                        // >= 8 rows per slice
-  if (S < 1) S = 1;
-  for (;; ++S) {
+  const int64_t Fe = F > 0 ? F : 1;
+  int s_max = (Fe >= cus) ? 1 : (int)(cus / Fe);               // folds x S <= CUs: co-resident
+  if (s_max > (K + 7) / 8) s_max = (K + 7) / 8;                // >= 8 rows per slice
+  if (s_max < 1) s_max = 1;
+  const int s_lim = K < cus ? K : cus;
+  int best = 0;
+  double best_t = 1e300;
+  for (int S = 1; S <= s_lim; ++S) {
+    if (S > s_max && best) break;                              // more slices than s_max only if the LDS demands it
     const int rows = (K + S - 1) / S;
-    if (pls_lds_bytes(K, M, A, rows, 0, 0, esize) <= PLS_LDS_BUDGET) break;
-    if (S >= K || S >= cus) return false;
+    if ((K + rows - 1) / rows != S) continue;                  // the same cut as a smaller S
+    if (pls_lds_bytes(K, M, A, rows, S > 1, 0, 0, 0, esize) > PLS_LDS_BUDGET) continue;
+    const bool res = pls_lds_bytes(K, M, A, rows, S > 1, 0, 0, 1, esize) <= PLS_LDS_BUDGET;
+    const double bytes = (double)rows * K * esize;
+    const double t = bytes / (res ? PLS_LDS_BYTES_PER_US : PLS_CU_BYTES_PER_US) +
+                     (S > 1 ? (M > 1 ? 4 : 3) * PLS_BARRIER_US : 0.0);
+    if (t < best_t) { best_t = t; best = S; }
   }
-  p.rows = (K + S - 1) / S;
-  p.S = (K + p.rows - 1) / p.rows;
-  p.folds_per_launch = p.S == 1 ? (int)(F < (1 << 20) ? (F > 0 ? F : 1) : (1 << 20)) : cus / p.S;
+  if (!best) return false;
+  p.S = best;
+  p.rows = (K + best - 1) / best;
+  p.folds_per_launch = best == 1 ? (int)(Fe < (1 << 20) ? Fe : (1 << 20)) : cus / best;
   if (p.folds_per_launch < 1) return false;
-  p.y_in_lds = pls_lds_bytes(K, M, A, p.rows, 1, 0, esize) <= PLS_LDS_BUDGET && (size_t)p.rows * M * 8 <= 48 * 1024;
-  p.xres = pls_lds_bytes(K, M, A, p.rows, p.y_in_lds, 1, esize) <= PLS_LDS_BUDGET;
-  p.lds = pls_lds_bytes(K, M, A, p.rows, p.y_in_lds, p.xres, esize);
+  // what else stays in LDS, most valuable first: the slice of XTX, of the deflated XTY, of P and R
+  p.xres = pls_lds_bytes(K, M, A, p.rows, best > 1, 0, 0, 1, esize) <= PLS_LDS_BUDGET;
+  p.y_in_lds = pls_lds_bytes(K, M, A, p.rows, best > 1, 1, 0, p.xres, esize) <= PLS_LDS_BUDGET;
+  p.pr_in_lds = pls_lds_bytes(K, M, A, p.rows, best > 1, p.y_in_lds, 1, p.xres, esize) <= PLS_LDS_BUDGET;
+  p.lds = pls_lds_bytes(K, M, A, p.rows, best > 1, p.y_in_lds, p.pr_in_lds, p.xres, esize);
   return true;
 }
 
@@ -371,7 +616,7 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
   if (F == 0) return CVM_OK;
   double *d = reinterpret_cast<double *>(ws);
   PlsArgs a;
-  a.K = K; a.M = M; a.A = A; a.S = p.S; a.rows = p.rows; a.y_in_lds = p.y_in_lds;
+  a.K = K; a.M = M; a.A = A; a.S = p.S; a.rows = p.rows; a.y_in_lds = p.y_in_lds; a.pr_in_lds = p.pr_in_lds;
   a.Yw = d; d += (size_t)F * K * M;
   a.Bw = d; d += (size_t)F * K * M;
   a.Pw = d; d += (size_t)F * K * A;
@@ -382,14 +627,8 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
   a.eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
   HIP_OK(hipMemsetAsync(a.cnt, 0, (size_t)F * sizeof(unsigned), st));
   HIP_OK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
-  const size_t es = sizeof(T);
-  // components that are not extracted (stopping rule) stay zero
-  HIP_OK(hipMemsetAsync(B, 0, (size_t)F * A * K * M * es, st));
-  if (W) HIP_OK(hipMemsetAsync(W, 0, (size_t)F * K * A * es, st));
-  if (P) HIP_OK(hipMemsetAsync(P, 0, (size_t)F * K * A * es, st));
-  if (R) HIP_OK(hipMemsetAsync(R, 0, (size_t)F * K * A * es, st));
-  if (Q) HIP_OK(hipMemsetAsync(Q, 0, (size_t)F * M * A * es, st));
-  auto kern = p.xres ? pls_kernel<T, true> : pls_kernel<T, false>;
+  void (*kern)(const PlsArgs) = p.S > 1 ? (p.xres ? pls_kernel<T, true, true> : pls_kernel<T, false, true>)
+                                        : (p.xres ? pls_kernel<T, true, false> : pls_kernel<T, false, false>);
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
   for (int64_t f0 = 0; f0 < F; f0 += p.folds_per_launch) {
     const int64_t nf = F - f0 < p.folds_per_launch ? F - f0 : p.folds_per_launch;
