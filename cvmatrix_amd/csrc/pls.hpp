@@ -147,6 +147,119 @@ __device__ __forceinline__ void matvec_rows(const T *__restrict__ x0, size_t ld,
   }
 }
 
+typedef double pls_v4d __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64 register maps: A operand lane l = A[l & 15][l >> 4], B operand lane l =
+// B[l >> 4][l & 15], C/D register q of lane l = C[(l >> 4) + 4 q][l & 15].  So register q of a
+// block X held in the C/D map is, as it stands, the B operand of k-step q for  . X  and the A
+// operand of k-step q for  X^T . : an M x M matrix cut in NB x NB blocks of 16 is multiplied by
+// itself without moving a number.
+
+// slice part of XTY^T XTY: s[bi][bj] += Y[:, bi]^T Y[:, bj], four rows per MFMA
+template <int NB>
+__device__ __forceinline__ void pls_gram_mfma(const double *Y, int yst, int n, int M, int wave, int lane,
+                                              pls_v4d (&s)[NB][NB]) {
+  const int col = lane & 15, sub = lane >> 4;
+  for (int r0 = 4 * wave; r0 < n; r0 += 4 * PLS_NW) {
+    const int r = r0 + sub;
+    double y[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) y[b] = (16 * b + col < M && r < n) ? Y[(size_t)r * yst + 16 * b + col] : 0.0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < NB; ++bj) s[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[bi], y[bj], s[bi][bj], 0, 0, 0);
+  }
+}
+
+// one wave: m <- m^2 / trace(m^2) until m is numerically rank one (m symmetric, trace 1)
+template <int NB>
+__device__ __forceinline__ void pls_power_mfma(pls_v4d (&m)[NB][NB], int lane) {
+  const int col = lane & 15, sub = lane >> 4;
+  for (int it = 0; it < 64; ++it) {
+    pls_v4d sq[NB][NB];
+    double d = 0.0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < NB; ++bj) {
+        pls_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int bk = 0; bk < NB; ++bk)                        // (m m)[bi][bj] += m[bi][bk] m[bk][bj]; A operand: m[bi][bk]^T = m[bk][bi]
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[bk][bi][q], m[bk][bj][q], acc, 0, 0, 0);
+        sq[bi][bj] = acc;
+        if (bi == bj) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) d += (sub + 4 * q == col) ? acc[q] : 0.0;
+        }
+      }
+    const double t2 = wave_sum(d);                             // sum lambda^2 with sum lambda = 1
+    const double inv = 1.0 / t2;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[bi][bj][q] = sq[bi][bj][q] * inv;
+    if (1.0 - t2 < 1e-13) break;                               // rank one: lambda2/lambda1 < 5e-14
+  }
+}
+
+// phase 1 and 2a of a component for M <= 16 NB
+template <int NB, bool SLICED>
+__device__ __forceinline__ void pls_gram_phase(const double *Y, int yst, int n, int M, double *ms, double *x_S_slice,
+                                               int tid) {
+  const int lane = tid & 63, wave = tid >> 6, col = lane & 15, sub = lane >> 4;
+  pls_v4d s[NB][NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NB; ++bj) s[bi][bj] = pls_v4d{0.0, 0.0, 0.0, 0.0};
+  pls_gram_mfma<NB>(Y, yst, n, M, wave, lane, s);
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NB; ++bj) {
+      if (bi + bj) __syncthreads();                            // ms is reused block after block
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ms[wave * 256 + (sub + 4 * q) * 16 + col] = s[bi][bj][q];
+      __syncthreads();
+      if (tid < 256) {
+        double msum = 0.0;
+#pragma unroll
+        for (int w = 0; w < PLS_NW; ++w) msum += ms[w * 256 + tid];
+        const int i = 16 * bi + (tid >> 4), j = 16 * bj + (tid & 15);
+        if (i < M && j < M) xput<SLICED>(&x_S_slice[i * M + j], msum);
+      }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void pls_eig_phase(const double *S0, double tr, int M, double *fin, int lane) {
+  const int col = lane & 15, sub = lane >> 4;
+  pls_v4d m[NB][NB];
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * bi + sub + 4 * q, c = 16 * bj + col;
+        m[bi][bj][q] = (row < M && c < M) ? S0[(size_t)row * M + c] / tr : 0.0;
+      }
+  pls_power_mfma<NB>(m, lane);
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * bi + sub + 4 * q, c = 16 * bj + col;
+        if (row < M && c < M) fin[(size_t)row * M + c] = m[bi][bj][q];
+      }
+}
+
 // dst[p] = sum over the S slices of x[t * len + p], p in [0, len): a thread per element, the
 // loads of 16 slices in flight at a time, summed in slice order
 template <bool SLICED>
@@ -173,7 +286,6 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
 #ifdef CVM_STAMPS
   unsigned long long stamp_ = __builtin_readcyclecounter();
 #endif
-  typedef double v4d __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char pls_smem[];
   const int K = a.K, M = a.M, A = a.A, S = SLICED ? a.S : 1;
   const int f = blockIdx.x / S, s = blockIdx.x - f * S;
@@ -237,44 +349,8 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
   for (int c = 0; c < A; ++c) {
     if (M > 1) {
       // ---- 1: partial XTY^T XTY of the slice's rows ----------------------------------------
-      if (M <= 16) {
-        // one MFMA per 4 rows: A = Y^T (16 x 4), B = Y (4 x 16) are the same register
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        const int col = lane & 15, sub = lane >> 4;
-        for (int r0 = 4 * wave; r0 < n; r0 += 4 * PLS_NW) {
-          const int r = r0 + sub;
-          const double y = (col < M && r < n) ? Y[(size_t)r * yst + col] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ms[wave * 256 + (sub + 4 * q) * 16 + col] = acc[q];
-        __syncthreads();
-        {
-          const int i = tid >> 4, j = tid & 15;
-          double msum = 0.0;
-          if (tid < 256) {
-#pragma unroll
-            for (int w = 0; w < PLS_NW; ++w) msum += ms[w * 256 + tid];
-          }
-          if (tid < 256 && i < M && j < M)
-            xput<SLICED>(&x_S[(size_t)s * MM + i * M + j], msum);
-        }
-      } else {
-        for (int p = tid; p < MM; p += PLS_THREADS) {
-          const int i = p / M, j = p - i * M;
-          if (i > j) continue;
-          double acc0 = 0.0, acc1 = 0.0;
-          int k = 0;
-          for (; k + 1 < n; k += 2) {
-            acc0 += Y[(size_t)k * yst + i] * Y[(size_t)k * yst + j];
-            acc1 += Y[(size_t)(k + 1) * yst + i] * Y[(size_t)(k + 1) * yst + j];
-          }
-          if (k < n) acc0 += Y[(size_t)k * yst + i] * Y[(size_t)k * yst + j];
-          const double acc = acc0 + acc1;
-          xput<SLICED>(&x_S[(size_t)s * MM + p], acc);
-          if (i != j) xput<SLICED>(&x_S[(size_t)s * MM + j * M + i], acc);
-        }
-      }
+      if (M <= 16) pls_gram_phase<1, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
+      else pls_gram_phase<2, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
       PLS_STAMP(1);
       if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
       PLS_STAMP(2);
@@ -287,72 +363,14 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
       for (int i = 0; i < M; ++i) tr += S0[(size_t)i * M + i];
       double *fin = Ba;                                        // the (nearly) rank-one power of S
       if (tr > 0.0) {
-        if (M <= 16) {
-          // wave 0, matrix in registers: the C/D layout of the 16x16x4 MFMA (row = sub + 4 reg,
-          // col) is, register by register, the layout of its A and B operands for a symmetric
-          // matrix, so a squaring is four MFMAs on the accumulator registers themselves
-          if (wave == 0) {
-            const int col = lane & 15, sub = lane >> 4;
-            v4d m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int row = sub + 4 * q;
-              m[q] = (row < M && col < M) ? S0[(size_t)row * M + col] / tr : 0.0;
-            }
-            for (int it = 0; it < 64; ++it) {
-              v4d sq = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int q = 0; q < 4; ++q) sq = __builtin_amdgcn_mfma_f64_16x16x4f64(m[q], m[q], sq, 0, 0, 0);
-              double d = 0.0;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) d += (sub + 4 * q == col) ? sq[q] : 0.0;
-              const double t2 = wave_sum(d);
-              const double inv = 1.0 / t2;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) m[q] = sq[q] * inv;
-              if (1.0 - t2 < 1e-13) break;                     // rank one: lambda2/lambda1 < 5e-14
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int row = sub + 4 * q;
-              if (row < M && col < M) fin[(size_t)row * M + col] = m[q];
-            }
-          }
-          __syncthreads();
-        } else {
-          for (int p = tid; p < MM; p += PLS_THREADS) Ba[p] = S0[p];
-          __syncthreads();
-          double *src = Ba, *dst = Bb;
-          double scale = 1.0 / tr;                             // src holds B_t / scale
-          for (int it = 0; it < 64; ++it) {
-            const double s2 = scale * scale;
-            for (int p = tid; p < MM; p += PLS_THREADS) {
-              const int i = p / M, j = p - i * M;
-              double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-              int k = 0;
-              for (; k + 3 < M; k += 4) {
-                a0 += src[(size_t)i * M + k] * src[(size_t)k * M + j];
-                a1 += src[(size_t)i * M + k + 1] * src[(size_t)(k + 1) * M + j];
-                a2 += src[(size_t)i * M + k + 2] * src[(size_t)(k + 2) * M + j];
-                a3 += src[(size_t)i * M + k + 3] * src[(size_t)(k + 3) * M + j];
-              }
-              for (; k < M; ++k) a0 += src[(size_t)i * M + k] * src[(size_t)k * M + j];
-              dst[p] = ((a0 + a1) + (a2 + a3)) * s2;           // B_t^2
-            }
-            __syncthreads();
-            double t0 = 0.0, t1 = 0.0;
-            int i = 0;
-            for (; i + 1 < M; i += 2) { t0 += dst[(size_t)i * M + i]; t1 += dst[(size_t)(i + 1) * M + i + 1]; }
-            if (i < M) t0 += dst[(size_t)i * M + i];
-            const double t2 = t0 + t1;
-            scale = 1.0 / t2;
-            double *tmp = src; src = dst; dst = tmp;
-            if (1.0 - t2 < 1e-13) break;
-          }
-          fin = src;
+        // wave 0, the matrix in registers (see the register maps above)
+        if (wave == 0) {
+          if (M <= 16) pls_eig_phase<1>(S0, tr, M, fin, lane);
+          else pls_eig_phase<2>(S0, tr, M, fin, lane);
         }
+        __syncthreads();
         // the column with the largest diagonal entry, then two power steps with the sum itself
-        double *scr = (fin == Ba) ? Bb : Ba;
+        double *scr = Bb;
         int best = 0;
         for (int i = 1; i < M; ++i) if (fin[(size_t)i * M + i] > fin[(size_t)best * M + best]) best = i;
         if (tid < M) qv[tid] = fin[(size_t)tid * M + best];

@@ -80,6 +80,9 @@ def fold_matrices(N, K, M, P, seed, dtype=np.float64, weighted=True):
     (900, 40, 1, 300, 6),      # many folds: one workgroup per fold
     (500, 33, 5, 7, 9),        # odd K: ragged last slice
     (300, 200, 2, 2, 10),
+    (500, 40, 20, 4, 8),       # 16 < M <= 32: the M x M matrix in 2 x 2 MFMA blocks
+    (700, 48, 32, 300, 6),
+    (400, 36, 17, 2, 5),
 ])
 def test_folds_from_cvmatrix_match_oracle(pls, N, K, M, P, A):
     from cvmatrix_amd import CVMatrix
