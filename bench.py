@@ -293,6 +293,25 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(bts / ms1 / 1e6, 1), "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
                              "bytes_per_fold": "s*n*(K+M+1) + 8n"}}
+        # the step after the path: Improved Kernel PLS (20 components) on the
+        # training matrices of this workload's folds, where the fold stage left them
+        if supp is not None:
+            from cvmatrix_amd.pls import pls_fit_batched, pls_plan
+            (bx, by), _ = model.training_XTX_XTY_batched(batch)
+            A_pls = 20
+            pls_fit_batched(bx, by, A_pls)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tl = []
+            for _ in range(10):
+                e0.record(); pls_fit_batched(bx, by, A_pls, check=False); e1.record()
+                torch.cuda.synchronize(); tl.append(e0.elapsed_time(e1))
+            ms1 = float(np.median(tl))
+            pp = pls_plan(P, K, M, A_pls, np.float64 if es == 8 else np.float32)
+            supp[f"pls_fit, {A_pls} components ({args.workload})"] = {
+                "folds": P, "ms": round(ms1, 4), "folds_per_s": round(P / ms1 * 1e3, 1),
+                "us_per_component": round(ms1 / A_pls * 1e3, 2), "plan": pp}
+            del bx, by
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not ho:
             from oracle.cvmatrix_oracle import run_cv

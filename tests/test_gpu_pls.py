@@ -161,3 +161,30 @@ def test_argument_errors(pls):
         pls.pls_fit_batched(XTX, torch.ones((1, 4, 33), dtype=torch.float64, device="cuda"), 2)
     with pytest.raises(TypeError):
         pls.pls_fit_batched(XTX.cpu(), XTY.cpu(), 2)
+
+
+def test_end_to_end_equals_refitting_each_fold_with_sklearn(pls):
+    """CVMatrix (centre + scale, ddof=1, unweighted) -> device PLS -> predictions on the validation
+    rows, against scikit-learn refitted from scratch on every training set (PLS1: no inner
+    iteration, agreement to rounding)."""
+    cross = pytest.importorskip("sklearn.cross_decomposition")
+    from cvmatrix_amd import CVMatrix
+    rng = np.random.default_rng(17)
+    N, K, P, A = 240, 12, 4, 5
+    L = rng.standard_normal((N, 4))
+    X = L @ rng.standard_normal((4, K)) + 0.3 * rng.standard_normal((N, K))
+    Y = L[:, :2] @ rng.standard_normal((2, 1)) + 0.05 * rng.standard_normal((N, 1))
+    folds = [np.arange(N)[np.arange(N) % P == f] for f in range(P)]
+    m = CVMatrix(True, True, True, True, ddof=1, dtype=np.float64)
+    m.fit(X, Y)
+    (XTX, XTY), (muX, sdX, muY, sdY) = m.training_XTX_XTY_batched(m.prepare_folds(folds))
+    fit = pls.pls_fit_batched(XTX, XTY, A)
+    B = fit.B.cpu().numpy()
+    muX, sdX, muY, sdY = (t.cpu().numpy() for t in (muX, sdX, muY, sdY))
+    for f, val in enumerate(folds):
+        train = np.setdiff1d(np.arange(N), val)
+        Xs = (X[val] - muX[f]) / sdX[f]
+        for a in range(A):
+            ref = cross.PLSRegression(n_components=a + 1, scale=True).fit(X[train], Y[train]).predict(X[val])
+            got = Xs @ B[f, a] * sdY[f] + muY[f]
+            assert np.abs(got - ref.reshape(got.shape)).max() <= 1e-9 * np.abs(ref).max(), (f, a)
