@@ -10,6 +10,8 @@
 // read from HBM once, not once per component), and trades only K + O(S (M^2 + A)) numbers with
 // the other slices of its fold per component, through L2/HBM, behind a per-fold barrier (a
 // monotonic counter; slices of one launch are co-resident by construction: folds x S <= CUs).
+// (Two sliced launches running at once on one device can each hold half the CUs and starve the
+// other's slices: the spin limit then reports status 1 instead of hanging; run one at a time.)
 // With S == 1 (many folds) the barrier is a __syncthreads().  All arithmetic in float64; fixed
 // summation orders, no float atomics: results do not depend on scheduling.
 #pragma once
@@ -83,7 +85,7 @@ __device__ __forceinline__ bool fold_barrier(unsigned *cnt, unsigned &target, in
     int ok = 1;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1L << 24)) { ok = 0; break; }      // seconds: the slices were not co-resident
+      if (++spins > (1L << 21)) { ok = 0; break; }      // seconds: the slices were not co-resident
     }
     if (!ok) *status = 1;
     *lflag = ok;

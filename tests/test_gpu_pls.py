@@ -188,3 +188,18 @@ def test_end_to_end_equals_refitting_each_fold_with_sklearn(pls):
             ref = cross.PLSRegression(n_components=a + 1, scale=True).fit(X[train], Y[train]).predict(X[val])
             got = Xs @ B[f, a] * sdY[f] + muY[f]
             assert np.abs(got - ref.reshape(got.shape)).max() <= 1e-9 * np.abs(ref).max(), (f, a)
+
+
+def test_sliced_runs_are_bitwise_repeatable(pls):
+    # the per-fold barrier and the exchange between slices: same bits run after run
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    for F, K, M, A in ((6, 256, 8, 10), (2, 1024, 1, 6)):
+        X = torch.randn((F, 2 * K, K), dtype=torch.float64, device="cuda", generator=g)
+        Y = torch.randn((F, 2 * K, M), dtype=torch.float64, device="cuda", generator=g)
+        XTX, XTY = X.transpose(1, 2) @ X, X.transpose(1, 2) @ Y
+        assert pls.pls_plan(F, K, M, A)["slices"] > 1
+        ref = pls.pls_fit_batched(XTX, XTY, A, return_factors=True)
+        for _ in range(25):
+            out = pls.pls_fit_batched(XTX, XTY, A, return_factors=True)
+            for a, b in zip((out.B, out.W, out.P, out.Q, out.R), (ref.B, ref.W, ref.P, ref.Q, ref.R)):
+                assert torch.equal(a, b)
