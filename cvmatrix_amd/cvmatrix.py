@@ -96,7 +96,10 @@ class CVMatrix:
         copy: bool = True,
         backend: str = "hip",
         device: Union[None, str, int, torch.device] = None,
+        lazy_fit: bool = True,
     ) -> None:
+        self.lazy_fit = bool(lazy_fit)
+        self._pending = False
         self.center_X, self.center_Y = center_X, center_Y
         self.scale_X, self.scale_Y = scale_X, scale_Y
         self.ddof = ddof
@@ -134,6 +137,87 @@ class CVMatrix:
         self._sweep_ws = None
         self.sweep_folds = None
         self._w_checked = None
+
+    # ------------------------------------------------------------------ full-data matrices
+    # ``fit`` may leave them pending (``lazy_fit``): they are computed on first use -- by the
+    # fit-stage kernel, or, when the first use is a batched call whose folds partition the
+    # rows, as the sum of the folds' validation matrices in the same sweep that serves the
+    # folds (half the arithmetic; SURVEY.md 8(f) rank 1, "behind the same API").
+    @property
+    def XTX(self):
+        self._ensure_fit()
+        return self._G
+
+    @XTX.setter
+    def XTX(self, v):
+        self._G = v
+
+    @property
+    def XTY(self):
+        self._ensure_fit()
+        return self._H
+
+    @XTY.setter
+    def XTY(self, v):
+        self._H = v
+
+    @property
+    def _gstats(self):
+        self._ensure_fit()
+        return self._gs
+
+    @_gstats.setter
+    def _gstats(self, v):
+        self._gs = v
+
+    def _ensure_fit(self) -> None:
+        if not self.__dict__.get("_pending", False):
+            return
+        self._pending = False
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            self._launch_fit(lib)
+        self._after_globals()
+
+    def _launch_fit(self, lib) -> None:
+        """The fit-stage kernel over all rows (cvm_gram_fit)."""
+        M = self.M or 0
+        neg = torch.empty(1, dtype=torch.int32, device=self.device)   # always written by fit_stats_kernel
+        ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self.K, M, self._cdt))
+        rc = lib.cvm_gram_fit(
+            self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), self.N, self.K,
+            M, self._cdt, self._G.data_ptr(), _lib.ptr(self._H),
+            self._gs.data_ptr(), neg.data_ptr(), ws.data_ptr(), ws.numel(),
+            self._stream(),
+        )
+        _lib.check(rc, "cvm_gram_fit")
+        self._neg = neg
+
+    def _after_globals(self) -> None:
+        """Hook: the full-data matrices of this process have just been launched (multi-GPU
+        subclasses exchange them here)."""
+
+    def _lazy_sweep(self, batch) -> None:
+        """First use after a lazy ``fit`` is a batched call: if its folds partition the rows,
+        form the full-data matrices as the sum of the folds' validation matrices."""
+        if not self.__dict__.get("_pending", False):
+            return
+        lib = _lib.load()
+        sizes = batch.sizes
+        # worth it when the folds are large: the sweep saves one pass of the Gram kernel over all
+        # rows and costs a write + read of every fold's K x (K+M) partials (about 256 rows of
+        # Gram work per fold at float64); small folds have their own direct route anyway
+        worth = (batch.n_folds > 0 and int(sizes.min()) > 32 and self.N >= 256 * batch.n_folds
+                 and lib.cvm_sweep_workspace_bytes(batch.n_folds, int(sizes.max()), self.K, self.M or 0,
+                                                   self._cdt) <= (4 << 30))
+        if worth and batch._n_rows == self.N and batch.is_partition:
+            self._pending = False
+            with torch.cuda.device(self.device):
+                neg = torch.empty(1, dtype=torch.int32, device=self.device)
+                self._fit_sweep(lib, batch, neg)
+            self._after_globals()
+        else:
+            self._ensure_fit()
 
     # ------------------------------------------------------------------ plumbing
     def _pick_device(self) -> torch.device:
@@ -208,27 +292,34 @@ class CVMatrix:
             else:
                 self.weights, self._w_host, self._w_checked = None, None, None
             M = self.M or 0
+            self._pending = False
             self._alloc_globals(lib.cvm_gstats_len(self.K, M))
-            neg = torch.empty(1, dtype=torch.int32, device=self.device)   # always written by fit_stats_kernel
             if folds is not None:
+                neg = torch.empty(1, dtype=torch.int32, device=self.device)
                 self._fit_sweep(lib, folds, neg)
+                self._neg = neg
+            elif self.lazy_fit:
+                self._neg = None
+                if self.weights is not None and self._w_host is None:
+                    # device-resident weights seen for the first time: sign check and the host
+                    # copy for the fold validity checks without waiting for a kernel
+                    self._w_host = self.weights.reshape(-1).cpu().numpy()
+                    if bool(np.any(self._w_host < 0)):
+                        raise ValueError(MSG_NEG_W)
+                    self._w_checked = self._weights_key(weights)
+                self._pending = True
             else:
-                ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self.K, M, self._cdt))
-                rc = lib.cvm_gram_fit(
-                    self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), self.N, self.K,
-                    M, self._cdt, self.XTX.data_ptr(), _lib.ptr(self.XTY),
-                    self._gstats.data_ptr(), neg.data_ptr(), ws.data_ptr(), ws.numel(),
-                    self._stream(),
-                )
-                _lib.check(rc, "cvm_gram_fit")
+                self._launch_fit(lib)
             if self.weights is not None and self._w_host is None:
                 # device-resident weights: one readback for the sign check and for the
                 # host-side fold validity checks (non-zero counts)
-                if int(neg.item()) != 0:
+                if int(self._neg.item()) != 0:
                     raise ValueError(MSG_NEG_W)
                 self._w_host = self.weights.reshape(-1).cpu().numpy()
                 self._w_checked = self._weights_key(weights)
             self._publish_stats()
+        if not self._pending:
+            self._after_globals()
 
     def _alloc_globals(self, n_gstats: int) -> None:
         """``XTX``, ``XTY`` and the float64 statistics vector as views of ONE contiguous
@@ -273,7 +364,7 @@ class CVMatrix:
         rc = lib.cvm_sweep_fit(
             self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), batch.idx.data_ptr(),
             batch.offsets.data_ptr(), batch.host_offsets.ctypes.data, P, self.N, K, M, self._cdt,
-            self.XTX.data_ptr(), _lib.ptr(self.XTY), self._gstats.data_ptr(), neg.data_ptr(),
+            self._G.data_ptr(), _lib.ptr(self._H), self._gs.data_ptr(), neg.data_ptr(),
             self._sweep_ws.data_ptr(), self._sweep_ws.numel(), self._stream(), C.byref(splits),
         )
         _lib.check(rc, "cvm_sweep_fit")
@@ -581,6 +672,7 @@ class CVMatrix:
         if rXTY and self.Y is None:
             raise ValueError(MSG_NO_Y)
         batch = self.prepare_folds(folds)
+        self._lazy_sweep(batch)
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         r_muX = cX or (rXTY and cY)                 # cvmatrix.py:828-831
         r_muY = rXTY and (cX or cY)
@@ -651,6 +743,7 @@ class CVMatrix:
         r_muY, r_sdY = ((cY or sY) and hasY), (sY and hasY)
         if not (r_muX or r_sdX or r_muY or r_sdY):
             return None, None, None, None
+        self._ensure_fit()
         self._validate(batch, True, r_sdX or r_sdY)
         # the kernel derives "what to compute" from (return flags, centre/scale flags)
         # exactly like cvmatrix.py:828-831; pass a flag set whose derived wants cover

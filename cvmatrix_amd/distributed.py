@@ -92,11 +92,15 @@ class ShardedCVMatrix(CVMatrix):
     ``training_*`` are local row numbers of this rank.  mode="replicated": ``fit`` receives
     all rows on every rank; use ``my_folds`` to pick this rank's share of the folds."""
 
-    def __init__(self, *args, mode: str = "row_sharded", group=None, src: int = 0, **kw):
-        super().__init__(*args, **kw)
+    def __init__(self, *args, mode: str = "row_sharded", group=None, src: int = 0, lazy_fit: bool = False,
+                 **kw):
+        # lazy_fit=True moves the exchange of the full-data matrices from ``fit`` to the first
+        # call that needs them: every rank must then make that call (it is collective)
+        super().__init__(*args, lazy_fit=lazy_fit, **kw)
         if mode not in ("row_sharded", "replicated"):
             raise ValueError("mode must be 'row_sharded' or 'replicated'")
         self.mode, self.group, self.src = mode, group, src
+        self._fit_weights = None
 
     @property
     def world(self) -> int:
@@ -110,14 +114,35 @@ class ShardedCVMatrix(CVMatrix):
         return assign_folds(sizes, self.world)[self.rank]
 
     def fit(self, X, Y=None, weights=None, folds=None) -> None:
+        if self.world > 1 and self.mode == "replicated" and folds is not None:
+            raise ValueError("fit(folds=...) needs mode='row_sharded' (or a single process)")
+        self._fit_weights = weights
+        super().fit(X, Y, weights, folds=folds)     # row_sharded: this rank's rows (and folds)
+
+    def _launch_fit(self, lib) -> None:
+        if self.world > 1 and self.mode == "replicated" and self.rank != self.src:
+            self._neg = torch.zeros(1, dtype=torch.int32, device=self.device)
+            if self.weights is not None and self._w_host is None:
+                self._w_host = self.weights.reshape(-1).cpu().numpy()
+                if bool(np.any(self._w_host < 0)):
+                    raise ValueError("Weights must be non-negative.")
+            return                                  # the broadcast fills the matrices
+        super()._launch_fit(lib)
+
+    def _lazy_sweep(self, batch) -> None:
+        if self.world > 1 and self.mode == "replicated":
+            return self._ensure_fit()               # a rank's folds do not partition the rows
+        super()._lazy_sweep(batch)
+
+    def _after_globals(self) -> None:
+        """The one exchange of the path: sum (row-sharded) or replicate the full-data matrices."""
         if self.world == 1:
-            return super().fit(X, Y, weights, folds=folds)
+            return
         if self.mode == "row_sharded":
-            super().fit(X, Y, weights, folds=folds)   # folds: this rank's rows, partitioned
-            allreduce_globals(self.XTX, self.XTY, self._gstats, self.group, flat=self._globals)
+            allreduce_globals(self._G, self._H, self._gs, self.group, flat=self._globals)
             # the global counts depend on the weights and the row counts only: when the same
             # (unmodified) device tensors are fitted again, skip the device read-back
-            key = (self._weights_key(weights), self.N, self.world)
+            key = (self._weights_key(self._fit_weights), self.N, self.world)
             if key[0] is not None and key == getattr(self, "_totals_key", None):
                 self._n_total, self._nz_total = self._totals_val
                 self._sum_w = None
@@ -125,50 +150,18 @@ class ShardedCVMatrix(CVMatrix):
                 self._sync_totals()
                 self._totals_key, self._totals_val = key, (self._n_total, self._nz_total)
         else:
-            if folds is not None:
-                raise ValueError("fit(folds=...) needs mode='row_sharded' (or a single process)")
-            if self.rank == self.src:
-                super().fit(X, Y, weights)
-            else:
-                self._fit_without_gram(X, Y, weights)
-            broadcast_globals(self.XTX, self.XTY, self._gstats, self.src, self.group,
-                              flat=self._globals)
+            broadcast_globals(self._G, self._H, self._gs, self.src, self.group, flat=self._globals)
 
     def _sync_totals(self) -> None:
         """Global sample / non-zero-weight counts for the host-side validity checks
         (cvmatrix.py:612-630, 1074-1078): they ride in the all-reduced gstats."""
         K, M = self.K, self.M or 0
-        tail = self._gstats[2 * K + 2 * M : 2 * K + 2 * M + 2].cpu()
+        tail = self._gs[2 * K + 2 * M : 2 * K + 2 * M + 2].cpu()
         self._nz_total = int(round(float(tail[1])))
         if self.weights is None:
             self._n_total = int(round(float(tail[0])))
         else:
-            cnt = torch.tensor([self.N], dtype=torch.int64, device=self._gstats.device)
+            cnt = torch.tensor([self.N], dtype=torch.int64, device=self._gs.device)
             dist.all_reduce(cnt, group=self.group)
             self._n_total = int(cnt.item())
         self._sum_w = None
-
-    def _fit_without_gram(self, X, Y, weights) -> None:
-        """Non-source rank of the replicated mode: upload the data, allocate the globals,
-        skip the fit-stage kernel (the broadcast fills them)."""
-        from . import _lib
-
-        lib = _lib.load()
-        self.device = self._pick_device()
-        with torch.cuda.device(self.device):
-            self.X = self._init_mat(X)
-            self.N, self.K = self.X.shape
-            self.Y = self._init_mat(Y) if Y is not None else None
-            self.M = self.Y.shape[1] if Y is not None else None
-            if weights is not None:
-                self._check_weights_host(weights)
-                self.weights = self._init_mat(weights)
-                if self._w_host is None:
-                    self._w_host = self.weights.reshape(-1).cpu().numpy()
-                    if bool(np.any(self._w_host < 0)):
-                        raise ValueError("Weights must be non-negative.")
-            else:
-                self.weights, self._w_host = None, None
-            M = self.M or 0
-            self._alloc_globals(lib.cvm_gstats_len(self.K, M))
-        self._publish_stats()

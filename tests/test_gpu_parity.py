@@ -884,6 +884,17 @@ def _sharded_worker(rank, world, port, tmp, mode):
         assert torch.allclose(a, c, rtol=1e-10, atol=1e-10) and torch.allclose(b, d, rtol=1e-10, atol=1e-10)
         for s, t in zip(sa, sc):
             assert torch.allclose(s, t, rtol=1e-10, atol=1e-12)
+        # lazy fit (what bench.py times): the exchange moves to the first batched call, which every
+        # rank makes; row-sharded: the rank's folds partition its rows -> one sweep + all-reduce
+        lz = ShardedCVMatrix(mode=mode, lazy_fit=True)
+        lz.fit(X[rows], Y[rows], w[rows]) if mode == "row_sharded" else lz.fit(X, Y, w)
+        assert lz._pending
+        (a2, b2), sa2 = lz.training_XTX_XTY_batched(local)
+        assert not lz._pending and (lz._sweep is not None) == (mode == "row_sharded")
+        assert torch.allclose(a2, c, rtol=1e-10, atol=1e-10) and torch.allclose(b2, d, rtol=1e-10, atol=1e-10)
+        for s, t in zip(sa2, sc):
+            assert torch.allclose(s, t, rtol=1e-10, atol=1e-12)
+        assert torch.allclose(lz.XTX, full.XTX, rtol=1e-12, atol=1e-12)
         open(os.path.join(tmp, f"ok_{mode}_{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -945,3 +956,89 @@ def test_float32_shape_sweep(amd, K, M, route):
                     np.testing.assert_allclose(to_np(a_[f]).astype(np.float64), b_, rtol=3e-5)
             t = bx[f]
             assert bool((t == t.T).all())
+
+
+# ---------------------------------------------------------------- lazy fit (the default)
+@pytest.mark.parametrize("weighted", [True, False])
+@pytest.mark.parametrize("flags", [(True,) * 4, (False,) * 4, (True, False, False, True)])
+def test_lazy_fit_one_sweep_equals_eager_and_oracle(amd, weighted, flags):
+    """fit() leaves the full-data matrices pending; a batched call whose folds partition the rows
+    forms them as the sum of the folds' validation matrices (one sweep).  Same results as the
+    eager two-stage path (to rounding) and as the oracle (1e-10)."""
+    rng = np.random.default_rng(77)
+    N, K, M, P = 6000, 136, 6, 5
+    X, Y = rng.random((N, K)), rng.random((N, M))
+    w = rng.random(N) if weighted else None
+    if weighted:
+        w[::17] = 0.0
+    folds = [np.arange(N)[np.arange(N) % P == f] for f in range(P)]
+    lz = amd.CVMatrix(*flags, lazy_fit=True)
+    eg = amd.CVMatrix(*flags, lazy_fit=False)
+    lz.fit(X, Y, w)
+    eg.fit(X, Y, w)
+    assert lz._pending and not eg._pending
+    (a, b), sa = lz.training_XTX_XTY_batched(folds)
+    assert not lz._pending and lz._sweep is not None
+    (c, d), sc = eg.training_XTX_XTY_batched(folds)
+    assert_normwise(a, to_np(c), 1e-11, "lazy vs eager XTX")
+    assert_normwise(b, to_np(d), 1e-11, "lazy vs eager XTY")
+    assert_normwise(lz.XTX, to_np(eg.XTX), 1e-12, "full-data XTX")
+    assert_normwise(lz.XTY, to_np(eg.XTY), 1e-12, "full-data XTY")
+    o = OracleCVMatrix(*flags)
+    o.fit(X, Y, w)
+    for f in (0, P - 1):
+        (rx, ry), rst = o.training_XTX_XTY(folds[f])
+        assert_normwise(a[f], rx, TOL, "XTX")
+        assert_normwise(b[f], ry, TOL, "XTY")
+        assert_stats(tuple(None if s is None else s[f] for s in sa), rst, TOL)
+    # the same batch again (no refit): the partials are reused; a refit makes it pending again
+    batch = lz.prepare_folds(folds)
+    lz.fit(X, Y, w)
+    (a3, b3), _ = lz.training_XTX_XTY_batched(batch)
+    (a4, b4), _ = lz.training_XTX_XTY_batched(batch)
+    assert torch_equal(a3, a4) and torch_equal(b3, b4) and torch_equal(a3, a)
+
+
+def torch_equal(x, y):
+    import torch
+    return bool(torch.equal(x, y))
+
+
+def test_lazy_fit_other_first_uses_take_the_fit_kernel(amd):
+    rng = np.random.default_rng(78)
+    N, K, M = 3000, 40, 3
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    eg = amd.CVMatrix(lazy_fit=False)
+    eg.fit(X, Y, w)
+    sub = [np.arange(0, 500), np.arange(700, 1500)]              # not a partition
+    for first_use in ("attribute", "per_fold", "subset", "statistics"):
+        lz = amd.CVMatrix()                                      # lazy by default
+        lz.fit(X, Y, w)
+        assert lz._pending
+        if first_use == "attribute":
+            assert torch_equal(lz.XTX, eg.XTX) and torch_equal(lz.sum_X, eg.sum_X)
+        elif first_use == "per_fold":
+            (a, b), _ = lz.training_XTX_XTY(sub[0])
+            (c, d), _ = eg.training_XTX_XTY(sub[0])
+            assert torch_equal(a, c) and torch_equal(b, d)
+        elif first_use == "subset":
+            (a, b), _ = lz.training_XTX_XTY_batched(sub)
+            (c, d), _ = eg.training_XTX_XTY_batched(sub)
+            assert torch_equal(a, c) and torch_equal(b, d)
+        else:
+            sa = lz.training_statistics_batched(sub)
+            sc = eg.training_statistics_batched(sub)
+            assert all(torch_equal(s, t) for s, t in zip(sa, sc))
+        assert not lz._pending and lz._sweep is None
+        assert torch_equal(lz.XTY, eg.XTY)
+
+
+def test_lazy_fit_raises_on_negative_device_weights_in_fit(amd):
+    import torch
+    rng = np.random.default_rng(79)
+    X = torch.from_numpy(rng.random((200, 8))).cuda()
+    w = torch.from_numpy(rng.random(200)).cuda()
+    w[5] = -1.0
+    for lazy in (True, False):
+        with pytest.raises(ValueError, match="Weights must be non-negative."):
+            amd.CVMatrix(lazy_fit=lazy).fit(X, None, w)
