@@ -4,6 +4,10 @@
 One "step" = one full cross-validation pass over device-resident inputs, the quantity the
 reference's benchmark times (benchmarks/benchmark.py:101-158): CVMatrix.fit() (full-data
 Gram + column statistics) followed by training_XTX_XTY for every fold (one batched call).
+`value` is the package's default path: fit() is lazy and, the folds partitioning the rows,
+one sweep of the Gram kernel yields the full-data matrices and every fold's matrices
+(DESIGN.md 4.5); the eager two-stage path is timed next to it (two_stage_*, fit_ms,
+fold_stage_ms).
 Workload = BASELINE.json configs[2] ("C3"): N=100000, K=512, M=16, 10 folds
 (folds = arange(N) % P), weighted, center+scale X and Y, float64, inputs from
 default_rng(42).random exactly as benchmarks/benchmark.py:223-233.
@@ -57,8 +61,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="run only warmup + the timed steps (no split timers, per-fold-call, "
-                         "one-sweep, supplementary or CPU legs): the command profiled under "
+                    help="run only warmup + the timed steps (no split timers, two-stage, per-fold-call, "
+                         "supplementary or CPU legs): the command profiled under "
                          "rocprofv3 for profiles/, so that every launch in the trace is a "
                          "launch of the timed region")
     ap.add_argument("--rows", type=int, default=0, help="override N per GPU (debug)")
