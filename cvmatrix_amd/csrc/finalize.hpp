@@ -45,9 +45,17 @@ template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *
     else if (c < 2 * g.K + g.M) src = 2 * g.Kp + (c - 2 * g.K);
     else if (c < 2 * g.K + 2 * g.M) src = 2 * g.Kp + g.Mp + (c - 2 * g.K - g.M);
     else src = 2 * g.Kp + 2 * g.Mp + (c - 2 * g.K - 2 * g.M);
+    // in split order; sixteen loads in flight at a time (the chain of adds stays sequential)
     double s = 0;
-#pragma unroll 4
-    for (int p = 0; p < a.splits; ++p) s += unit_stats<T>((char *)a.ws, g, p)[src];
+    int p = 0;
+    for (; p + 16 <= a.splits; p += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = unit_stats<T>((char *)a.ws, g, p + u)[src];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; p < a.splits; ++p) s += unit_stats<T>((char *)a.ws, g, p)[src];
     if (c < total - 1) gstats[c] = s;
     else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
   }

@@ -184,7 +184,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   memset(&f, 0, sizeof(f));
   f.g = p.g; f.splits = p.splits; f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
-  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
+  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
   hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
                      dim3(APPLY_THREADS_FIT), 0, st, f);
   HIP_OK(hipGetLastError());
@@ -430,7 +430,7 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   f.g = p.g; f.splits = (int)(n_folds * p.splits);   // every unit of every fold, fold-major
   f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
-  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(8), dim3(256), 0, st, f, gstats);
+  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
   hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
                      dim3(APPLY_THREADS_FIT), 0, st, f);
   HIP_OK(hipGetLastError());
