@@ -203,3 +203,29 @@ def test_sliced_runs_are_bitwise_repeatable(pls):
             out = pls.pls_fit_batched(XTX, XTY, A, return_factors=True)
             for a, b in zip((out.B, out.W, out.P, out.Q, out.R), (ref.B, ref.W, ref.P, ref.Q, ref.R)):
                 assert torch.equal(a, b)
+
+
+def test_example_fast_cv_matches_refits(pls):
+    """examples/fast_cv_pls.py: cross-validated RMSE per number of components equals the one from
+    scikit-learn models refitted on every training set (PLS1)."""
+    cross = pytest.importorskip("sklearn.cross_decomposition")
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fast_cv_pls", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "fast_cv_pls.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    rng = np.random.default_rng(2)
+    N, K, P, A = 300, 10, 5, 4
+    L = rng.standard_normal((N, 3))
+    X = L @ rng.standard_normal((3, K)) + 0.3 * rng.standard_normal((N, K))
+    Y = L[:, :1] * 2.0 + 0.1 * rng.standard_normal((N, 1))
+    labels = np.arange(N) % P
+    got = ex.fast_cv_rmse(X, Y, labels, A)
+    sse = np.zeros(A)
+    for f in range(P):
+        val, tr = labels == f, labels != f
+        for a in range(A):
+            pred = cross.PLSRegression(n_components=a + 1, scale=True).fit(X[tr], Y[tr]).predict(X[val])
+            sse[a] += ((pred.reshape(-1) - Y[val].reshape(-1)) ** 2).sum()
+    np.testing.assert_allclose(got[:, 0], np.sqrt(sse / N), rtol=1e-9)
