@@ -339,8 +339,24 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
 #pragma unroll
       for (int e = 0; e < VW; ++e) v[j][e] = 0;
     }
-#pragma unroll 2
-    for (int p = 0; p < a.splits; ++p) {
+    // UP splits' pieces requested before the first is added (fit mode runs on few workgroups:
+    // it needs the loads of several splits in flight per thread)
+    constexpr int UP = FOLD ? 2 : 8;
+    int p = 0;
+    for (; p + UP <= a.splits; p += UP) {
+      vld_t qv[UP][NQ];
+#pragma unroll
+      for (int u = 0; u < UP; ++u)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)(p + u) * g.unit_bytes);
+#pragma unroll
+      for (int u = 0; u < UP; ++u)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[u][j][e];
+    }
+    for (; p < a.splits; ++p) {
       vld_t qv[NQ];
 #pragma unroll
       for (int j = 0; j < NQ; ++j) qv[j] = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)p * g.unit_bytes);
@@ -382,6 +398,141 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
         else if (sY) v = v / fs[2 * K + M + m];
       }
       out[(size_t)ga * M + m] = (T)v;
+    }
+  }
+}
+
+// Fit mode on many workgroups: the full-data matrices as the ordered sum of the units' partials.
+// A 64x64 sub-tile is cut into FIT_RC row chunks, one 256-thread workgroup each (176 workgroups
+// at K = 512 instead of 44: the sum of 25-50 partials per element is bound by what a CU can pull).
+// Rows are stored as they are summed; the mirrored block goes through a [rows][65] LDS transpose.
+// On a diagonal sub-tile only the upper triangle is stored, twice (as is and mirrored), so the
+// result is exactly symmetric.  Needs 16-byte aligned rows (K * sizeof(T) % 16 == 0).
+constexpr int FIT_RC = 4;
+constexpr int FIT_RH = ST / FIT_RC;
+constexpr int FIT_THREADS = 256;
+constexpr int FIT_PCH = 4;             // row chunks of a 128-row XTY panel
+template <typename T>
+__global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a) {
+  const Geom &g = a.g;
+  const int K = g.K, M = g.M;
+  const int x = blockIdx.x, tid = threadIdx.x;
+  const int n_sub = g.nTiles * APPLY_SUB * FIT_RC;
+  constexpr int VW = 16 / sizeof(T);
+  typedef T vld_t __attribute__((ext_vector_type(VW)));
+  if (x < n_sub) {
+    if (!a.out_XTX) return;
+    const int t = x / (APPLY_SUB * FIT_RC);
+    const int rem = x - t * (APPLY_SUB * FIT_RC);
+    const int sub = rem / FIT_RC, ch = rem - sub * FIT_RC;
+    int ti, tj;
+    decode_tile(t, g.P, ti, tj);
+    const int si = sub >> 1, sj = sub & 1;
+    if (ti == tj && si > sj) return;                 // strictly lower: mirror of sub-tile (0,1)
+    const int a0 = ti * TILE + si * ST + ch * FIT_RH, b0 = tj * TILE + sj * ST;
+    if (a0 >= K || b0 >= K) return;
+    const bool diag = (ti == tj && si == sj);
+    __shared__ double Ts[FIT_RH][ST + 1];
+    constexpr int LPR = ST / VW;
+    constexpr int NQ = FIT_RH * LPR / FIT_THREADS;   // 2 (float64) or 1 (float32) pieces per thread
+    static_assert(NQ >= 1, "chunk smaller than the workgroup");
+    double v[NQ][VW];
+    const char *pp[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = tid + j * FIT_THREADS;
+      const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+      const size_t off = (size_t)t * TILE * TILE + (size_t)(si * ST + ch * FIT_RH + lr) * TILE + sj * ST + lc;
+      pp[j] = a.ws + off * sizeof(T);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[j][e] = 0;
+    }
+    constexpr int UP = 8;                            // splits requested before the first is added
+    int p = 0;
+    for (; p + UP <= a.splits; p += UP) {
+      vld_t qv[UP][NQ];
+#pragma unroll
+      for (int u = 0; u < UP; ++u)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)(p + u) * g.unit_bytes);
+#pragma unroll
+      for (int u = 0; u < UP; ++u)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[u][j][e];
+    }
+    for (; p < a.splits; ++p) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const vld_t qv = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)p * g.unit_bytes);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[e];
+      }
+    }
+    T *out = (T *)a.out_XTX;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = tid + j * FIT_THREADS;
+      const int lr = q / LPR, lc = (q - lr * LPR) * VW;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = v[j][e];
+      const int gr = a0 + lr, gc = b0 + lc;
+      if (gr >= K || gc >= K) continue;
+      T *dst = out + (size_t)gr * K + gc;
+      if (!diag && gc + VW <= K) {
+        vld_t vv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vv[e] = (T)v[j][e];
+        *reinterpret_cast<vld_t *>(dst) = vv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e)
+          if (gc + e < K && (!diag || gc + e >= gr)) dst[e] = (T)v[j][e];
+      }
+    }
+    __syncthreads();
+    // mirrored: rows b0 + c, columns a0 + rr (contiguous over rr)
+    constexpr int PPR = FIT_RH / VW;                 // 16-byte pieces per mirrored row
+    for (int q = tid; q < ST * PPR; q += FIT_THREADS) {
+      const int c = q / PPR, rr = (q - c * PPR) * VW;
+      const int gr = b0 + c, gc = a0 + rr;
+      if (gr >= K || gc >= K) continue;
+      T *dst = out + (size_t)gr * K + gc;
+      if (!diag && gc + VW <= K) {
+        vld_t vv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vv[e] = (T)Ts[rr + e][c];
+        *reinterpret_cast<vld_t *>(dst) = vv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e)
+          if (gc + e < K && (!diag || gr > gc + e)) dst[e] = (T)Ts[rr + e][c];
+      }
+    }
+  } else {
+    if (!a.out_XTY || M == 0) return;
+    const int x2 = x - n_sub;
+    const int ti = x2 / FIT_PCH, pc = x2 - ti * FIT_PCH;
+    constexpr int PR = TILE / FIT_PCH;
+    T *out = (T *)a.out_XTY;
+    const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
+    for (int e = tid; e < PR * M; e += FIT_THREADS) {
+      const int ra = e / M, m = e - ra * M;
+      const int ga = ti * TILE + pc * PR + ra;
+      if (ga >= K) continue;
+      double s = 0;
+      const char *pp = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
+      int p = 0;
+      for (; p + 8 <= a.splits; p += 8) {
+        T t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = *reinterpret_cast<const T *>(pp + (size_t)(p + u) * g.unit_bytes);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)t8[u];
+      }
+      for (; p < a.splits; ++p) s += (double)*reinterpret_cast<const T *>(pp + (size_t)p * g.unit_bytes);
+      out[(size_t)ga * M + m] = (T)s;
     }
   }
 }

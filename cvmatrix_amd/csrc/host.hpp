@@ -163,6 +163,16 @@ bool rows_aligned(const void *X, int K, int esize) {
   return ((uintptr_t)X % 16 == 0) && (((size_t)K * esize) % 16 == 0);
 }
 
+// full-data matrices from the partials: the many-workgroup kernel when rows are 16-byte aligned
+template <typename T> void launch_fit_apply(const FinArgs &f, const Geom &g, hipStream_t st) {
+  const bool aligned = ((size_t)g.K * sizeof(T)) % 16 == 0 && ((uintptr_t)f.out_XTX % 16 == 0);
+  if (aligned)
+    hipLaunchKernelGGL((fit_apply_kernel<T>), dim3(g.nTiles * APPLY_SUB * FIT_RC + g.P * FIT_PCH), dim3(FIT_THREADS), 0,
+                       st, f);
+  else
+    hipLaunchKernelGGL((apply_kernel<T, false>), dim3(g.nTiles * APPLY_SUB + g.P, 1), dim3(APPLY_THREADS_FIT), 0, st, f);
+}
+
 template <typename T>
 int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
                   void *G, void *H, double *gstats, int32_t *neg_flag, void *ws, size_t ws_bytes,
@@ -185,8 +195,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   f.g = p.g; f.splits = p.splits; f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
   hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
-  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
-                     dim3(APPLY_THREADS_FIT), 0, st, f);
+  launch_fit_apply<T>(f, p.g, st);
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
@@ -431,8 +440,7 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
   hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
-  hipLaunchKernelGGL((apply_kernel<T, false>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, 1),
-                     dim3(APPLY_THREADS_FIT), 0, st, f);
+  launch_fit_apply<T>(f, p.g, st);
   HIP_OK(hipGetLastError());
   if (splits_out) *splits_out = p.splits;
   return CVM_OK;
