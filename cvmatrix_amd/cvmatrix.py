@@ -17,6 +17,8 @@ There is no CPU path in this module: it raises if the extension or a GPU is miss
 
 from __future__ import annotations
 
+import os
+
 from typing import Iterable, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -96,8 +98,11 @@ class CVMatrix:
         copy: bool = True,
         backend: str = "hip",
         device: Union[None, str, int, torch.device] = None,
-        lazy_fit: bool = True,
+        lazy_fit: Optional[bool] = None,
     ) -> None:
+        # None: lazy unless the environment says CVM_LAZY_FIT=0 (the test-suite runs both ways)
+        if lazy_fit is None:
+            lazy_fit = os.environ.get("CVM_LAZY_FIT", "1") != "0"
         self.lazy_fit = bool(lazy_fit)
         self._pending = False
         self.center_X, self.center_Y = center_X, center_Y

@@ -23,14 +23,25 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.fixture(scope="module")
-def amd(hip_device):
+@pytest.fixture(scope="module", params=["lazy_fit", "eager_fit"])
+def amd(hip_device, request):
+    """Every test runs twice: with the package default (fit() lazy: a batched call over folds that
+    partition the rows is served by one sweep) and with CVM_LAZY_FIT=0 (fit kernel, then the fold
+    update kernels), so both routes see all the cases."""
+    import os
+
     import cvmatrix_amd
 
     from cvmatrix_amd import _lib
 
     _lib.load()  # fails loudly if the extension is missing
-    return cvmatrix_amd
+    old = os.environ.get("CVM_LAZY_FIT")
+    os.environ["CVM_LAZY_FIT"] = "1" if request.param == "lazy_fit" else "0"
+    yield cvmatrix_amd
+    if old is None:
+        os.environ.pop("CVM_LAZY_FIT", None)
+    else:
+        os.environ["CVM_LAZY_FIT"] = old
 
 
 def make_factory(amd):
@@ -1012,7 +1023,7 @@ def test_lazy_fit_other_first_uses_take_the_fit_kernel(amd):
     eg.fit(X, Y, w)
     sub = [np.arange(0, 500), np.arange(700, 1500)]              # not a partition
     for first_use in ("attribute", "per_fold", "subset", "statistics"):
-        lz = amd.CVMatrix()                                      # lazy by default
+        lz = amd.CVMatrix(lazy_fit=True)
         lz.fit(X, Y, w)
         assert lz._pending
         if first_use == "attribute":

@@ -11,7 +11,7 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 X = torch.rand((N, K), dtype=torch.float64, device=dev, generator=g)
 Y = torch.rand((N, M), dtype=torch.float64, device=dev, generator=g)
 w = torch.rand((N,), dtype=torch.float64, device=dev, generator=g)
-m = CVMatrix(copy=False); m.fit(X, Y, w)
+m = CVMatrix(copy=False, lazy_fit=False); m.fit(X, Y, w)
 for P in (3, 5, 10, 30, 100, 300, 1000, 2000, 3000):
     nv = N // P
     nf = min(P, max(1, int(8e9 // (K * (K + M) * 8))))      # cap the output at 8 GB

@@ -12,7 +12,7 @@ def run(name, N, K, M, nv, nfolds, dtype, reps=5):
     X = torch.rand((N, K), dtype=tdt, device=dev, generator=g)
     Y = torch.rand((N, M), dtype=tdt, device=dev, generator=g)
     w = torch.rand((N,), dtype=tdt, device=dev, generator=g)
-    m = CVMatrix(dtype=dtype, copy=False)
+    m = CVMatrix(dtype=dtype, copy=False, lazy_fit=False)
     m.fit(X, Y, w)
     folds = [np.arange(i * nv, (i + 1) * nv) for i in range(nfolds)]
     b = m.prepare_folds(folds)

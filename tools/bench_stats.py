@@ -15,7 +15,7 @@ for (N, K, M, P, dt) in ((100000, 512, 16, 10, torch.float64), (200000, 4096, 1,
     X = torch.rand((N, K), dtype=dt, device=dev, generator=g)
     Y = torch.rand((N, M), dtype=dt, device=dev, generator=g)
     w = torch.rand((N,), dtype=dt, device=dev, generator=g)
-    m = CVMatrix(dtype=np.float64 if dt == torch.float64 else np.float32, copy=False, device=dev)
+    m = CVMatrix(dtype=np.float64 if dt == torch.float64 else np.float32, copy=False, device=dev, lazy_fit=False)
     m.fit(X, Y, w)
     b = m.prepare_folds(Partitioner(np.arange(N) % P))
     m.training_statistics_batched(b); torch.cuda.synchronize()

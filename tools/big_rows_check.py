@@ -7,7 +7,7 @@ for (N, K, M) in ((6000000, 64, 2), (40000000, 8, 0)):
     X = torch.rand((N, K), dtype=torch.float64, device=dev, generator=g)
     Y = torch.rand((N, M), dtype=torch.float64, device=dev, generator=g) if M else None
     w = torch.rand((N,), dtype=torch.float64, device=dev, generator=g)
-    m = CVMatrix(copy=False, device=dev); m.fit(X, Y, w)
+    m = CVMatrix(copy=False, device=dev, lazy_fit=False); m.fit(X, Y, w)
     Gr = (X * w[:, None]).T @ X
     print(N, K, "fit err", float((m.XTX - Gr).abs().max() / Gr.abs().max()))
     P = 4

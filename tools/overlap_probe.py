@@ -12,8 +12,8 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 X = torch.rand((N, K), dtype=torch.float64, device=dev, generator=g)
 Y = torch.rand((N, M), dtype=torch.float64, device=dev, generator=g)
 w = torch.rand((N,), dtype=torch.float64, device=dev, generator=g)
-a = CVMatrix(copy=False, device=dev); a.fit(X, Y, w)
-b = CVMatrix(copy=False, device=dev); b.fit(X, Y, w)
+a = CVMatrix(copy=False, device=dev, lazy_fit=False); a.fit(X, Y, w)
+b = CVMatrix(copy=False, device=dev, lazy_fit=False); b.fit(X, Y, w)
 batch = b.prepare_folds(Partitioner(np.arange(N) % P))
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 

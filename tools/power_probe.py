@@ -8,7 +8,7 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 X = torch.rand((N, K), dtype=torch.float64, device=dev, generator=g)
 Y = torch.rand((N, M), dtype=torch.float64, device=dev, generator=g)
 w = torch.rand((N,), dtype=torch.float64, device=dev, generator=g)
-m = CVMatrix(copy=False, device=dev); m.fit(X, Y, w)
+m = CVMatrix(copy=False, device=dev, lazy_fit=False); m.fit(X, Y, w)
 b = m.prepare_folds(Partitioner(np.arange(N) % P))
 samples = []
 stop = False

@@ -9,7 +9,7 @@ N, K, M, P = 100000, 512, 16, 10
 X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
 import os
 if os.environ.get("UNWEIGHTED"): w = None
-m = CVMatrix(); m.fit(X, Y, w)
+m = CVMatrix(lazy_fit=False); m.fit(X, Y, w)
 b = m.prepare_folds(Partitioner(np.arange(N) % P))
 for _ in range(3): m.training_XTX_XTY_batched(b)
 L.load().cvm_timing_enable(1)

@@ -17,7 +17,7 @@ def one(path):
     rng = np.random.default_rng(42)
     N, K, M, P = 100000, 512, 16, 10
     X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
-    m = CVMatrix(); m.fit(X, Y, w)
+    m = CVMatrix(lazy_fit=False); m.fit(X, Y, w)
     b = m.prepare_folds(Partitioner(np.arange(N) % P))
     Xd, Yd, wd = m.X, m.Y, m.weights if hasattr(m, "weights") else None
     for _ in range(3):
