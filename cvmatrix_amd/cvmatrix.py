@@ -487,11 +487,26 @@ class CVMatrix:
         if isinstance(folds, Partitioner):
             labels = list(folds.folds_dict)
             folds = list(folds.folds_dict.values())
-        parts = [self._wrap_indices(v) for v in folds]
-        sizes = np.array([p.size for p in parts], dtype=np.int64)
+        if not isinstance(folds, (list, tuple)):
+            folds = list(folds)
+        if folds and all(type(v) is np.ndarray and v.ndim == 1 and v.dtype.kind in "iu" for v in folds):
+            # integer index arrays (what a Partitioner holds): one bounds check / wrap for the
+            # whole batch instead of one per fold (100 000 leave-one-out folds: 0.2 s -> ms)
+            sizes = np.fromiter((v.size for v in folds), dtype=np.int64, count=len(folds))
+            idx = np.concatenate(folds).astype(np.int64, copy=False)
+            if idx.size:
+                lo, hi = int(idx.min()), int(idx.max())
+                if lo < -self.N or hi >= self.N:
+                    raise IndexError(f"validation index out of bounds for {self.N} samples")
+                if lo < 0:
+                    idx = np.where(idx < 0, idx + self.N, idx)
+            parts = folds
+        else:
+            parts = [self._wrap_indices(v) for v in folds]
+            sizes = np.array([p.size for p in parts], dtype=np.int64)
+            idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
         host_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
         np.cumsum(sizes, out=host_offsets[1:])
-        idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
         if self._w_host is not None:
             wh = self._w_host
             if self._nz_mask is None or self._nz_mask[0] is not wh:

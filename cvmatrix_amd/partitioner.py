@@ -45,11 +45,19 @@ class Partitioner:
             order = np.argsort(arr, kind="stable")
             sorted_labels = arr[order]
             starts = np.flatnonzero(np.r_[True, sorted_labels[1:] != sorted_labels[:-1]])
-            ends = np.r_[starts[1:], arr.size]
             first_pos = order[starts]
-            out: dict = {}
-            for g in np.argsort(first_pos, kind="stable"):
-                out[arr[first_pos[g]]] = order[starts[g] : ends[g]].astype(int, copy=False)
+            by_first = np.argsort(first_pos, kind="stable")
+            keys = arr[first_pos[by_first]]           # iterating yields the labels as NumPy scalars
+            P = starts.size
+            order = order.astype(int, copy=False)
+            if arr.size % P == 0 and (P == 1 or bool(np.all(np.diff(starts) == arr.size // P))):
+                # equal folds (arange(N) % P, leave-one-out): rows of one matrix, no Python slicing
+                vals = list(order.reshape(P, arr.size // P)[by_first])
+            else:
+                bounds = np.r_[starts, arr.size]
+                lo, hi = bounds[by_first].tolist(), bounds[by_first + 1].tolist()
+                vals = [order[a:b] for a, b in zip(lo, hi)]
+            out = dict(zip(keys, vals))
             self.folds_dict = out
             return
         buckets: dict = {}
