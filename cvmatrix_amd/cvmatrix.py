@@ -62,6 +62,7 @@ class FoldBatch:
         self.idx, self.offsets = idx, offsets
         self.host_offsets, self.nz_val, self.labels = host_offsets, nz_val, labels
         self._host_idx, self._n_rows, self._is_partition = host_idx, n_rows, None
+        self._sizes = None
 
     @property
     def is_partition(self) -> bool:
@@ -78,7 +79,9 @@ class FoldBatch:
 
     @property
     def sizes(self) -> np.ndarray:
-        return np.diff(self.host_offsets)
+        if self._sizes is None:
+            self._sizes = np.diff(self.host_offsets)
+        return self._sizes
 
 
 class CVMatrix:
