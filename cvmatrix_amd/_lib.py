@@ -18,6 +18,7 @@ CVM_OK, CVM_EINVAL, CVM_EWORKSPACE, CVM_ELAUNCH = 0, 1, 2, 3
 CVM_F32, CVM_F64 = 0, 1
 RET_XTX, RET_XTY = 0x01, 0x02
 CENTER_X, CENTER_Y, SCALE_X, SCALE_Y = 0x04, 0x08, 0x10, 0x20
+IDX_HOST = 0x40
 
 EXPORTS = (
     "cvm_version", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",

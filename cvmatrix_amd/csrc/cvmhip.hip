@@ -97,6 +97,9 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
   if ((flags & CVM_RET_XTY) && (M == 0 || !H))
     return fail(CVM_EINVAL, "cvm_fold_update: CVM_RET_XTY needs Y and H%s");
   if (n_folds == 0) return CVM_OK;
+  if ((flags & CVM_IDX_HOST) && (n_folds != 1 || host_offsets[1] - host_offsets[0] > SMALL_ROWS ||
+                                host_offsets[1] < host_offsets[0]))
+    return fail(CVM_EINVAL, "cvm_fold_update: CVM_IDX_HOST takes one fold of at most 32 rows%s");
   if (dtype == CVM_F64)
     return fold_update_impl<double>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype,
                                     flags, ddof, resolution, G, H, gstats, out_XTX, out_XTY, out_muX,

@@ -219,6 +219,12 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
   a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY;
   a.out_fold = out_fold; a.ddof = ddof; a.resolution = resolution; a.flags = flags;
   a.P64 = (K + ST - 1) / ST; a.nT64 = a.P64 * (a.P64 + 1) / 2;
+  a.inl_n = -1;
+  if (flags & CVM_IDX_HOST) {            // one fold, indices on the host: into the kernel arguments
+    a.inl_n = (int)(offsets[1] - offsets[0]);
+    for (int i = 0; i < a.inl_n; ++i) a.inl[i] = idx[offsets[0] + i];
+    a.idx = nullptr; a.offs = nullptr;
+  }
   for (int64_t f0 = 0; f0 < n_folds; f0 += nb_max) {
     const int64_t nb = (n_folds - f0 < nb_max) ? n_folds - f0 : nb_max;
     a.seg0 = f0;

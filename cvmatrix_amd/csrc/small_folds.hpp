@@ -30,18 +30,23 @@ struct SmallArgs {
   double ddof, resolution;
   unsigned flags;
   int P64, nT64;
+  // one small fold whose indices came from the host (CVM_IDX_HOST): they travel in the kernel
+  // arguments, no device copy of the index array is needed; inl_n < 0: idx / offs are used
+  int inl_n;
+  int64_t inl[SMALL_ROWS];
 };
 
 template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_stats_kernel(const SmallArgs a) {
   const int f = blockIdx.x;
   const int K = a.K, M = a.M;
-  const int64_t o0 = a.offs[a.seg0 + f];
-  const int n = (int)(a.offs[a.seg0 + f + 1] - o0);
+  const bool inl = a.inl_n >= 0;
+  const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
+  const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
   const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
   __shared__ int64_t rows[SMALL_ROWS];
   __shared__ double wl[SMALL_ROWS];
   if (threadIdx.x < n) {
-    const int64_t r = a.idx[o0 + threadIdx.x];
+    const int64_t r = inl ? a.inl[threadIdx.x] : a.idx[o0 + threadIdx.x];
     rows[threadIdx.x] = r;
     wl[threadIdx.x] = WEIGHTED ? (double)W[r] : 1.0;
   }
@@ -105,8 +110,9 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const int x = blockIdx.x;
   const int K = a.K, M = a.M;
   const int tid = threadIdx.x;
-  const int64_t o0 = a.offs[a.seg0 + f];
-  const int n = (int)(a.offs[a.seg0 + f + 1] - o0);
+  const bool inl = a.inl_n >= 0;
+  const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
+  const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
   const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
   const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
   const double swt = fs[2 * K + 2 * M];
@@ -126,7 +132,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   __shared__ int64_t rows[SMALL_ROWS];
   __shared__ double wl[SMALL_ROWS];
   if (tid < n) {
-    const int64_t r = a.idx[o0 + tid];
+    const int64_t r = inl ? a.inl[tid] : a.idx[o0 + tid];
     rows[tid] = r;
     wl[tid] = WEIGHTED ? (double)W[r] : 1.0;
   }

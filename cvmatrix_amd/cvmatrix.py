@@ -58,11 +58,37 @@ class FoldBatch:
     Built by ``CVMatrix.prepare_folds``; reusable across ``*_batched`` calls.
     """
 
-    def __init__(self, idx, offsets, host_offsets, nz_val, labels=None, host_idx=None, n_rows=0):
-        self.idx, self.offsets = idx, offsets
+    def __init__(self, idx, offsets, host_offsets, nz_val, labels=None, host_idx=None, n_rows=0,
+                 device=None):
+        self._idx, self._offsets = idx, offsets
         self.host_offsets, self.nz_val, self.labels = host_offsets, nz_val, labels
         self._host_idx, self._n_rows, self._is_partition = host_idx, n_rows, None
         self._sizes = None
+        self._device = device
+
+    # one fold of at most 32 rows is created without device arrays: the matrix calls hand its
+    # indices to the library from the host (CVM_IDX_HOST); anything else uploads them on demand
+    @property
+    def inline(self) -> bool:
+        return self._idx is None
+
+    def _upload(self) -> None:
+        with torch.cuda.device(self._device):
+            d_all = torch.from_numpy(np.concatenate([self.host_offsets, self._host_idx])).to(self._device)
+        n_off = self.host_offsets.size
+        self._offsets, self._idx = d_all[:n_off], d_all[n_off:]
+
+    @property
+    def idx(self):
+        if self._idx is None:
+            self._upload()
+        return self._idx
+
+    @property
+    def offsets(self):
+        if self._offsets is None:
+            self._upload()
+        return self._offsets
 
     @property
     def is_partition(self) -> bool:
@@ -530,6 +556,10 @@ class CVMatrix:
         if sizes.size and int(sizes.max()) <= 32:
             # tiny folds (leave-one-out style calls): the device work per call is shorter than
             # the host's; the plain copy costs the host less than staging does
+            if len(parts) == 1:
+                # the reference's call pattern, one small fold per call: no device copy at all
+                return FoldBatch(None, None, host_offsets, nz_val, labels,
+                                 np.ascontiguousarray(idx, dtype=np.int64), self.N, device=self.device)
             with torch.cuda.device(self.device):
                 d_all = torch.from_numpy(np.concatenate([host_offsets, idx])).to(self.device)
             return FoldBatch(d_all[n_off:], d_all[:n_off], host_offsets, nz_val, labels, idx, self.N)
@@ -674,9 +704,14 @@ class CVMatrix:
                                                 int(sizes.max()) if P else 0, K, M,
                                                 self._cdt, flags)
             ws = self._workspace(want)
+            if batch.inline and mats and (rXTX or rXTY):
+                flags |= _lib.IDX_HOST
+                p_idx, p_off = batch._host_idx.ctypes.data, batch.host_offsets.ctypes.data
+            else:
+                p_idx, p_off = batch.idx.data_ptr(), batch.offsets.data_ptr()
             rc = lib.cvm_fold_update(
                 self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights),
-                batch.idx.data_ptr(), batch.offsets.data_ptr(),
+                p_idx, p_off,
                 batch.host_offsets.ctypes.data, P, self.N, K, M, self._cdt, flags,
                 float(self.ddof), float(self.resolution), self.XTX.data_ptr(),
                 _lib.ptr(self.XTY), self._gstats.data_ptr(), _lib.ptr(out_XTX),

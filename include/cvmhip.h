@@ -51,6 +51,11 @@ extern "C" {
 #define CVM_CENTER_Y 0x08u
 #define CVM_SCALE_X 0x10u
 #define CVM_SCALE_Y 0x20u
+/* cvm_fold_update only: `idx` and `offsets` are HOST pointers.  For one fold of at most 32 rows
+ * (the reference's call pattern in leave-one-out: one training_XTX_XTY(validation_indices) per
+ * sample, cvmatrix.py:451-517): the indices travel inside the kernel arguments and no device
+ * copy of the index array is made. */
+#define CVM_IDX_HOST 0x40u
 
 const char *cvm_version(void);
 const char *cvm_last_error(void);

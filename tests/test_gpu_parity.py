@@ -1053,3 +1053,44 @@ def test_lazy_fit_raises_on_negative_device_weights_in_fit(amd):
     for lazy in (True, False):
         with pytest.raises(ValueError, match="Weights must be non-negative."):
             amd.CVMatrix(lazy_fit=lazy).fit(X, None, w)
+
+
+def test_one_small_fold_per_call_sends_indices_with_the_launch(amd):
+    """The reference's call pattern with tiny folds (leave-one-out): the indices of the single fold
+    travel in the kernel arguments (CVM_IDX_HOST), no device index array is made; same bits as the
+    same fold inside a batch that uploads its indices."""
+    import ctypes as C
+
+    import torch
+    from cvmatrix_amd import _lib
+    rng = np.random.default_rng(31)
+    N, K, M = 400, 70, 3
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    m = amd.CVMatrix(lazy_fit=False)
+    m.fit(X, Y, w)
+    for v in (np.array([7]), np.array([3, 3, -1, 250]), np.arange(100, 132)):
+        b1 = m.prepare_folds([v])
+        assert b1.inline
+        (a, b), sa = m.training_XTX_XTY_batched(b1)
+        assert b1.inline                                   # still no device copy
+        b2 = m.prepare_folds([v, np.array([0, 1])])
+        assert not b2.inline
+        (c, d), sc = m.training_XTX_XTY_batched(b2)
+        assert torch.equal(a[0], c[0]) and torch.equal(b[0], d[0])
+        for s, t in zip(sa, sc):
+            assert torch.equal(s[0], t[0])
+        st = m.training_statistics_batched(b1)             # statistics-only: uploads on demand
+        assert not b1.inline and torch.equal(st[0][0], sc[0][0])
+    # the flag is refused for anything but one small fold
+    lib = _lib.load()
+    off = np.array([0, 1, 2], dtype=np.int64)
+    idx = np.array([1, 2], dtype=np.int64)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    out = torch.empty((2, K, K), dtype=torch.float64, device="cuda")
+    st4 = torch.empty((2, 4), dtype=torch.float64, device="cuda")
+    mu = torch.empty((2, K), dtype=torch.float64, device="cuda")
+    rc = lib.cvm_fold_update(m.X.data_ptr(), 0, 0, idx.ctypes.data, off.ctypes.data, off.ctypes.data, 2, N, K, 0,
+                             _lib.CVM_F64, _lib.RET_XTX | _lib.IDX_HOST, 1.0, 1e-14, m.XTX.data_ptr(), 0,
+                             m._gstats.data_ptr(), out.data_ptr(), 0, mu.data_ptr(), mu.data_ptr(), 0, 0,
+                             st4.data_ptr(), ws.data_ptr(), ws.numel(), 0)
+    assert rc == _lib.CVM_EINVAL and b"CVM_IDX_HOST" in lib.cvm_last_error()
