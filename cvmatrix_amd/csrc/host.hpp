@@ -202,7 +202,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 
 template <typename T>
 int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
-                    int64_t n_folds, int K, int M, unsigned flags, double ddof, double resolution,
+                    int64_t n_folds, int64_t max_rows, int K, int M, unsigned flags, double ddof, double resolution,
                     const void *G, const void *H, const double *gstats, void *out_XTX, void *out_XTY,
                     void *out_muX, void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
                     void *ws, size_t ws_bytes, hipStream_t st) {
@@ -210,6 +210,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
   int64_t nb_max = (int64_t)(ws_bytes / per_fold);
   if (nb_max < 1) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
   if (nb_max > 32768) nb_max = 32768;   // grid.y
+  static const bool no_direct = getenv("CVM_NO_DIRECT") != nullptr;   // tests: force the transposing kernel
   SmallArgs a;
   memset(&a, 0, sizeof(a));
   a.X = X; a.Y = Y; a.w = w; a.idx = idx; a.offs = offsets; a.K = K; a.M = M;
@@ -228,13 +229,37 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
   for (int64_t f0 = 0; f0 < n_folds; f0 += nb_max) {
     const int64_t nb = (n_folds - f0 < nb_max) ? n_folds - f0 : nb_max;
     a.seg0 = f0;
-    const dim3 gs((unsigned)nb), ga((unsigned)(a.nT64 + a.P64), (unsigned)nb);
-    if (w) {
-      hipLaunchKernelGGL((small_stats_kernel<T, true>), gs, dim3(256), 0, st, a);
-      if (a.out_XTX || a.out_XTY) hipLaunchKernelGGL((small_apply_kernel<T, true>), ga, dim3(256), 0, st, a);
-    } else {
-      hipLaunchKernelGGL((small_stats_kernel<T, false>), gs, dim3(256), 0, st, a);
-      if (a.out_XTX || a.out_XTY) hipLaunchKernelGGL((small_apply_kernel<T, false>), ga, dim3(256), 0, st, a);
+    // folds per workgroup of the apply kernel: as many as leave >= 16 workgroups per CU in the launch
+    const int64_t wg1 = (int64_t)(a.nT64 + a.P64) * nb;
+    int fpb = (int)(wg1 / (16 * 256));
+    if (fpb < 1) fpb = 1;
+    if (fpb > 8) fpb = 8;
+    a.nb = (int)nb; a.fpb = fpb;
+    const dim3 gs((unsigned)nb), ga((unsigned)(a.nT64 + a.P64), (unsigned)((nb + fpb - 1) / fpb));
+    // one- and two-row folds (leave-one-out) of a matrix whose rows are not whole 128-byte lines and
+    // fit one column chunk: whole rows of the full output, nothing transposed (small_rows_kernel;
+    // measured +23 % at the reference's published leave-one-out shape K = 500, slower elsewhere)
+    const int tc = 256 * (16 / (int)sizeof(T));
+    const bool direct = !no_direct && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
+                        ((size_t)K * sizeof(T)) % 16 == 0 && ((size_t)K * sizeof(T)) % 128 != 0 &&
+                        ((uintptr_t)G % 16 == 0) && ((uintptr_t)X % 16 == 0) &&
+                        (!a.out_XTX || (uintptr_t)a.out_XTX % 16 == 0);
+    if (w) hipLaunchKernelGGL((small_stats_kernel<T, true>), gs, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((small_stats_kernel<T, false>), gs, dim3(256), 0, st, a);
+    if (a.out_XTX || a.out_XTY) {
+      if (direct) {
+        const int panels = ((K + SR_ROWS - 1) / SR_ROWS) * ((K + tc - 1) / tc);
+        int fpr = (int)((int64_t)panels * nb / (16 * 256));
+        if (fpr < 1) fpr = 1;
+        if (fpr > 8) fpr = 8;
+        a.fpb = fpr;
+        const dim3 gd((unsigned)panels, (unsigned)((nb + fpr - 1) / fpr));
+        if (w) hipLaunchKernelGGL((small_rows_kernel<T, true>), gd, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((small_rows_kernel<T, false>), gd, dim3(256), 0, st, a);
+      } else {
+        if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), ga, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((small_apply_kernel<T, false>), ga, dim3(256), 0, st, a);
+      }
     }
     HIP_OK(hipGetLastError());
   }
@@ -305,7 +330,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     if (n > max_rows) max_rows = n;
   }
   if (max_rows <= SMALL_ROWS)
-    return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, K, M, flags, ddof, resolution, G, H, gstats,
+    return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
   const bool want_xtx = (flags & CVM_RET_XTX) && out_XTX, want_xty = (flags & CVM_RET_XTY) && out_XTY;
   if (!want_xtx && !want_xty)   // statistics only: stream the rows once, no Gram launch

@@ -34,6 +34,7 @@ struct SmallArgs {
   // arguments, no device copy of the index array is needed; inl_n < 0: idx / offs are used
   int inl_n;
   int64_t inl[SMALL_ROWS];
+  int nb, fpb;                         // folds of this launch, folds per workgroup of small_apply_kernel
 };
 
 template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_stats_kernel(const SmallArgs a) {
@@ -106,19 +107,13 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
 }
 
 template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_apply_kernel(const SmallArgs a) {
-  const int f = blockIdx.y;
   const int x = blockIdx.x;
   const int K = a.K, M = a.M;
   const int tid = threadIdx.x;
-  const bool inl = a.inl_n >= 0;
-  const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
-  const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
   const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
-  const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-  const double swt = fs[2 * K + 2 * M];
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
-  const size_t fo = (size_t)(a.seg0 + f);
+  const bool inl = a.inl_n >= 0;
   // As: w * x, columns of the tile's rows; Bs: x (or y), columns of the tile's columns;
   // Ts: the finished tile for the transposed store -- it reuses the As/Bs space (33 KB per
   // workgroup instead of 66: four workgroups per CU keep more loads and stores in flight)
@@ -131,83 +126,242 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm);
   __shared__ int64_t rows[SMALL_ROWS];
   __shared__ double wl[SMALL_ROWS];
-  if (tid < n) {
-    const int64_t r = inl ? a.inl[tid] : a.idx[o0 + tid];
-    rows[tid] = r;
-    wl[tid] = WEIGHTED ? (double)W[r] : 1.0;
-  }
-  __syncthreads();
-  if (x < a.nT64) {
-    if (!a.out_XTX) return;
-    int ti, tj;
-    decode_tile(x, a.P64, ti, tj);
-    const int a0 = ti * ST, b0 = tj * ST;
-    // the tile of G first: its latency overlaps the staging of the rows and the update
-    constexpr int NQG = ST * (ST / (16 / (int)sizeof(T))) / 256;
-    T gpre[NQG][16 / sizeof(T)];
-    T *out = (T *)a.out_XTX + fo * (size_t)K * K;
-    finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, out, tid, 256);
-    const int ty = tid >> 4, tx = tid & 15;      // rows 4ty.., columns 4tx..
-    for (int e = tid; e < n * ST; e += 256) {
-      const int r = e / ST, c = e - r * ST;
-      const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
-      const T xb = (b0 + c < K) ? X[rows[r] * (int64_t)K + b0 + c] : (T)0;
-      As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
-      Bs[r][c] = (TS)xb;
+  const bool xtx_part = x < a.nT64;
+  if (xtx_part ? !a.out_XTX : (!a.out_XTY || M == 0)) return;
+  // a workgroup takes its tile for `fpb` consecutive folds: the tile of G (the same for every
+  // fold) is fetched once and stays in registers, and the fixed latencies of a workgroup are
+  // paid once per group of folds -- with leave-one-out style batches the kernel is otherwise
+  // bound by them, not by the bytes it writes
+  int ti = 0, tj = 0;
+  if (xtx_part) decode_tile(x, a.P64, ti, tj);
+  const int a0 = (xtx_part ? ti : x - a.nT64) * ST, b0 = tj * ST;
+  constexpr int NQG = ST * (ST / (16 / (int)sizeof(T))) / 256;
+  T gpre[NQG][16 / sizeof(T)];
+  if (xtx_part)
+    finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, (const T *)a.out_XTX, tid, 256);
+  for (int ff = 0; ff < a.fpb; ++ff) {
+    const int f = blockIdx.y * a.fpb + ff;
+    if (f >= a.nb) break;
+    const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
+    const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
+    const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+    const double swt = fs[2 * K + 2 * M];
+    const size_t fo = (size_t)(a.seg0 + f);
+    if (ff) __syncthreads();                   // the previous fold is done with rows / wl / sm
+    if (tid < n) {
+      const int64_t r = inl ? a.inl[tid] : a.idx[o0 + tid];
+      rows[tid] = r;
+      wl[tid] = WEIGHTED ? (double)W[r] : 1.0;
     }
     __syncthreads();
-    TS acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = 0;
-    for (int r = 0; r < n; ++r) {
-      TS av[4], bv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { av[i] = As[r][4 * ty + i]; bv[i] = Bs[r][4 * tx + i]; }
+    if (xtx_part) {
+      T *out = (T *)a.out_XTX + fo * (size_t)K * K;
+      const int ty = tid >> 4, tx = tid & 15;      // rows 4ty.., columns 4tx..
+      for (int e = tid; e < n * ST; e += 256) {
+        const int r = e / ST, c = e - r * ST;
+        const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
+        const T xb = (b0 + c < K) ? X[rows[r] * (int64_t)K + b0 + c] : (T)0;
+        As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
+        Bs[r][c] = (TS)xb;
+      }
+      __syncthreads();
+      TS acc[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
-    }
-    __syncthreads();   // every thread is done with As/Bs: Ts may overwrite them
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+      for (int r = 0; r < n; ++r) {
+        TS av[4], bv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) { av[i] = As[r][4 * ty + i]; bv[i] = Bs[r][4 * tx + i]; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
-    __syncthreads();
-    finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256, gpre);
-  } else {
-    if (!a.out_XTY || M == 0) return;
-    const int ti = x - a.nT64;
-    const int a0 = ti * ST;
-    const T *Ht = (const T *)a.H;
-    T *out = (T *)a.out_XTY + fo * (size_t)K * M;
-    for (int e = tid; e < n * ST; e += 256) {
-      const int r = e / ST, c = e - r * ST;
-      const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
-      As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
-    }
-    for (int m0 = 0; m0 < M; m0 += ST) {
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+      }
+      __syncthreads();   // every thread is done with As/Bs: Ts may overwrite them
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
       __syncthreads();
+      finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256, gpre);
+    } else {
+      const T *Ht = (const T *)a.H;
+      T *out = (T *)a.out_XTY + fo * (size_t)K * M;
       for (int e = tid; e < n * ST; e += 256) {
         const int r = e / ST, c = e - r * ST;
-        Bs[r][c] = (m0 + c < M) ? (TS)Y[rows[r] * (int64_t)M + m0 + c] : (TS)0;
+        const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
+        As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
       }
-      __syncthreads();
-      const int mw = (M - m0 < ST) ? M - m0 : ST;
-      for (int e = tid; e < ST * mw; e += 256) {
-        const int la = e / mw, lm = e - la * mw;
-        const int ga = a0 + la, gm = m0 + lm;
+      for (int m0 = 0; m0 < M; m0 += ST) {
+        __syncthreads();
+        for (int e = tid; e < n * ST; e += 256) {
+          const int r = e / ST, c = e - r * ST;
+          Bs[r][c] = (m0 + c < M) ? (TS)Y[rows[r] * (int64_t)M + m0 + c] : (TS)0;
+        }
+        __syncthreads();
+        const int mw = (M - m0 < ST) ? M - m0 : ST;
+        for (int e = tid; e < ST * mw; e += 256) {
+          const int la = e / mw, lm = e - la * mw;
+          const int ga = a0 + la, gm = m0 + lm;
+          if (ga >= K) continue;
+          TS acc = 0;
+          for (int r = 0; r < n; ++r) acc += As[r][la] * Bs[r][lm];
+          double v = (double)Ht[(size_t)ga * M + gm] - (double)acc;
+          if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + gm]);
+          if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + gm]);
+          else if (sX) v = v / fs[K + ga];
+          else if (sY) v = v / fs[2 * K + M + gm];
+          out[(size_t)ga * M + gm] = (T)v;
+        }
+      }
+    }
+  }
+}
+
+
+// The same fold update as full ROWS of the output, nothing transposed: a workgroup owns 8 rows x
+// (256 x 16 bytes) columns of the K x K result (all columns when K <= 512 in float64), a thread
+// one 16-byte column piece of each of the 8 rows.  The update of element (a, b) is
+// sum_i w_i * (x_ia * x_ib) -- the product of the two x commutes, so both triangles come out
+// bit-identical without mirroring -- and every store is part of a contiguous run of whole rows:
+// a 64x64 tile of a matrix whose rows are not multiples of 128 bytes (K = 500) is written in
+// partial cache lines, which the memory system sustains at 2.8 TB/s; whole rows at 5.5 TB/s
+// (tools/write_pattern.hip).  G is read for both triangles, so this kernel is for matrices that
+// stay in L2 / MALL across the folds of a batch.  One barrier per fold; the column data (x of the
+// validation rows, means, stds) goes straight from global memory to registers.
+constexpr int SR_ROWS = 8;
+template <typename T, bool WEIGHTED>
+__global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
+  const int K = a.K, M = a.M;
+  const int tid = threadIdx.x;
+  const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const bool inl = a.inl_n >= 0;
+  typedef typename std::conditional<sizeof(T) == 8, double, float>::type TS;
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int TC = 256 * VW;
+  typedef T vec_t __attribute__((ext_vector_type(VW)));
+  typedef double dvec_t __attribute__((ext_vector_type(VW)));
+  __shared__ TS xr[SMALL_ROWS][SR_ROWS];           // x of the validation rows at the panel's 8 rows
+  __shared__ TS wxr[SMALL_ROWS][SR_ROWS];          // w * x there (rounded like the reference's WX)
+  __shared__ double wl[SMALL_ROWS];
+  __shared__ double str[2][SR_ROWS];               // mean, std of the panel's rows
+  const int ncc = (K + TC - 1) / TC;               // column chunks
+  const int rp = blockIdx.x / ncc, cc = blockIdx.x - rp * ncc;
+  const int a0 = rp * SR_ROWS, b0 = cc * TC;
+  const int gc = b0 + tid * VW;                    // K % VW == 0: a piece is inside or outside
+  const bool col_ok = gc < K;
+  const T *Gt = (const T *)a.G;
+  T gpre[SR_ROWS][VW];
+  if (a.out_XTX && col_ok) {
+#pragma unroll
+    for (int i = 0; i < SR_ROWS; ++i)
+      if (a0 + i < K) {
+        const vec_t t = *reinterpret_cast<const vec_t *>(Gt + (size_t)(a0 + i) * K + gc);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) gpre[i][e] = t[e];
+      }
+  }
+  for (int ff = 0; ff < a.fpb; ++ff) {
+    const int f = blockIdx.y * a.fpb + ff;
+    if (f >= a.nb) break;
+    const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
+    const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
+    const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+    const double swt = fs[2 * K + 2 * M];
+    const size_t fo = (size_t)(a.seg0 + f);
+    if (ff) __syncthreads();                       // the previous fold is done with the LDS
+    if (tid < n * SR_ROWS) {
+      const int r = tid / SR_ROWS, i = tid - r * SR_ROWS;
+      const int64_t ridx = inl ? a.inl[r] : a.idx[o0 + r];
+      const T wv = WEIGHTED ? W[ridx] : (T)1;
+      const T xv = (a0 + i < K) ? X[ridx * (int64_t)K + a0 + i] : (T)0;
+      xr[r][i] = (TS)xv;
+      wxr[r][i] = (TS)(WEIGHTED ? (T)(wv * xv) : xv);
+      if (i == 0) wl[r] = (double)wv;
+    }
+    if (tid < 2 * SR_ROWS) {
+      const int which = tid / SR_ROWS, i = tid - which * SR_ROWS;
+      double v = which ? 1.0 : 0.0;
+      if (a0 + i < K) {
+        if (!which && cX) v = fs[a0 + i];
+        if (which && sX) v = fs[K + a0 + i];
+      }
+      str[which][i] = v;
+    }
+    // column data of this thread, straight to registers
+    dvec_t muc, sdc;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { muc[e] = 0.0; sdc[e] = 1.0; }
+    if (a.out_XTX && col_ok) {
+      if (cX) muc = *reinterpret_cast<const dvec_t *>(fs + gc);
+      if (sX) sdc = *reinterpret_cast<const dvec_t *>(fs + K + gc);
+    }
+    TS acc[SR_ROWS][VW];
+#pragma unroll
+    for (int i = 0; i < SR_ROWS; ++i)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) acc[i][e] = 0;
+    __syncthreads();
+    if (a.out_XTX && col_ok) {
+      for (int r0 = 0; r0 < n; r0 += 8) {
+        vec_t xc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (r0 + u < n) {
+            const int64_t ridx = inl ? a.inl[r0 + u] : a.idx[o0 + r0 + u];
+            xc[u] = *reinterpret_cast<const vec_t *>(X + ridx * (int64_t)K + gc);
+          }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (r0 + u < n) {
+            const TS wr = (TS)(T)wl[r0 + u];
+#pragma unroll
+            for (int i = 0; i < SR_ROWS; ++i) {
+              const TS rv = xr[r0 + u][i];
+#pragma unroll
+              for (int e = 0; e < VW; ++e) acc[i][e] += WEIGHTED ? wr * (rv * (TS)xc[u][e]) : rv * (TS)xc[u][e];
+            }
+          }
+      }
+      T *out = (T *)a.out_XTX + fo * (size_t)K * K;
+#pragma unroll
+      for (int i = 0; i < SR_ROWS; ++i) {
+        if (a0 + i >= K) continue;
+        const double mur = str[0][i], sdr = str[1][i];
+        vec_t vv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          double v = (double)gpre[i][e] - (double)acc[i][e];
+          if (cX) v -= swt * (mur * muc[e]);
+          if (sX) v = v / (sdr * sdc[e]);
+          vv[e] = (T)v;
+        }
+        *reinterpret_cast<vec_t *>(out + (size_t)(a0 + i) * K + gc) = vv;
+      }
+    }
+    // the panel's rows of XTY (first column chunk only)
+    if (a.out_XTY && M > 0 && cc == 0) {
+      const T *Ht = (const T *)a.H;
+      T *out = (T *)a.out_XTY + fo * (size_t)K * M;
+      for (int e = tid; e < SR_ROWS * M; e += 256) {
+        const int i = e / M, m = e - i * M;
+        const int ga = a0 + i;
         if (ga >= K) continue;
-        TS acc = 0;
-        for (int r = 0; r < n; ++r) acc += As[r][la] * Bs[r][lm];
-        double v = (double)Ht[(size_t)ga * M + gm] - (double)acc;
-        if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + gm]);
-        if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + gm]);
+        TS s = 0;
+        for (int r = 0; r < n; ++r) {
+          const int64_t ridx = inl ? a.inl[r] : a.idx[o0 + r];
+          s += wxr[r][i] * (TS)Y[ridx * (int64_t)M + m];
+        }
+        double v = (double)Ht[(size_t)ga * M + m] - (double)s;
+        if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
+        if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + m]);
         else if (sX) v = v / fs[K + ga];
-        else if (sY) v = v / fs[2 * K + M + gm];
-        out[(size_t)ga * M + gm] = (T)v;
+        else if (sY) v = v / fs[2 * K + M + m];
+        out[(size_t)ga * M + m] = (T)v;
       }
     }
   }

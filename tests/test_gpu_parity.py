@@ -1094,3 +1094,30 @@ def test_one_small_fold_per_call_sends_indices_with_the_launch(amd):
                              m._gstats.data_ptr(), out.data_ptr(), 0, mu.data_ptr(), mu.data_ptr(), 0, 0,
                              st4.data_ptr(), ws.data_ptr(), ws.numel(), 0)
     assert rc == _lib.CVM_EINVAL and b"CVM_IDX_HOST" in lib.cvm_last_error()
+
+
+@pytest.mark.parametrize("dtype,K", [(np.float64, 300), (np.float64, 500), (np.float32, 600)])
+def test_leave_one_out_rows_kernel(amd, dtype, K):
+    """One- and two-row folds of a matrix whose rows are not whole cache lines go through
+    small_rows_kernel (whole output rows, both triangles computed): against the oracle, exactly
+    symmetric, same bits with and without XTY."""
+    rng = np.random.default_rng(K)
+    N, M = 1500, 3
+    X, Y = rng.random((N, K)).astype(dtype), rng.random((N, M)).astype(dtype)
+    w = rng.random(N).astype(dtype)
+    w[::11] = 0
+    folds = [np.array([i]) for i in range(40)] + [np.array([100 + 2 * i, 101 + 2 * i]) for i in range(20)]
+    tol = TOL if dtype is np.float64 else 3e-4
+    for flags, ww in (((True,) * 4, w), ((False,) * 4, None), ((True, False, True, False), w)):
+        m = amd.CVMatrix(*flags, dtype=dtype)
+        m.fit(X, Y, ww)
+        (bx, by), bst = m.training_XTX_XTY_batched(folds)
+        o = OracleCVMatrix(*flags, dtype=np.float64)
+        o.fit(X.astype(np.float64), Y.astype(np.float64), None if ww is None else ww.astype(np.float64))
+        for f in (0, 13, 39, 40, 59):
+            (rx, ry), rst = o.training_XTX_XTY(folds[f])
+            assert_normwise(bx[f].double(), rx, tol, f"fold{f} XTX")
+            assert_normwise(by[f].double(), ry, tol, f"fold{f} XTY")
+            assert bool((bx[f] == bx[f].T).all())
+        bx1 = m.training_XTX_batched(folds)[0]
+        assert bool((bx1 == bx).all())

@@ -34,6 +34,13 @@ if __name__ == "__main__":
     run("K=4096 M=1 fp32 n_v=16 (C5-hbm)", 20000, 4096, 1, 16, 48, np.float32)
     run("K=500 M=10 fp64 LOOCV", 100000, 500, 10, 1, 2000, np.float64)
     run("K=512 M=16 fp64 n_v=8", 100000, 512, 16, 8, 2000, np.float64)
+    if os.environ.get("SMALL_EXTRA"):
+        run("K=512 M=16 fp64 n_v=1", 100000, 512, 16, 1, 2000, np.float64)
+        run("K=500 M=10 fp64 n_v=8", 100000, 500, 10, 8, 2000, np.float64)
+        run("K=500 M=10 fp64 n_v=32", 100000, 500, 10, 32, 1000, np.float64)
+        run("K=200 M=5 fp64 n_v=1", 100000, 200, 5, 1, 8000, np.float64)
+        run("K=1000 M=4 fp64 n_v=4", 50000, 1000, 4, 4, 500, np.float64)
+        run("K=500 M=10 fp32 n_v=1", 100000, 500, 10, 1, 4000, np.float32)
 
 def write_ceiling():
     dev = torch.device("cuda")
