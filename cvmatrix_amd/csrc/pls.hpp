@@ -208,7 +208,8 @@ __device__ __forceinline__ void pls_power_mfma(pls_v4d (&m)[NB][NB], int lane) {
   }
 }
 
-// phase 1 and 2a of a component for M <= 16 NB
+// phase 1 of a component: the slice's part of XTY^T XTY (M <= 16 NB), summed over the waves in a
+// fixed order and handed to the other slices of the fold
 template <int NB, bool SLICED>
 __device__ __forceinline__ void pls_gram_phase(const double *Y, int yst, int n, int M, double *ms, double *x_S_slice,
                                                int tid) {

@@ -46,7 +46,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
   __shared__ int64_t rows[SMALL_ROWS];
   __shared__ double wl[SMALL_ROWS];
-  if (threadIdx.x < n) {
+  if ((int)threadIdx.x < n) {
     const int64_t r = inl ? a.inl[threadIdx.x] : a.idx[o0 + threadIdx.x];
     rows[threadIdx.x] = r;
     wl[threadIdx.x] = WEIGHTED ? (double)W[r] : 1.0;

@@ -63,7 +63,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   const int wr = wave >> 2, wc = wave & 3;
   const bool h_wave = diag && wr == 1 && wc < 2;
   const bool do_g = !g.diag_only && yc == 0;       // the G tile of this item is wanted
-  const bool mfma_wave = h_wave ? (g.M > 0 || yc == 0) : do_g;   // H waves also feed the X column sums
 
   int64_t seg_begin, seg_rows;
   if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }

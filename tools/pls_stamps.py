@@ -19,7 +19,7 @@ def run(F, K, M, A, dtype=torch.float64):
     pls_fit_batched(XTX, XTY, A)
     lib.cvm_debug_pls_stamps(buf, 1)
     a = np.array(list(buf), dtype=np.float64)
-    print(f"F={F} K={K} M={M} A={A} {pls_plan(F, K, M, A)}  total {a.sum()/A:.0f} cycles/component (100 MHz ticks? no: shader clock)")
+    print(f"F={F} K={K} M={M} A={A} {pls_plan(F, K, M, A)}  total {a.sum()/A:.0f} shader-clock cycles/component")
     for i, nm in enumerate(NAMES):
         print(f"   {nm:18s} {a[i]/ (1 if i == 0 else A):10.0f} cycles{'' if i == 0 else '/component'}")
 run(10, 512, 16, 20)
