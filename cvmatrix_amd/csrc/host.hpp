@@ -239,7 +239,9 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     // one- and two-row folds (leave-one-out) of a matrix whose rows are not whole 128-byte lines and
     // fit one column chunk: whole rows of the full output, nothing transposed (small_rows_kernel;
     // measured +23 % at the reference's published leave-one-out shape K = 500, slower elsewhere)
-    const int tc = 256 * (16 / (int)sizeof(T));
+    const int vw = 16 / (int)sizeof(T);
+    const int lpr = K <= 64 * vw ? 64 : (K <= 128 * vw ? 128 : 256);     // pieces per row of a workgroup
+    const int tc = lpr * vw;
     const bool direct = !no_direct && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
                         ((size_t)K * sizeof(T)) % 16 == 0 && ((size_t)K * sizeof(T)) % 128 != 0 &&
                         ((uintptr_t)G % 16 == 0) && ((uintptr_t)X % 16 == 0) &&
@@ -254,8 +256,15 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         if (fpr > 8) fpr = 8;
         a.fpb = fpr;
         const dim3 gd((unsigned)panels, (unsigned)((nb + fpr - 1) / fpr));
-        if (w) hipLaunchKernelGGL((small_rows_kernel<T, true>), gd, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((small_rows_kernel<T, false>), gd, dim3(256), 0, st, a);
+#define CVM_ROWS(L)                                                                          \
+  do {                                                                                       \
+    if (w) hipLaunchKernelGGL((small_rows_kernel<T, true, L>), gd, dim3(256), 0, st, a);     \
+    else hipLaunchKernelGGL((small_rows_kernel<T, false, L>), gd, dim3(256), 0, st, a);      \
+  } while (0)
+        if (lpr == 64) CVM_ROWS(64);
+        else if (lpr == 128) CVM_ROWS(128);
+        else CVM_ROWS(256);
+#undef CVM_ROWS
       } else {
         if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), ga, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((small_apply_kernel<T, false>), ga, dim3(256), 0, st, a);

@@ -232,7 +232,9 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
 // stay in L2 / MALL across the folds of a batch.  One barrier per fold; the column data (x of the
 // validation rows, means, stds) goes straight from global memory to registers.
 constexpr int SR_ROWS = 8;
-template <typename T, bool WEIGHTED>
+// LPR: 16-byte pieces per output row handled by a workgroup (64, 128 or 256: the smallest that
+// covers K keeps the threads busy); 256 / LPR rows go in one pass, SR_ROWS rows per workgroup.
+template <typename T, bool WEIGHTED, int LPR>
 __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   const int K = a.K, M = a.M;
   const int tid = threadIdx.x;
@@ -242,7 +244,9 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   const bool inl = a.inl_n >= 0;
   typedef typename std::conditional<sizeof(T) == 8, double, float>::type TS;
   constexpr int VW = 16 / (int)sizeof(T);
-  constexpr int TC = 256 * VW;
+  constexpr int TC = LPR * VW;
+  constexpr int RSTEP = 256 / LPR;                 // rows per pass
+  constexpr int NP = SR_ROWS / RSTEP;              // passes = pieces per thread
   typedef T vec_t __attribute__((ext_vector_type(VW)));
   typedef double dvec_t __attribute__((ext_vector_type(VW)));
   __shared__ TS xr[SMALL_ROWS][SR_ROWS];           // x of the validation rows at the panel's 8 rows
@@ -252,17 +256,18 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   const int ncc = (K + TC - 1) / TC;               // column chunks
   const int rp = blockIdx.x / ncc, cc = blockIdx.x - rp * ncc;
   const int a0 = rp * SR_ROWS, b0 = cc * TC;
-  const int gc = b0 + tid * VW;                    // K % VW == 0: a piece is inside or outside
+  const int rr = tid / LPR;                        // this thread's rows: rr + p * RSTEP
+  const int gc = b0 + (tid - rr * LPR) * VW;       // K % VW == 0: a piece is inside or outside
   const bool col_ok = gc < K;
   const T *Gt = (const T *)a.G;
-  T gpre[SR_ROWS][VW];
+  T gpre[NP][VW];
   if (a.out_XTX && col_ok) {
 #pragma unroll
-    for (int i = 0; i < SR_ROWS; ++i)
-      if (a0 + i < K) {
-        const vec_t t = *reinterpret_cast<const vec_t *>(Gt + (size_t)(a0 + i) * K + gc);
+    for (int p = 0; p < NP; ++p)
+      if (a0 + rr + p * RSTEP < K) {
+        const vec_t t = *reinterpret_cast<const vec_t *>(Gt + (size_t)(a0 + rr + p * RSTEP) * K + gc);
 #pragma unroll
-        for (int e = 0; e < VW; ++e) gpre[i][e] = t[e];
+        for (int e = 0; e < VW; ++e) gpre[p][e] = t[e];
       }
   }
   for (int ff = 0; ff < a.fpb; ++ff) {
@@ -300,11 +305,11 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
       if (cX) muc = *reinterpret_cast<const dvec_t *>(fs + gc);
       if (sX) sdc = *reinterpret_cast<const dvec_t *>(fs + K + gc);
     }
-    TS acc[SR_ROWS][VW];
+    TS acc[NP][VW];
 #pragma unroll
-    for (int i = 0; i < SR_ROWS; ++i)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int e = 0; e < VW; ++e) acc[i][e] = 0;
+      for (int e = 0; e < VW; ++e) acc[p][e] = 0;
     __syncthreads();
     if (a.out_XTX && col_ok) {
       for (int r0 = 0; r0 < n; r0 += 8) {
@@ -320,22 +325,23 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
           if (r0 + u < n) {
             const TS wr = (TS)(T)wl[r0 + u];
 #pragma unroll
-            for (int i = 0; i < SR_ROWS; ++i) {
-              const TS rv = xr[r0 + u][i];
+            for (int p = 0; p < NP; ++p) {
+              const TS rv = xr[r0 + u][rr + p * RSTEP];
 #pragma unroll
-              for (int e = 0; e < VW; ++e) acc[i][e] += WEIGHTED ? wr * (rv * (TS)xc[u][e]) : rv * (TS)xc[u][e];
+              for (int e = 0; e < VW; ++e) acc[p][e] += WEIGHTED ? wr * (rv * (TS)xc[u][e]) : rv * (TS)xc[u][e];
             }
           }
       }
       T *out = (T *)a.out_XTX + fo * (size_t)K * K;
 #pragma unroll
-      for (int i = 0; i < SR_ROWS; ++i) {
+      for (int p = 0; p < NP; ++p) {
+        const int i = rr + p * RSTEP;
         if (a0 + i >= K) continue;
         const double mur = str[0][i], sdr = str[1][i];
         vec_t vv;
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
-          double v = (double)gpre[i][e] - (double)acc[i][e];
+          double v = (double)gpre[p][e] - (double)acc[p][e];
           if (cX) v -= swt * (mur * muc[e]);
           if (sX) v = v / (sdr * sdc[e]);
           vv[e] = (T)v;

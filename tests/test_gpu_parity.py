@@ -1096,7 +1096,8 @@ def test_one_small_fold_per_call_sends_indices_with_the_launch(amd):
     assert rc == _lib.CVM_EINVAL and b"CVM_IDX_HOST" in lib.cvm_last_error()
 
 
-@pytest.mark.parametrize("dtype,K", [(np.float64, 300), (np.float64, 500), (np.float32, 600)])
+@pytest.mark.parametrize("dtype,K", [(np.float64, 300), (np.float64, 500), (np.float32, 600), (np.float64, 100),
+                                      (np.float64, 200), (np.float32, 500), (np.float32, 200)])
 def test_leave_one_out_rows_kernel(amd, dtype, K):
     """One- and two-row folds of a matrix whose rows are not whole cache lines go through
     small_rows_kernel (whole output rows, both triangles computed): against the oracle, exactly
