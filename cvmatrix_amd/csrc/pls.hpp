@@ -40,10 +40,27 @@ __host__ __device__ inline size_t pls_xch_len(int K, int M, int A, int S) {
   return (size_t)S * M * M + (size_t)S * (1 + A) + (size_t)K + (size_t)S * (1 + M);
 }
 
+// Sum over the 64 lanes, the same value in every lane.  Data-parallel-primitive moves inside the
+// VALU (row shifts inside 16-lane rows, then the row broadcasts 15 and 31 of the GFX9 family) instead
+// of ds_bpermute round trips through the LDS pipeline: about a third of the latency, and the PLS
+// kernel's small phases are chains of such reductions.  Lane 63 ends up with the total.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, false);
+  return v + __hiloint2double(hi, lo);      // lanes without a source add +0.0
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0x111, 0xF, 0xF>(v);          // row_shr:1
+  v = dpp_add<0x112, 0xF, 0xF>(v);          // row_shr:2
+  v = dpp_add<0x114, 0xF, 0xE>(v);          // row_shr:4, banks 1-3
+  v = dpp_add<0x118, 0xF, 0xC>(v);          // row_shr:8, banks 2-3: lane 15 of every row = row sum
+  v = dpp_add<0x142, 0xA, 0xF>(v);          // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC, 0xF>(v);          // row_bcast:31 into rows 2 and 3: lane 63 = total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // sum over the workgroup, same value (bitwise) in every thread
@@ -411,11 +428,19 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
     if (tid == 0) xput<SLICED>(&x_2[(size_t)s * (1 + c)], nrm2);
     for (int j0 = wave * 4; j0 < c; j0 += 4 * PLS_NW) {
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int k = lane; k < n; k += 64) {
-        const double wv = wl[k];
+      for (int k = lane; k < n; k += 256) {      // sixteen loads of P in flight per lane
+        double pv[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (j0 + q < c) acc[q] += Pp[(size_t)(j0 + q) * pst + k] * wv;
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            pv[u][q] = (k + 64 * u < n && j0 + q < c) ? Pp[(size_t)(j0 + q) * pst + k + 64 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double wv = (k + 64 * u < n) ? wl[k + 64 * u] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += pv[u][q] * wv;
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
