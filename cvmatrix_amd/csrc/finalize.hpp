@@ -35,10 +35,11 @@ inline int fold_stats_chunks(int K, int M, int64_t n_folds) {
 }
 
 // fit: gstats = ordered sum of the split partials
-template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *gstats) {
+template <typename T>
+__device__ __forceinline__ void fit_stats_columns(const FinArgs &a, double *gstats, int c0, int stride) {
   const Geom &g = a.g;
   const int total = 2 * g.K + 2 * g.M + 3;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
+  for (int c = c0; c < total; c += stride) {
     int src;
     if (c < g.K) src = c;
     else if (c < 2 * g.K) src = g.Kp + (c - g.K);
@@ -59,6 +60,9 @@ template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *
     if (c < total - 1) gstats[c] = s;
     else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
   }
+}
+template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *gstats) {
+  fit_stats_columns<T>(a, gstats, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // fold: training-set mean / std of every column; reference operation order
@@ -412,6 +416,7 @@ constexpr int FIT_RC = 4;
 constexpr int FIT_RH = ST / FIT_RC;
 constexpr int FIT_THREADS = 256;
 constexpr int FIT_PCH = 4;             // row chunks of a 128-row XTY panel
+constexpr int FIT_STAT_WGS = 8;        // workgroups that sum the column statistics (a.gstats: output)
 template <typename T>
 __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a) {
   const Geom &g = a.g;
@@ -510,6 +515,11 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
           if (gc + e < K && (!diag || gr > gc + e)) dst[e] = (T)Ts[rr + e][c];
       }
     }
+  } else if (x >= n_sub + g.P * FIT_PCH) {
+    // the column statistics ride in the same launch (FIT_STAT_WGS workgroups): one kernel less
+    // between the Gram kernel and the fold stage
+    const int b = x - (n_sub + g.P * FIT_PCH);
+    fit_stats_columns<T>(a, const_cast<double *>(a.gstats), b * FIT_THREADS + tid, FIT_STAT_WGS * FIT_THREADS);
   } else {
     if (!a.out_XTY || M == 0) return;
     const int x2 = x - n_sub;

@@ -163,14 +163,18 @@ bool rows_aligned(const void *X, int K, int esize) {
   return ((uintptr_t)X % 16 == 0) && (((size_t)K * esize) % 16 == 0);
 }
 
-// full-data matrices from the partials: the many-workgroup kernel when rows are 16-byte aligned
-template <typename T> void launch_fit_apply(const FinArgs &f, const Geom &g, hipStream_t st) {
+// full-data matrices and column statistics from the partials: one launch of the many-workgroup
+// kernel when rows are 16-byte aligned, else the statistics kernel and the general apply kernel
+template <typename T> void launch_fit_apply(FinArgs f, const Geom &g, double *gstats, hipStream_t st) {
   const bool aligned = ((size_t)g.K * sizeof(T)) % 16 == 0 && ((uintptr_t)f.out_XTX % 16 == 0);
-  if (aligned)
-    hipLaunchKernelGGL((fit_apply_kernel<T>), dim3(g.nTiles * APPLY_SUB * FIT_RC + g.P * FIT_PCH), dim3(FIT_THREADS), 0,
-                       st, f);
-  else
+  if (aligned) {
+    f.gstats = gstats;
+    hipLaunchKernelGGL((fit_apply_kernel<T>), dim3(g.nTiles * APPLY_SUB * FIT_RC + g.P * FIT_PCH + FIT_STAT_WGS),
+                       dim3(FIT_THREADS), 0, st, f);
+  } else {
+    hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
     hipLaunchKernelGGL((apply_kernel<T, false>), dim3(g.nTiles * APPLY_SUB + g.P, 1), dim3(APPLY_THREADS_FIT), 0, st, f);
+  }
 }
 
 template <typename T>
@@ -194,8 +198,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   memset(&f, 0, sizeof(f));
   f.g = p.g; f.splits = p.splits; f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
-  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
-  launch_fit_apply<T>(f, p.g, st);
+  launch_fit_apply<T>(f, p.g, gstats, st);
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
@@ -479,8 +482,7 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   f.g = p.g; f.splits = (int)(n_folds * p.splits);   // every unit of every fold, fold-major
   f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
-  hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
-  launch_fit_apply<T>(f, p.g, st);
+  launch_fit_apply<T>(f, p.g, gstats, st);
   HIP_OK(hipGetLastError());
   if (splits_out) *splits_out = p.splits;
   return CVM_OK;
