@@ -368,7 +368,9 @@ def main():
                              f"(oracle/cvmatrix_oracle.py) on the host, BLAS threads={thr}, "
                              f"host cores={os.cpu_count()}"}
         result = {
-            "metric": "folds/sec (training_XTX_XTY, center+scale) at N=1e5,K=512",
+            # BASELINE.json's metric string at its own workload (C3); other workloads say their shape
+            "metric": ("folds/sec (training_XTX_XTY, center+scale) at N=1e5,K=512" if args.workload == "C3"
+                       and not args.rows else f"folds/sec (training_XTX_XTY) at N={N},K={K} [{args.workload}]"),
             "value": round(value, 2), "unit": "folds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
