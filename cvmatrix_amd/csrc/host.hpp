@@ -245,7 +245,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     const int vw = 16 / (int)sizeof(T);
     const int lpr = K <= 64 * vw ? 64 : (K <= 128 * vw ? 128 : 256);     // pieces per row of a workgroup
     const int tc = lpr * vw;
-    const bool direct = !no_direct && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
+    const bool direct = !no_direct && sizeof(T) == 8 && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
                         ((size_t)K * sizeof(T)) % 16 == 0 && ((size_t)K * sizeof(T)) % 128 != 0 &&
                         ((uintptr_t)G % 16 == 0) && ((uintptr_t)X % 16 == 0) &&
                         (!a.out_XTX || (uintptr_t)a.out_XTX % 16 == 0);
@@ -258,7 +258,8 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         if (fpr < 1) fpr = 1;
         if (fpr > 8) fpr = 8;
         a.fpb = fpr;
-        const dim3 gd((unsigned)panels, (unsigned)((nb + fpr - 1) / fpr));
+        a.gx = panels; a.gy = (int)((nb + fpr - 1) / fpr);
+        const dim3 gd((unsigned)(8 * (((size_t)a.gx * a.gy + 7) / 8)));
 #define CVM_ROWS(L)                                                                          \
   do {                                                                                       \
     if (w) hipLaunchKernelGGL((small_rows_kernel<T, true, L>), gd, dim3(256), 0, st, a);     \
@@ -269,8 +270,10 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         else CVM_ROWS(256);
 #undef CVM_ROWS
       } else {
-        if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), ga, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((small_apply_kernel<T, false>), ga, dim3(256), 0, st, a);
+        a.gx = (int)ga.x; a.gy = (int)ga.y;
+        const dim3 g1((unsigned)(8 * (((size_t)ga.x * ga.y + 7) / 8)));
+        if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), g1, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((small_apply_kernel<T, false>), g1, dim3(256), 0, st, a);
       }
     }
     HIP_OK(hipGetLastError());

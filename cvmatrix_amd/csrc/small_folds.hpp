@@ -35,6 +35,7 @@ struct SmallArgs {
   int inl_n;
   int64_t inl[SMALL_ROWS];
   int nb, fpb;                         // folds of this launch, folds per workgroup of small_apply_kernel
+  int gx, gy;                          // small_apply_kernel: tiles + panels, fold groups
 };
 
 template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_stats_kernel(const SmallArgs a) {
@@ -107,7 +108,15 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
 }
 
 template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_apply_kernel(const SmallArgs a) {
-  const int x = blockIdx.x;
+  // Workgroups go to the 8 XCDs round-robin by their linear number; neighbouring tiles of one
+  // output matrix share cache lines when its rows are not whole lines, and only one L2 can merge
+  // the two halves before they go to HBM: give every XCD a contiguous range of (fold group, tile).
+  // (a 1-D launch of 8 * ceil(gx * gy / 8) workgroups; gx tiles and panels, gy fold groups)
+  const unsigned lin = blockIdx.x, tot = (unsigned)a.gx * (unsigned)a.gy;
+  const unsigned per = (tot + 7) / 8;
+  const unsigned item = (lin & 7) * per + (lin >> 3);
+  if (item >= tot) return;
+  const int x = (int)(item % (unsigned)a.gx), by = (int)(item / (unsigned)a.gx);
   const int K = a.K, M = a.M;
   const int tid = threadIdx.x;
   const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
@@ -140,7 +149,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   if (xtx_part)
     finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, (const T *)a.out_XTX, tid, 256);
   for (int ff = 0; ff < a.fpb; ++ff) {
-    const int f = blockIdx.y * a.fpb + ff;
+    const int f = by * a.fpb + ff;
     if (f >= a.nb) break;
     const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
     const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
@@ -253,8 +262,14 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   __shared__ TS wxr[SMALL_ROWS][SR_ROWS];          // w * x there (rounded like the reference's WX)
   __shared__ double wl[SMALL_ROWS];
   __shared__ double str[2][SR_ROWS];               // mean, std of the panel's rows
+  // XCD-contiguous ranges of (fold group, panel), as in small_apply_kernel
+  const unsigned lin = blockIdx.x, tot = (unsigned)a.gx * (unsigned)a.gy;
+  const unsigned per = (tot + 7) / 8;
+  const unsigned item = (lin & 7) * per + (lin >> 3);
+  if (item >= tot) return;
+  const int bx = (int)(item % (unsigned)a.gx), by = (int)(item / (unsigned)a.gx);
   const int ncc = (K + TC - 1) / TC;               // column chunks
-  const int rp = blockIdx.x / ncc, cc = blockIdx.x - rp * ncc;
+  const int rp = bx / ncc, cc = bx - rp * ncc;
   const int a0 = rp * SR_ROWS, b0 = cc * TC;
   const int rr = tid / LPR;                        // this thread's rows: rr + p * RSTEP
   const int gc = b0 + (tid - rr * LPR) * VW;       // K % VW == 0: a piece is inside or outside
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
       }
   }
   for (int ff = 0; ff < a.fpb; ++ff) {
-    const int f = blockIdx.y * a.fpb + ff;
+    const int f = by * a.fpb + ff;
     if (f >= a.nb) break;
     const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
     const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
