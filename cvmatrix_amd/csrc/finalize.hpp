@@ -22,6 +22,7 @@ struct FinArgs {
   double ddof, resolution;
   unsigned flags;
   int32_t *neg_flag;
+  int gx, gy;           // apply_kernel<.., true>: sub-tiles + panels, folds of the launch
 };
 __host__ __device__ inline size_t fstat_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 4; }
 
@@ -303,8 +304,22 @@ template <typename T, bool FOLD>
 __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void apply_kernel(const FinArgs a) {
   constexpr int NTHR = FOLD ? APPLY_THREADS : APPLY_THREADS_FIT;
   const Geom &g = a.g;
-  const int f = blockIdx.y;
-  const int x = blockIdx.x;
+  // fold mode: a 1-D launch of 8 * ceil(gx * gy / 8) workgroups; the 8 XCDs take workgroups
+  // round-robin, so workgroup `lin` works on item (lin % 8) * per + lin / 8: every XCD gets a
+  // contiguous range of (fold, sub-tile) -- neighbouring sub-tiles and the G tiles they read meet
+  // in one L2
+  int f, x;
+  if (FOLD) {
+    const unsigned lin = blockIdx.x, tot = (unsigned)a.gx * (unsigned)a.gy;
+    const unsigned per = (tot + 7) / 8;
+    const unsigned item = (lin & 7) * per + (lin >> 3);
+    if (item >= tot) return;
+    x = (int)(item % (unsigned)a.gx);
+    f = (int)(item / (unsigned)a.gx);
+  } else {
+    f = blockIdx.y;
+    x = blockIdx.x;
+  }
   const int K = g.K, M = g.M;
   const long u0 = (long)f * a.splits;
   const double *fs = FOLD ? a.fstats + (size_t)f * fstat_len(K, M) : nullptr;

@@ -439,7 +439,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     // fstats rows are fstat_len doubles apart inside the 256-byte aligned slots? keep dense
     hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)), dim3(256), 0, st, f);
     if (f.out_XTX || f.out_XTY) {
-      hipLaunchKernelGGL((apply_kernel<T, true>), dim3(p.g.nTiles * APPLY_SUB + p.g.P, (unsigned)nb),
+      f.gx = p.g.nTiles * APPLY_SUB + p.g.P; f.gy = (int)nb;
+      hipLaunchKernelGGL((apply_kernel<T, true>), dim3((unsigned)(8 * (((size_t)f.gx * f.gy + 7) / 8))),
                          dim3(APPLY_THREADS), 0, st, f);
     }
     HIP_OK(hipGetLastError());
@@ -512,9 +513,11 @@ int sweep_folds_impl(const int64_t *offsets, int64_t n_folds, int K, int M, int 
   f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
   f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
   hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)n_folds, (unsigned)fold_stats_chunks(K, M, n_folds)), dim3(256), 0, st, f);
-  if (f.out_XTX || f.out_XTY)
-    hipLaunchKernelGGL((apply_kernel<T, true>), dim3(g.nTiles * APPLY_SUB + g.P, (unsigned)n_folds),
+  if (f.out_XTX || f.out_XTY) {
+    f.gx = g.nTiles * APPLY_SUB + g.P; f.gy = (int)n_folds;
+    hipLaunchKernelGGL((apply_kernel<T, true>), dim3((unsigned)(8 * (((size_t)f.gx * f.gy + 7) / 8))),
                        dim3(APPLY_THREADS), 0, st, f);
+  }
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
