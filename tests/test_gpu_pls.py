@@ -229,3 +229,12 @@ def test_example_fast_cv_matches_refits(pls):
             pred = cross.PLSRegression(n_components=a + 1, scale=True).fit(X[tr], Y[tr]).predict(X[val])
             sse[a] += ((pred.reshape(-1) - Y[val].reshape(-1)) ** 2).sum()
     np.testing.assert_allclose(got[:, 0], np.sqrt(sse / N), rtol=1e-9)
+
+
+@pytest.mark.parametrize("K,M,A,F", [(3, 2, 3, 4), (1, 1, 1, 3), (5, 4, 5, 300), (7, 1, 7, 2), (2, 3, 2, 1)])
+def test_tiny_shapes(pls, K, M, A, F):
+    rng = np.random.default_rng(K * 10 + M)
+    XTX = np.stack([(lambda Z: Z.T @ Z)(rng.standard_normal((4 * K + 3, K))) for _ in range(F)])
+    XTY = np.stack([rng.standard_normal((K, M)) for _ in range(F)])
+    fit = pls.pls_fit_batched(torch.from_numpy(XTX).cuda(), torch.from_numpy(XTY).cuda(), A, return_factors=True)
+    check_against_oracle(fit, XTX, XTY, A, 1e-8)
