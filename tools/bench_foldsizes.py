@@ -12,7 +12,8 @@ X = torch.rand((N, K), dtype=torch.float64, device=dev, generator=g)
 Y = torch.rand((N, M), dtype=torch.float64, device=dev, generator=g)
 w = torch.rand((N,), dtype=torch.float64, device=dev, generator=g)
 m = CVMatrix(copy=False, lazy_fit=False); m.fit(X, Y, w)
-for P in (3, 5, 10, 30, 100, 300, 1000, 2000, 3000):
+PS = [int(p) for p in os.environ["FOLD_PS"].split(",")] if os.environ.get("FOLD_PS") else (3, 5, 10, 30, 100, 300, 1000, 2000, 3000)
+for P in PS:
     nv = N // P
     nf = min(P, max(1, int(8e9 // (K * (K + M) * 8))))      # cap the output at 8 GB
     folds = [np.arange(f, N, P)[:nv] for f in range(nf)]
