@@ -247,10 +247,12 @@ __device__ __forceinline__ void finish_tile_preload(T (&gpre)[NQ][16 / sizeof(T)
 // The same finishing step for ONE WAVE inside wgram4_kernel<.., FUSED> (float64, K even): the raw
 // update of a 64x64 block is in Ts, the row/column means and stds in rs[0..255].  A wave has no
 // other wave to hide its latency behind, so the G loads go out eight rows at a time.
+// Direct half: rows 2*it + (lane >> 5) for it in [it_lo, it_hi) of the 64-row block (it_hi - it_lo a
+// multiple of 8).  Finished values are parked in Ts for the mirrored store (off the diagonal).
 template <int TP>
-__device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const double *rs, bool diagb, int a0,
-                                                   int b0, int K, const double *Gt, double *out,
-                                                   double swt, bool cX, bool sX, int lane) {
+__device__ __forceinline__ void fused_finish_direct(double (*Ts)[TP], const double *rs, bool diagb, int a0,
+                                                    int b0, int K, const double *Gt, double *out,
+                                                    double swt, bool cX, bool sX, int lane, int it_lo, int it_hi) {
   typedef double v2 __attribute__((ext_vector_type(2)));
   const int half = lane >> 5, lc = 2 * (lane & 31);
   const int gc = b0 + lc;
@@ -258,7 +260,7 @@ __device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const doubl
   const double muc0 = rs[128 + lc], muc1 = rs[128 + lc + 1];
   const double sdc0 = rs[192 + lc], sdc1 = rs[192 + lc + 1];
 #pragma unroll 1
-  for (int it0 = 0; it0 < 32; it0 += 8) {
+  for (int it0 = it_lo; it0 < it_hi; it0 += 8) {
     v2 gv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -279,18 +281,31 @@ __device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const doubl
       if (!diagb) { Ts[lr][lc] = v0; Ts[lr][lc + 1] = v1; }   // parked for the mirrored store
     }
   }
-  if (diagb) return;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // mirrored block: rows b0.., columns a0..; out[b0 + r][a0 + c] = finished[c][r]
+}
+// Mirrored half: rows b0 + 2*it + (lane >> 5), columns a0..; out[b0 + r][a0 + c] = finished[c][r]
+template <int TP>
+__device__ __forceinline__ void fused_finish_mirror(double (*Ts)[TP], int a0, int b0, int K, double *out, int lane,
+                                                    int it_lo, int it_hi) {
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const int half = lane >> 5, lc = 2 * (lane & 31);
   const int gc2 = a0 + lc;
   if (gc2 >= K) return;
 #pragma unroll 4
-  for (int it = 0; it < 32; ++it) {
+  for (int it = it_lo; it < it_hi; ++it) {
     const int lr = 2 * it + half, gr = b0 + lr;
     if (gr >= K) continue;
     *reinterpret_cast<v2 *>(out + (size_t)gr * K + gc2) = (v2){Ts[lc][lr], Ts[lc + 1][lr]};
   }
+}
+template <int TP>
+__device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const double *rs, bool diagb, int a0,
+                                                   int b0, int K, const double *Gt, double *out,
+                                                   double swt, bool cX, bool sX, int lane) {
+  fused_finish_direct<TP>(Ts, rs, diagb, a0, b0, K, Gt, out, swt, cX, sX, lane, 0, 32);
+  if (diagb) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  fused_finish_mirror<TP>(Ts, a0, b0, K, out, lane, 0, 32);
 }
 
 // One 64x64 sub-tile of a 128x128 upper tile (or one 128 x M panel of H) of one segment:

@@ -44,6 +44,13 @@ template <int TP>
 __device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const double *rs, bool diagb, int a0,
                                                    int b0, int K, const double *Gt, double *out,
                                                    double swt, bool cX, bool sX, int lane);
+template <int TP>
+__device__ __forceinline__ void fused_finish_direct(double (*Ts)[TP], const double *rs, bool diagb, int a0,
+                                                    int b0, int K, const double *Gt, double *out,
+                                                    double swt, bool cX, bool sX, int lane, int it_lo, int it_hi);
+template <int TP>
+__device__ __forceinline__ void fused_finish_mirror(double (*Ts)[TP], int a0, int b0, int K, double *out, int lane,
+                                                    int it_lo, int it_hi);
 constexpr int WAVE_LDS_DOUBLES = 64 * 65 + 256;   // a wave's 64x64 block + row/column means and stds
 
 template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
@@ -258,6 +265,28 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing in flight at wave exit
     if (FUSEDR) __builtin_amdgcn_s_barrier();       // the compute waves reuse the ring in their epilogue
+    if constexpr (FUSEDR && sizeof(T) == 8) {
+      if (do_g && !diag) {
+        // off-diagonal tile of the fused route: help compute wave d with the second half of its
+        // 64x64 block (see the compute role's epilogue; same two barriers)
+        const int K = g.K, M = g.M;
+        const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
+        const double swt = fs[2 * K + 2 * M];
+        const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
+        const size_t fo = (size_t)(a.seg0 + seg);
+        const int a0 = ti * TILE + 64 * (d >> 1), b0 = tj * TILE + 64 * (d & 1);
+        const bool active = a.out_XTX && a0 < K && b0 < K;
+        double *slice = reinterpret_cast<double *>(smem) + (size_t)d * WAVE_LDS_DOUBLES;
+        double (*Ts)[65] = reinterpret_cast<double (*)[65]>(slice);
+        const double *rs = slice + 64 * 65;
+        double *outp = (double *)a.out_XTX + fo * (size_t)K * K;
+        __syncthreads();   // B_dump
+        if (active)
+          fused_finish_direct<65>(Ts, rs, false, a0, b0, K, (const double *)a.G, outp, swt, cX, sX, lane, 16, 32);
+        __syncthreads();   // B_parked
+        if (active) fused_finish_mirror<65>(Ts, a0, b0, K, outp, lane, 16, 32);
+      }
+    }
 #ifdef CVM_STAMPS
     if (lane == 0 && blockIdx.x < 1024) {
       unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave_all) * 4;
@@ -446,12 +475,18 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
               }
             }
       }
-    } else if (do_g && MFM && a.out_XTX) {
+    } else if (do_g && MFM) {
+      // off-diagonal tile: wave w finishes rows 0..31 of its 64x64 block, the idle loader wave
+      // w + 4 rows 32..63 (no MFMA is running any more, so its VALU work costs nothing extra):
+      // two workgroup barriers, after the accumulators are in LDS and after the finished values
+      // are parked for the mirrored store
       const int a0 = ti * TILE + 64 * wr, b0 = tj * TILE + 64 * wc;
-      if (a0 < K && b0 < K) {
-        double *slice = smem + (size_t)wave * WAVE_LDS_DOUBLES;
-        double (*Ts)[65] = reinterpret_cast<double (*)[65]>(slice);
-        double *rs = slice + 64 * 65;
+      const bool active = a.out_XTX && a0 < K && b0 < K;
+      double *slice = smem + (size_t)wave * WAVE_LDS_DOUBLES;
+      double (*Ts)[65] = reinterpret_cast<double (*)[65]>(slice);
+      double *rs = slice + 64 * 65;
+      double *outp = (double *)a.out_XTX + fo * (size_t)K * K;
+      if (active) {
         rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
         rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
         rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
@@ -463,11 +498,12 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               Ts[16 * m + MF<T>::drow(lane, r)][16 * n + lc] = acc[m * 4 + n][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        fused_finish_block<65>(Ts, rs, diag && wr == wc, a0, b0, K, (const double *)a.G,
-                           (double *)a.out_XTX + fo * (size_t)K * K, swt, cX, sX, lane);
       }
+      __syncthreads();   // B_dump
+      if (active)
+        fused_finish_direct<65>(Ts, rs, false, a0, b0, K, (const double *)a.G, outp, swt, cX, sX, lane, 0, 16);
+      __syncthreads();   // B_parked
+      if (active) fused_finish_mirror<65>(Ts, a0, b0, K, outp, lane, 0, 16);
     }
     return;
   }
