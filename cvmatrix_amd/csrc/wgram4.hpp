@@ -53,6 +53,30 @@ __device__ __forceinline__ void fused_finish_mirror(double (*Ts)[TP], int a0, in
                                                     int it_lo, int it_hi);
 constexpr int WAVE_LDS_DOUBLES = 64 * 65 + 256;   // a wave's 64x64 block + row/column means and stds
 
+// Fused epilogue of a DIAGONAL 128x128 tile, shared by all eight waves of the workgroup (the four
+// loader waves are idle by then): the tile's raw update is in Td (LDS), the statistics of block b in
+// rs_b = rs0 + 256 b.  Blocks: 0 = (0,0) and 2 = (1,1) on the diagonal, 1 = (0,1) off it (stored
+// mirrored too).  Phase 0: twelve units of eight row pairs (block u / 4, rows 16 (u % 4) ..), wave v
+// takes units v and v + 8; phase 1 (after a barrier): the mirrored store of block 1, waves 0..3.
+template <int TP>
+__device__ __forceinline__ void diag_tile_finish(double (*Td)[TP], double *rs0, int v, int phase, int ti, int K,
+                                                 const double *Gt, double *out, double swt, bool cX, bool sX,
+                                                 int lane) {
+  if (phase == 0) {
+    for (int u = v; u < 12; u += 8) {
+      const int b = u >> 2, si = b == 2, sj = b >= 1;
+      const int a0 = ti * TILE + 64 * si, b0 = ti * TILE + 64 * sj;
+      if (a0 >= K || b0 >= K) continue;
+      fused_finish_direct<TP>(reinterpret_cast<double (*)[TP]>(&Td[64 * si][64 * sj]), rs0 + 256 * b, si == sj, a0,
+                              b0, K, Gt, out, swt, cX, sX, lane, (u & 3) * 8, (u & 3) * 8 + 8);
+    }
+  } else if (v < 4) {
+    const int a0 = ti * TILE, b0 = ti * TILE + 64;
+    if (b0 < K)
+      fused_finish_mirror<TP>(reinterpret_cast<double (*)[TP]>(&Td[0][64]), a0, b0, K, out, lane, 8 * v, 8 * v + 8);
+  }
+}
+
 template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
 __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
   typedef typename MF<T>::acc_t acc_t;
@@ -266,6 +290,22 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing in flight at wave exit
     if (FUSEDR) __builtin_amdgcn_s_barrier();       // the compute waves reuse the ring in their epilogue
     if constexpr (FUSEDR && sizeof(T) == 8) {
+      if (do_g && diag && a.out_XTX) {
+        // diagonal tile of the fused route: share the epilogue (diag_tile_finish), waves 4..7
+        constexpr int TP = TILE + 1;
+        const int K = g.K, M = g.M;
+        const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
+        const double swt = fs[2 * K + 2 * M];
+        const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
+        double *smd = reinterpret_cast<double *>(smem);
+        double (*Td)[TP] = reinterpret_cast<double (*)[TP]>(smd);
+        double *rs0 = smd + (size_t)TILE * TP;
+        double *outp = (double *)a.out_XTX + (size_t)(a.seg0 + seg) * (size_t)K * K;
+        __syncthreads();   // B_dump
+        diag_tile_finish<TP>(Td, rs0, wave_all, 0, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
+        __syncthreads();   // B_parked
+        diag_tile_finish<TP>(Td, rs0, wave_all, 1, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
+      }
       if (do_g && !diag) {
         // off-diagonal tile of the fused route: help compute wave d with the second half of its
         // 64x64 block (see the compute role's epilogue; same two barriers)
@@ -725,22 +765,22 @@ __device__ __noinline__ void wgram4_diag_body(const WgramArgs<T> &a_ref) {
       for (int j = 0; j < W + 1; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Td[16 * R1 + MF<T>::drow(lane, r)][16 * (R1 + j) + lc] = acc[NB0 + j][r];
-      __syncthreads();   // (the loader waves have ended or are ending: only live waves count)
+      double *rs0 = smem + (size_t)TILE * TP;
       if (W != 2) {
-        const int si = W == 3 ? 1 : 0, sj = W == 0 ? 0 : 1;
+        // waves 0, 1, 3 set up the statistics of blocks 0, 1, 2
+        const int bb = W == 3 ? 2 : W, si = bb == 2, sj = bb >= 1;
         const int a0 = ti * TILE + 64 * si, b0 = ti * TILE + 64 * sj;
-        if (a0 < K && b0 < K) {
-          double *rs = smem + (size_t)TILE * TP + (size_t)W * 256;
-          rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
-          rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
-          rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
-          rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          fused_finish_block<TP>(reinterpret_cast<double (*)[TP]>(&Td[64 * si][64 * sj]), rs, si == sj, a0, b0, K,
-                                 (const double *)a.G, (double *)a.out_XTX + fo * (size_t)K * K, swt, cX, sX, lane);
-        }
+        double *rs = rs0 + 256 * bb;
+        rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
+        rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
+        rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
+        rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
       }
+      __syncthreads();   // B_dump: the tile and the statistics are in LDS (all eight waves)
+      double *outp = (double *)a.out_XTX + fo * (size_t)K * K;
+      diag_tile_finish<TP>(Td, rs0, W, 0, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
+      __syncthreads();   // B_parked
+      diag_tile_finish<TP>(Td, rs0, W, 1, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
     }
     return;
   }
