@@ -64,7 +64,7 @@ for c in range(cases):
     # (to rounding where the batch takes the rows kernel -- it sums w * (x_a * x_b), the tile kernel
     #  (w * x_a) * x_b -- and bit for bit elsewhere)
     one = m.training_XTX(folds[0])[0]
-    rows_kernel = dt is np.float64 and nmax <= 2 and P >= 8 and K % 16 != 0 and K % 2 == 0 and K <= 512
+    rows_kernel = dt is np.float64 and max(len(v) for v in folds) <= 2 and P >= 8 and K % 16 != 0 and K % 2 == 0 and K <= 512
     if rows_kernel:
         assert float((one - bx[0]).abs().max()) <= 1e-12 * float(bx[0].abs().max()), (c, "per-call vs batch")
     else:
