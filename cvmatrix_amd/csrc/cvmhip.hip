@@ -128,6 +128,11 @@ int cvm_debug_pls_stamps(unsigned long long *host_out, int reset) {
   }
   return CVM_OK;
 }
+int cvm_debug_stamps4(unsigned long long *host_out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps4), sizeof(unsigned long long) * 1024 * 8));
+  return CVM_OK;
+}
 int cvm_debug_stamps3(unsigned long long *host_out) {
   HIP_OK(hipDeviceSynchronize());
   HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps3), sizeof(unsigned long long) * 1024 * 8 * 2));

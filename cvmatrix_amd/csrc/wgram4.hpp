@@ -483,6 +483,10 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
 #endif
 
   if constexpr (FUSEDR && sizeof(T) == 8) {
+#ifdef CVM_STAMPS
+    unsigned long long f0, f1, f2, f3, f4, f5;
+    STAMP(f0);
+#endif
     // ---- fused single-split epilogue: no partials, no apply kernel --------------------------
     // The fold's statistics are already in a.fstats (colstats_kernel + fold_stats_kernel ran
     // first); every wave finishes its own block: total - update, rank-1 centring, outer-std
@@ -539,11 +543,32 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
             for (int r = 0; r < 4; ++r)
               Ts[16 * m + MF<T>::drow(lane, r)][16 * n + lc] = acc[m * 4 + n][r];
       }
+#ifdef CVM_STAMPS
+      STAMP(f1);
+#endif
       __syncthreads();   // B_dump
+#ifdef CVM_STAMPS
+      STAMP(f2);
+#endif
       if (active)
         fused_finish_direct<65>(Ts, rs, false, a0, b0, K, (const double *)a.G, outp, swt, cX, sX, lane, 0, 16);
+#ifdef CVM_STAMPS
+      STAMP(f3);
+#endif
       __syncthreads();   // B_parked
+#ifdef CVM_STAMPS
+      STAMP(f4);
+#endif
       if (active) fused_finish_mirror<65>(Ts, a0, b0, K, outp, lane, 0, 16);
+#ifdef CVM_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(f5);
+      if (lane == 0 && wave == 0 && blockIdx.x < 1024) {
+        unsigned long long *o = g_stamps4 + (size_t)blockIdx.x * 8;
+        o[0] = c_loop0 - c_entry; o[1] = c_loop1 - c_loop0; o[2] = f1 - f0; o[3] = f2 - f1; o[4] = f3 - f2;
+        o[5] = f4 - f3; o[6] = f5 - f4; o[7] = f5 - c_entry;
+      }
+#endif
     }
     return;
   }

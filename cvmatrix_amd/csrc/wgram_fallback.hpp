@@ -26,6 +26,7 @@ __device__ float g_one_line_f[4] = {1.0f, 1.0f, 1.0f, 1.0f};
 // diagnostic build only: per (workgroup, wave) cycle sums of the three phases of a stage
 __device__ unsigned long long g_stamps[1024 * 8 * 4];
 __device__ unsigned long long g_stamps2[1024 * 8 * 4];
+__device__ unsigned long long g_stamps4[1024 * 8];   // fused off-diagonal epilogue, wave 0: 8 time points
 __device__ unsigned long long g_stamps3[1024 * 8 * 2];   // per compute wave: prologue, epilogue cycles   // per wave: shader cycles, 100 MHz ticks, start tick
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif

@@ -5,7 +5,7 @@ import cvmatrix_amd._lib as L
 L.LIB_PATH = sys.argv[1]
 from cvmatrix_amd import CVMatrix, Partitioner
 rng = np.random.default_rng(42)
-N, K, M, P = 100000, 512, 16, 10
+N, K, M, P = 100000, 512, 16, int(os.environ.get("STAMP_P", "10"))
 X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
 import os
 if os.environ.get("UNWEIGHTED"): w = None
