@@ -294,7 +294,10 @@ class CVMatrix:
     # ------------------------------------------------------------------ fit stage
     def fit(self, X, Y=None, weights=None, folds=None) -> None:
         """Store ``X``, ``Y``, ``weights`` on the device and compute the full-data
-        ``XᵀWX``, ``XᵀWY`` and column statistics in one pass (cvmatrix.py:207-328).
+        ``XᵀWX``, ``XᵀWY`` and column statistics in one pass (cvmatrix.py:207-328).  With
+        ``lazy_fit`` (the default) that pass is left pending until the matrices are first needed
+        (see the class properties above): a batched call over folds that partition the rows then
+        produces them in the same sweep that serves the folds.
 
         ``folds`` (not in the reference; optional): a ``Partitioner``, a list of index arrays
         or a ``FoldBatch`` that PARTITIONS the rows.  The full-data matrices are then formed
