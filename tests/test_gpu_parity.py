@@ -1122,3 +1122,26 @@ def test_leave_one_out_rows_kernel(amd, dtype, K):
             assert bool((bx[f] == bx[f].T).all())
         bx1 = m.training_XTX_batched(folds)[0]
         assert bool((bx1 == bx).all())
+
+
+@pytest.mark.parametrize("N,K,M,P,flags", [(30000, 260, 40, 200, (True,) * 4), (20000, 132, 66, 100, (True, False, True, False)),
+                                           (24000, 516, 34, 60, (False,) * 4)])
+def test_mid_size_folds_with_wide_y(amd, N, K, M, P, flags):
+    """One unit per fold with more than 32 responses: the fused route has Y-chunk items next to the
+    G tiles (all eight waves share the epilogue of a G tile, none that of a Y chunk)."""
+    rng = np.random.default_rng(N + K)
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
+    folds = [np.arange(i, N, P) for i in range(P)]
+    m = amd.CVMatrix(*flags, lazy_fit=False)
+    m.fit(X, Y, w)
+    o = OracleCVMatrix(*flags)
+    o.fit(X, Y, w)
+    (bx, by), bst = m.training_XTX_XTY_batched(folds)
+    bx1, _ = m.training_XTX_batched(folds)
+    for f in (0, P // 2, P - 1):
+        (rx, ry), rst = o.training_XTX_XTY(folds[f])
+        assert_normwise(bx[f], rx, TOL, "XTX")
+        assert_normwise(by[f], ry, TOL, "XTY")
+        assert_normwise(bx1[f], rx, TOL, "XTX only")
+        assert_stats(tuple(None if s is None else s[f] for s in bst), rst, TOL)
+        assert bool((bx[f] == bx[f].T).all())
