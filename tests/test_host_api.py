@@ -170,3 +170,18 @@ def test_launch_planning_is_host_logic():
 
 def test_package_metadata():
     assert cvmatrix_amd.__all__ == ["CVMatrix", "Partitioner", "FoldBatch"]
+
+
+def test_header_constants_match_the_python_binding():
+    """Status codes, dtype codes and flag bits of include/cvmhip.h as cvmatrix_amd/_lib.py uses them."""
+    header = open(os.path.join(ROOT, "include", "cvmhip.h")).read()
+    defs = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"#define\s+(CVM_[A-Z0-9_]+)\s+(0x[0-9A-Fa-f]+u?|\d+u?)\b", header)}
+    expect = {
+        "CVM_OK": _lib.CVM_OK, "CVM_EINVAL": _lib.CVM_EINVAL, "CVM_EWORKSPACE": _lib.CVM_EWORKSPACE,
+        "CVM_ELAUNCH": _lib.CVM_ELAUNCH, "CVM_F32": _lib.CVM_F32, "CVM_F64": _lib.CVM_F64,
+        "CVM_RET_XTX": _lib.RET_XTX, "CVM_RET_XTY": _lib.RET_XTY, "CVM_CENTER_X": _lib.CENTER_X,
+        "CVM_CENTER_Y": _lib.CENTER_Y, "CVM_SCALE_X": _lib.SCALE_X, "CVM_SCALE_Y": _lib.SCALE_Y,
+        "CVM_IDX_HOST": _lib.IDX_HOST,
+    }
+    for name, value in expect.items():
+        assert defs.get(name) == value, (name, defs.get(name), value)
