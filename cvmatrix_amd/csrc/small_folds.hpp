@@ -256,12 +256,14 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   constexpr int TC = LPR * VW;
   constexpr int RSTEP = 256 / LPR;                 // rows per pass
   constexpr int NP = SR_ROWS / RSTEP;              // passes = pieces per thread
+  constexpr int NV = 2;                            // validation rows per fold this kernel takes
   typedef T vec_t __attribute__((ext_vector_type(VW)));
   typedef double dvec_t __attribute__((ext_vector_type(VW)));
-  __shared__ TS xr[SMALL_ROWS][SR_ROWS];           // x of the validation rows at the panel's 8 rows
-  __shared__ TS wxr[SMALL_ROWS][SR_ROWS];          // w * x there (rounded like the reference's WX)
-  __shared__ double wl[SMALL_ROWS];
-  __shared__ double str[2][SR_ROWS];               // mean, std of the panel's rows
+  // two LDS buffers: fold ff computes from buffer ff & 1 while the data of fold ff + 1 is on its way
+  __shared__ TS xr[2][NV][SR_ROWS];                // x of the validation rows at the panel's 8 rows
+  __shared__ TS wxr[2][NV][SR_ROWS];               // w * x there (rounded like the reference's WX)
+  __shared__ double wl[2][NV];
+  __shared__ double str[2][2][SR_ROWS];            // mean, std of the panel's rows
   // XCD-contiguous ranges of (fold group, panel), as in small_apply_kernel
   const unsigned lin = blockIdx.x, tot = (unsigned)a.gx * (unsigned)a.gy;
   const unsigned per = (tot + 7) / 8;
@@ -274,9 +276,10 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   const int rr = tid / LPR;                        // this thread's rows: rr + p * RSTEP
   const int gc = b0 + (tid - rr * LPR) * VW;       // K % VW == 0: a piece is inside or outside
   const bool col_ok = gc < K;
+  const bool do_xx = a.out_XTX && col_ok;
   const T *Gt = (const T *)a.G;
   T gpre[NP][VW];
-  if (a.out_XTX && col_ok) {
+  if (do_xx) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
       if (a0 + rr + p * RSTEP < K) {
@@ -285,23 +288,39 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
         for (int e = 0; e < VW; ++e) gpre[p][e] = t[e];
       }
   }
-  for (int ff = 0; ff < a.fpb; ++ff) {
-    const int f = by * a.fpb + ff;
-    if (f >= a.nb) break;
+  // ---- what a fold needs, fetched one fold ahead (registers; the staged part goes to LDS at the
+  //      top of its own iteration): the loads of fold ff + 1 are issued before the stores of fold ff
+  struct Pre {
+    int n;
+    vec_t xc[NV];        // x of the validation rows at this thread's columns
+    dvec_t muc, sdc;     // mean, std of this thread's columns
+    T sx, sw;            // staged by thread r * 8 + i: x[row r][a0 + i], w[row r]
+    double sst;          // staged by threads 0..15: mean / std of panel row
+  };
+  const int f_lo = by * a.fpb;
+  const int f_hi = (f_lo + a.fpb < a.nb) ? f_lo + a.fpb : a.nb;
+  auto fetch = [&](int f, Pre &p) {
     const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
-    const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
+    p.n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
     const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-    const double swt = fs[2 * K + 2 * M];
-    const size_t fo = (size_t)(a.seg0 + f);
-    if (ff) __syncthreads();                       // the previous fold is done with the LDS
-    if (tid < n * SR_ROWS) {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { p.muc[e] = 0.0; p.sdc[e] = 1.0; }
+    if (do_xx) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+        if (u < p.n) {
+          const int64_t ridx = inl ? a.inl[u] : a.idx[o0 + u];
+          p.xc[u] = *reinterpret_cast<const vec_t *>(X + ridx * (int64_t)K + gc);
+        }
+      if (cX) p.muc = *reinterpret_cast<const dvec_t *>(fs + gc);
+      if (sX) p.sdc = *reinterpret_cast<const dvec_t *>(fs + K + gc);
+    }
+    p.sx = (T)0; p.sw = (T)1; p.sst = 0.0;
+    if (tid < p.n * SR_ROWS) {
       const int r = tid / SR_ROWS, i = tid - r * SR_ROWS;
       const int64_t ridx = inl ? a.inl[r] : a.idx[o0 + r];
-      const T wv = WEIGHTED ? W[ridx] : (T)1;
-      const T xv = (a0 + i < K) ? X[ridx * (int64_t)K + a0 + i] : (T)0;
-      xr[r][i] = (TS)xv;
-      wxr[r][i] = (TS)(WEIGHTED ? (T)(wv * xv) : xv);
-      if (i == 0) wl[r] = (double)wv;
+      p.sw = WEIGHTED ? W[ridx] : (T)1;
+      p.sx = (a0 + i < K) ? X[ridx * (int64_t)K + a0 + i] : (T)0;
     }
     if (tid < 2 * SR_ROWS) {
       const int which = tid / SR_ROWS, i = tid - which * SR_ROWS;
@@ -310,55 +329,56 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
         if (!which && cX) v = fs[a0 + i];
         if (which && sX) v = fs[K + a0 + i];
       }
-      str[which][i] = v;
+      p.sst = v;
     }
-    // column data of this thread, straight to registers
-    dvec_t muc, sdc;
-#pragma unroll
-    for (int e = 0; e < VW; ++e) { muc[e] = 0.0; sdc[e] = 1.0; }
-    if (a.out_XTX && col_ok) {
-      if (cX) muc = *reinterpret_cast<const dvec_t *>(fs + gc);
-      if (sX) sdc = *reinterpret_cast<const dvec_t *>(fs + K + gc);
+  };
+  Pre cur, nxt;
+  if (f_lo < f_hi) fetch(f_lo, cur);
+  for (int f = f_lo; f < f_hi; ++f) {
+    const int b = (f - f_lo) & 1;
+    const int n = cur.n;
+    // stage this fold's small shared data (buffer b was last read two folds ago: one barrier per fold)
+    if (tid < n * SR_ROWS) {
+      const int r = tid / SR_ROWS, i = tid - r * SR_ROWS;
+      xr[b][r][i] = (TS)cur.sx;
+      wxr[b][r][i] = (TS)(WEIGHTED ? (T)(cur.sw * cur.sx) : cur.sx);
+      if (i == 0) wl[b][r] = (double)cur.sw;
     }
-    TS acc[NP][VW];
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-      for (int e = 0; e < VW; ++e) acc[p][e] = 0;
+    if (tid < 2 * SR_ROWS) str[b][tid / SR_ROWS][tid % SR_ROWS] = cur.sst;
     __syncthreads();
-    if (a.out_XTX && col_ok) {
-      for (int r0 = 0; r0 < n; r0 += 8) {
-        vec_t xc[8];
+    if (f + 1 < f_hi) fetch(f + 1, nxt);          // in flight during the arithmetic and the stores below
+    const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+    const double swt = fs[2 * K + 2 * M];
+    const size_t fo = (size_t)(a.seg0 + f);
+    if (do_xx) {
+      TS acc[NP][VW];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (r0 + u < n) {
-            const int64_t ridx = inl ? a.inl[r0 + u] : a.idx[o0 + r0 + u];
-            xc[u] = *reinterpret_cast<const vec_t *>(X + ridx * (int64_t)K + gc);
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc[p][e] = 0;
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+        if (u < n) {
+          const TS wr = (TS)(T)wl[b][u];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const TS rv = xr[b][u][rr + p * RSTEP];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) acc[p][e] += WEIGHTED ? wr * (rv * (TS)cur.xc[u][e]) : rv * (TS)cur.xc[u][e];
           }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (r0 + u < n) {
-            const TS wr = (TS)(T)wl[r0 + u];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-              const TS rv = xr[r0 + u][rr + p * RSTEP];
-#pragma unroll
-              for (int e = 0; e < VW; ++e) acc[p][e] += WEIGHTED ? wr * (rv * (TS)xc[u][e]) : rv * (TS)xc[u][e];
-            }
-          }
-      }
+        }
       T *out = (T *)a.out_XTX + fo * (size_t)K * K;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int i = rr + p * RSTEP;
         if (a0 + i >= K) continue;
-        const double mur = str[0][i], sdr = str[1][i];
+        const double mur = str[b][0][i], sdr = str[b][1][i];
         vec_t vv;
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
           double v = (double)gpre[p][e] - (double)acc[p][e];
-          if (cX) v -= swt * (mur * muc[e]);
-          if (sX) v = v / (sdr * sdc[e]);
+          if (cX) v -= swt * (mur * cur.muc[e]);
+          if (sX) v = v / (sdr * cur.sdc[e]);
           vv[e] = (T)v;
         }
         *reinterpret_cast<vec_t *>(out + (size_t)(a0 + i) * K + gc) = vv;
@@ -368,6 +388,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
     if (a.out_XTY && M > 0 && cc == 0) {
       const T *Ht = (const T *)a.H;
       T *out = (T *)a.out_XTY + fo * (size_t)K * M;
+      const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
       for (int e = tid; e < SR_ROWS * M; e += 256) {
         const int i = e / M, m = e - i * M;
         const int ga = a0 + i;
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
         TS s = 0;
         for (int r = 0; r < n; ++r) {
           const int64_t ridx = inl ? a.inl[r] : a.idx[o0 + r];
-          s += wxr[r][i] * (TS)Y[ridx * (int64_t)M + m];
+          s += wxr[b][r][i] * (TS)Y[ridx * (int64_t)M + m];
         }
         double v = (double)Ht[(size_t)ga * M + m] - (double)s;
         if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
@@ -385,5 +406,6 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
         out[(size_t)ga * M + m] = (T)v;
       }
     }
+    cur = nxt;
   }
 }
