@@ -6,14 +6,17 @@ from cvmatrix_amd import CVMatrix, Partitioner
 
 dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-for (N, K, M, P, dt) in ((100000, 512, 16, 10, torch.float64), (60000, 388, 34, 7, torch.float64),
-                         (50000, 260, 0, 300, torch.float64), (80000, 516, 5, 6, torch.float32),
-                         (30000, 130, 2, 3, torch.float64)):
+# (the last three: mid-size folds with wide Y through the shared fused epilogue, leave-one-out through
+#  the pipelined rows kernel, the lazy one-sweep fit)
+for (N, K, M, P, dt, lazy) in ((100000, 512, 16, 10, torch.float64, False), (60000, 388, 34, 7, torch.float64, False),
+                               (50000, 260, 0, 300, torch.float64, False), (80000, 516, 5, 6, torch.float32, False),
+                               (30000, 130, 2, 3, torch.float64, False), (40000, 260, 40, 400, torch.float64, False),
+                               (3000, 500, 10, 3000, torch.float64, False), (100000, 512, 16, 10, torch.float64, True)):
     g = torch.Generator(device=dev); g.manual_seed(K)
     X = torch.rand((N, K), dtype=dt, device=dev, generator=g)
     Y = torch.rand((N, M), dtype=dt, device=dev, generator=g) if M else None
     w = torch.rand((N,), dtype=dt, device=dev, generator=g)
-    m = CVMatrix(dtype=np.float64 if dt == torch.float64 else np.float32, copy=False, device=dev, lazy_fit=False)
+    m = CVMatrix(dtype=np.float64 if dt == torch.float64 else np.float32, copy=False, device=dev, lazy_fit=lazy)
     m.fit(X, Y, w)
     b = m.prepare_folds(Partitioner(np.arange(N) % P))
     ref = m.training_XTX_XTY_batched(b) if M else (m.training_XTX_batched(b),)
@@ -27,4 +30,4 @@ for (N, K, M, P, dt) in ((100000, 512, 16, 10, torch.float64), (60000, 388, 34, 
         ok = bool((x == rx).all()) and (y is None or bool((y == ry).all()))
         ok = ok and all(a is None or bool((a == c).all()) for a, c in zip(st, rst))
         bad += (not ok)
-    print(f"N={N} K={K} M={M} P={P} {dt}: {reps} repetitions, {bad} differ")
+    print(f"N={N} K={K} M={M} P={P} {dt} lazy={lazy}: {reps} repetitions, {bad} differ")
