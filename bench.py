@@ -4,25 +4,36 @@
 One "step" = one full cross-validation pass over device-resident inputs, the quantity the
 reference's benchmark times (benchmarks/benchmark.py:101-158): CVMatrix.fit() (full-data
 Gram + column statistics) followed by training_XTX_XTY for every fold (one batched call).
-`value` is the package's default path: fit() is lazy and, the folds partitioning the rows,
-one sweep of the Gram kernel yields the full-data matrices and every fold's matrices
-(DESIGN.md 4.5); the eager two-stage path is timed next to it (two_stage_*, fit_ms,
-fold_stage_ms).
 Workload = BASELINE.json configs[2] ("C3"): N=100000, K=512, M=16, 10 folds
 (folds = arange(N) % P), weighted, center+scale X and Y, float64, inputs from
 default_rng(42).random exactly as benchmarks/benchmark.py:223-233.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): weak scaling.  Every rank
-owns its own N rows and the P folds made of them; the fit stage runs on the local rows and
-ONE RCCL all-reduce of [G | H | column stats] (2.2 MB) makes the full-data matrices of the
-world*N-row data set; the fold stage then needs no communication.  value = folds of all
-ranks / max-over-ranks time.
+`value` = folds of the whole job / max-over-ranks time.  The timed path (`--path sweep`,
+default) is fit() deferred + a batched call whose folds partition the rows: ONE sweep of the
+Gram kernel yields the full-data matrices and every fold's matrices; the
+eager two-stage path (fit kernel, then fold update) is timed next to it (two_stage_*,
+fit_ms, fold_stage_ms), and so are the reference's one-call-per-fold loop and the
+reference's whole benchmark protocol from host arrays.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU):
+  --scaling strong (default)  BASELINE.json's metric: the SAME N x K x M problem and the
+      same P folds on 1/2/4/8 GPUs.  Fold f -> rank (LPT on fold sizes = round-robin for
+      equal folds); a rank holds the rows of its own folds only.
+        --mode row_sharded (default): every rank sweeps its own folds' rows; ONE RCCL
+            all-reduce of [G | H | column stats] (2.2 MB at C3) gives the full-data
+            matrices; the per-fold finalize needs no communication.
+        --mode replicated (the north_star variant): every rank holds all rows, rank 0 runs
+            the fit stage and broadcasts [G | H | stats]; each rank updates its own folds.
+      Ceiling P / ceil(P / G) folds-rounds: C3 (10 folds) 1x, 2x, 3.3x, 5x at 1/2/4/8 GPUs.
+  --scaling weak  every rank owns its own N rows and P folds made of them (a world*N-row,
+      world*P-fold cross-validation); one all-reduce.  The metric string says so.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings)."""
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -52,6 +63,93 @@ def synth(N, K, M, dtype, seed):
     return X, Y, w
 
 
+def synth_device_rows(torch, dev, rows, N, K, M, tdt, seed, block=8192):
+    """Rows ``rows`` (ascending global row numbers, a torch int64 tensor on ``dev``) of a
+    synthetic N x K / N x M / N problem that is the same on every rank whatever the world
+    size: row block b is drawn from a generator seeded with (seed, b).  Used for the shapes
+    whose inputs are not generated on the host (C4: 8.2 GB)."""
+    n_loc = int(rows.numel())
+    X = torch.empty((n_loc, K), dtype=tdt, device=dev)
+    Y = torch.empty((n_loc, M), dtype=tdt, device=dev)
+    w = torch.empty((n_loc,), dtype=tdt, device=dev)
+    gen = torch.Generator(device=dev)
+    blk = torch.div(rows, block, rounding_mode="floor")
+    o = 0
+    for b in range((N + block - 1) // block):
+        sel = rows[blk == b] - b * block
+        if sel.numel() == 0:
+            continue
+        nb = min(block, N - b * block)
+        gen.manual_seed(seed * 1000003 + b)
+        xb = torch.rand((nb, K), dtype=tdt, device=dev, generator=gen)
+        yb = torch.rand((nb, M), dtype=tdt, device=dev, generator=gen)
+        wb = torch.rand((nb,), dtype=tdt, device=dev, generator=gen)
+        n = int(sel.numel())
+        X[o:o + n], Y[o:o + n], w[o:o + n] = xb[sel], yb[sel], wb[sel]
+        o += n
+    return X, Y, w
+
+
+def direct_fold_check(torch, dist, world, Xd, Yd, wd, val_local, owner, rank, ddof, flags, got, dev):
+    """Size-independent parity property at full size: the training-set matrices of ONE fold
+    recomputed from scratch the naive way (tests/naive_cvmatrix.py's definition: centre and
+    scale the training rows, then multiply) in float64 by library GEMMs -- nothing shared
+    with the product path.  ``val_local``: the fold's validation rows in this rank's local
+    numbering (only meaningful on ``owner``; the other ranks' rows are all training rows).
+    Returns the norm-wise relative errors (XTX, XTY, mean_X, std_X) on every rank."""
+    f64 = torch.float64
+    n_loc = Xd.shape[0]
+    keep = torch.ones(n_loc, dtype=torch.bool, device=dev)
+    if rank == owner and val_local is not None:
+        keep[val_local] = False
+    Xt, Yt = Xd[keep].to(f64), Yd[keep].to(f64)
+    wt = wd[keep].to(f64) if wd is not None else torch.ones(Xt.shape[0], dtype=f64, device=dev)
+    K, M = Xt.shape[1], Yt.shape[1]
+    cX, cY, sX, sY = flags
+
+    def allsum(t):
+        if world > 1:
+            dist.all_reduce(t)
+        return t
+
+    head = allsum(torch.stack([wt.sum(), (wt != 0).sum().to(f64)]))
+    sw, nz = head[0], head[1]
+    s1 = allsum(torch.cat([(Xt * wt[:, None]).sum(0), (Yt * wt[:, None]).sum(0)]))
+    muX, muY = s1[:K] / sw, s1[K:] / sw
+    if not (cX or cY):
+        muXc, muYc = torch.zeros_like(muX), torch.zeros_like(muY)
+    else:
+        # cvmatrix.py:1001-1010: XTX is centred with mu_X only if center_X; XTY's rank-1 term
+        # uses both means whenever either flag is set
+        muXc, muYc = muX, muY
+    div = (nz - ddof) * sw / nz
+    v2 = allsum(torch.cat([((Xt - muX) ** 2 * wt[:, None]).sum(0), ((Yt - muY) ** 2 * wt[:, None]).sum(0)]))
+    sdX, sdY = (v2[:K] / div).sqrt(), (v2[K:] / div).sqrt()
+    Xc = Xt - muXc if cX else Xt
+    Xs = Xc / sdX if sX else Xc
+    refX = allsum((Xs * wt[:, None]).T @ Xs)
+    # XTY: (X - muX)^T W (Y - muY) when either centring flag is set
+    Xc2 = (Xt - muX) if (cX or cY) else Xt
+    Yc2 = (Yt - muY) if (cX or cY) else Yt
+    Xs2 = Xc2 / sdX if sX else Xc2
+    Ys2 = Yc2 / sdY if sY else Yc2
+    refY = allsum((Xs2 * wt[:, None]).T @ Ys2)
+    errs = torch.zeros(4, dtype=f64, device=dev)
+    if rank == owner:
+        gx, gy, gmu, gsd = got
+        dx, dy = gx.to(f64) - refX, gy.to(f64) - refY
+        errs[0] = torch.maximum(dx.abs().max() / refX.abs().max(), dx.norm() / refX.norm())
+        errs[1] = torch.maximum(dy.abs().max() / refY.abs().max(), dy.norm() / refY.norm())
+        if gmu is not None:
+            errs[2] = ((gmu.to(f64).reshape(-1) - muX).abs() / muX.abs()).max()
+        if gsd is not None:
+            errs[3] = ((gsd.to(f64).reshape(-1) - sdX).abs() / sdX.abs()).max()
+    if world > 1:
+        dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+    del Xt, Yt, Xs, Xs2, Ys2, Xc, Xc2, Yc2
+    return [float(e) for e in errs.cpu()]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,13 +157,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=50,
                     help="untimed steps; the GPU needs ~30 ms of work to reach its steady clocks")
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--mode", default="row_sharded", choices=["row_sharded", "replicated"])
+    ap.add_argument("--path", default="sweep", choices=["sweep", "two_stage"],
+                    help="timed path: lazy fit + one sweep (default) or eager fit + fold update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="run only warmup + the timed steps (no split timers, two-stage, per-fold-call, "
                          "supplementary or CPU legs): the command profiled under "
                          "rocprofv3 for profiles/, so that every launch in the trace is a "
                          "launch of the timed region")
-    ap.add_argument("--rows", type=int, default=0, help="override N per GPU (debug)")
+    ap.add_argument("--rows", type=int, default=0, help="override the global N (debug / tests)")
+    ap.add_argument("--device-data", action="store_true",
+                    help="generate the inputs on the device (default for C4)")
     args = ap.parse_args()
 
     import torch
@@ -91,35 +195,77 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from cvmatrix_amd import Partitioner, _lib
-    from cvmatrix_amd.distributed import ShardedCVMatrix
+    from cvmatrix_amd import CVMatrix, Partitioner, _lib
+    from cvmatrix_amd.distributed import ShardedCVMatrix, shard_folds
 
     lib = _lib.load()
     N, K, M, P, weighted, flags, dtype = WORKLOADS[args.workload]
     if args.rows:
         N = args.rows
     tdt = torch.float64 if dtype is np.float64 else torch.float32
+    es = np.dtype(dtype).itemsize
+    strong = args.scaling == "strong"
+    mode = args.mode if (strong and world > 1) else "row_sharded"
+    device_data = args.device_data or args.workload == "C4"
 
-    X, Y, w = synth(N, K, M, dtype, 42 + rank)
-    folds = np.arange(N) % P
-    Xd = torch.from_numpy(X).to(dev)
-    Yd = torch.from_numpy(Y).to(dev)
-    wd = torch.from_numpy(w).to(dev) if weighted else None
+    # ---- the problem, and this rank's share of it ------------------------------------------
+    X = Y = w = None
+    if strong:
+        labels = np.arange(N) % P                      # the folds of the WHOLE problem
+        keys, rows, local_labels = shard_folds(labels, world, rank)
+        if mode == "replicated":
+            rows_held = np.arange(N)
+            part = Partitioner(labels)
+            fold_lists = [part.get_validation_indices(k) for k in keys]
+        else:
+            rows_held = rows
+            part = Partitioner(local_labels)
+            fold_lists = [part.get_validation_indices(k) for k in keys]
+        if device_data:
+            Xd, Yd, wd = synth_device_rows(torch, dev, torch.from_numpy(rows_held).to(dev), N, K, M, tdt, 42)
+        else:
+            X, Y, w = synth(N, K, M, dtype, 42)
+            sel = slice(None) if rows_held.size == N else rows_held
+            Xd = torch.from_numpy(X[sel]).to(dev)
+            Yd = torch.from_numpy(Y[sel]).to(dev)
+            wd = torch.from_numpy(w[sel]).to(dev)
+        total_folds_per_step = P
+    else:
+        keys = list(range(P))
+        labels = np.arange(N) % P
+        if device_data:
+            Xd, Yd, wd = synth_device_rows(torch, dev, torch.arange(N, device=dev), N, K, M, tdt, 42 + rank)
+        else:
+            X, Y, w = synth(N, K, M, dtype, 42 + rank)
+            Xd, Yd, wd = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev), torch.from_numpy(w).to(dev)
+        part = Partitioner(labels)
+        fold_lists = [part.get_validation_indices(k) for k in keys]
+        total_folds_per_step = P * world
+    if not weighted:
+        wd = None
+    n_mine = len(fold_lists)
 
-    # `model`: the default behaviour of the package (lazy_fit): fit() + a batched call whose folds
-    # partition the rows is served by ONE sweep of the Gram kernel (full-data matrices = sum of
-    # the folds' validation matrices).  `eager`: the two-stage path (fit kernel, then fold update).
-    model = ShardedCVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev,
-                            mode="row_sharded", lazy_fit=True)
-    eager = ShardedCVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev,
-                            mode="row_sharded", lazy_fit=False)
+    # `model`: lazy fit; fit() + a batched call whose folds partition the (local) rows is served
+    # by ONE sweep of the Gram kernel (full-data matrices = sum of the folds' validation
+    # matrices, all-reduced over the ranks).  `eager`: fit kernel, then fold update.
+    # (copy=False: the inputs are already private device tensors of this process.)
+    model = ShardedCVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, mode=mode, lazy_fit=True)
+    eager = ShardedCVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, mode=mode, lazy_fit=False)
+    timed_model = model if args.path == "sweep" else eager
     model.fit(Xd, Yd, wd)
     eager.fit(Xd, Yd, wd)
-    batch = model.prepare_folds(Partitioner(folds))
+    batch = model.prepare_folds(fold_lists) if n_mine else None
 
-    def step():
-        model.fit(Xd, Yd, wd)
-        return model.training_XTX_XTY_batched(batch)
+    def step_of(m):
+        def step():
+            m.fit(Xd, Yd, wd)
+            if batch is None:          # more ranks than folds: take part in the exchange only
+                m._ensure_fit()
+                return None
+            return m.training_XTX_XTY_batched(batch)
+        return step
+
+    step = step_of(timed_model)
 
     def fence():
         if world > 1:
@@ -157,107 +303,176 @@ def main():
         for _ in range(reps):
             fn()
         torch.cuda.synchronize()
-        return (time.perf_counter() - a) / reps * 1e3
+        ms = (time.perf_counter() - a) / reps * 1e3
+        if world > 1:
+            tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = float(tt.item())
+        return ms
 
     ho = args.headline_only
-
-    def eager_step():
-        eager.fit(Xd, Yd, wd)
-        return eager.training_XTX_XTY_batched(batch)
-
+    other = eager if timed_model is model else model
+    other_step = step_of(other)
     fit_ms = fold_ms = two_ms = float("nan")
     ms_fit2, ms_fold2 = C.c_double(), C.c_double()
     n_fit2, n_fold2 = C.c_int64(), C.c_int64()
-    eager_out = None
+    other_out = None
     if not ho:
         for _ in range(5):
-            eager_out = eager_step()
+            other_out = other_step()
         lib.cvm_timing_enable(1)
-        two_ms = timed(eager_step, reps=20)
+        two_ms = timed(other_step, reps=20)
         lib.cvm_timing_read(C.byref(ms_fit2), C.byref(n_fit2), C.byref(ms_fold2), C.byref(n_fold2))
         lib.cvm_timing_enable(0)
-        if world > 1:
-            t = torch.tensor([two_ms], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            two_ms = float(t.item())
         fit_ms = timed(lambda: eager.fit(Xd, Yd, wd))
-        fold_ms = timed(lambda: eager.training_XTX_XTY_batched(batch))
+        if batch is not None:
+            fold_ms = timed(lambda: eager.training_XTX_XTY_batched(batch))
 
     # the reference's NumPy call pattern, fold by fold (benchmarks/benchmark.py:153-158):
     # fit, then one training_XTX_XTY(validation_indices) call per fold with host index arrays
-    part = Partitioner(folds)
-    fold_idx = [part.get_validation_indices(f) for f in part.folds_dict]
-
     def loop_step():
         eager.fit(Xd, Yd, wd)
-        return [eager.training_XTX_XTY(v) for v in fold_idx]
+        return [eager.training_XTX_XTY(v) for v in fold_lists]
 
     loop_ms = float("nan")
     if not ho:
         loop_step()
         loop_ms = timed(loop_step, reps=5)
 
-    result = None
-    if rank == 0:
-        total_folds = P * world * args.steps
-        value = total_folds / elapsed
-        n_val = np.diff(batch.host_offsets).astype(np.float64)
-        # algorithmic flops of one fold-stage Gram launch.  SURVEY.md 8(d) gives two
-        # conventions; `achieved` uses the smaller, symmetric one (what has to be computed:
-        # upper triangle of XTX + XTY), the dense one (what the reference's dgemm executes,
-        # F = 2 n K (K+M)) is reported next to it.
-        f_tri = float((n_val * (K * (K + 1) + 2.0 * K * M)).sum())
-        f_dense = float((2.0 * n_val * K * (K + M)).sum())
-        es = np.dtype(dtype).itemsize
-        b_alg = float((es * n_val * (K + M + 1) + 8 * n_val).sum() + 2.0 * es * K * (K + M) * P)
-        gram_ms = ms_fold.value / max(n_fold.value, 1)
-        fit_gram_ms = ms_fit2.value / max(n_fit2.value, 1) if n_fit2.value else float("nan")
-        two_gram_ms = ms_fold2.value / max(n_fold2.value, 1) if n_fold2.value else float("nan")
-        peak = PEAK_TFLOPS[dtype]
-        achieved = f_tri / (gram_ms * 1e-3) / 1e12
-        info = (C.c_int64 * 8)()
-        fl = 0x3F
-        lib.cvm_plan_fold(P, int(n_val.max()), K, M, _lib.CVM_F64 if es == 8 else _lib.CVM_F32,
-                          fl, C.c_size_t(1 << 40), info)
-        executed = float(info[5]) * 2048.0 * float(np.ceil(n_val / 4.0).sum())
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(args.workload, {}).get("fold_gram_bytes_per_launch")
-        roofline = {
-            "kernel": "wgram4_kernel<T,WEIGHTED,GATHER,FUSED> (gather + weighted Gram of all folds, 1 launch/step; "
-                      "in the default lazy-fit path the same launch also yields the full-data matrices)",
-            "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "flops_per_launch": f_tri, "flops_convention": "n*K*(K+1) + 2*n*K*M per fold (symmetric)",
-            "achieved_dense_convention": round(f_dense / (gram_ms * 1e-3) / 1e12, 3),
-            "mfma_executed_tflops": round(executed / (gram_ms * 1e-3) / 1e12, 3),
-            "avg_launch_ms": round(gram_ms, 4), "launches_timed": int(n_fold.value),
-            "two_stage_fit_gram_avg_launch_ms": round(fit_gram_ms, 4),
-            "two_stage_fit_gram_achieved": round((N * (K * (K + 1) + 2.0 * K * M)) / (fit_gram_ms * 1e-3) / 1e12, 3),
-            "two_stage_fold_gram_avg_launch_ms": round(two_gram_ms, 4),
-            "algorithmic_hbm_bytes_per_launch": b_alg,
-            "hbm_frac_if_bytes_bound": round(b_alg / (gram_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-        }
-        # parity gate in the same run (C2/C3 only: digests of the reference at these inputs)
-        parity = "not checked"
-        if world == 1 and not args.rows and args.workload in ("C2", "C3"):
+    # ---- parity gate in the same run ---------------------------------------------------------
+    # C2/C3 (host-generated inputs = the reference benchmark's): this rank's folds against the
+    # reference digests (tests/golden/g6_digest.npz); every workload: one fold recomputed from
+    # scratch the naive way at full size (direct_fold_check).
+    parity = "not checked"
+    if True:
+        notes, ok = [], True
+        results = [r for r in ((out, args.path), (other_out, "two_stage" if args.path == "sweep" else "sweep"))
+                   if r[0] is not None]
+        if not args.rows and not device_data and args.workload in ("C2", "C3") and strong:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import parity_cases as pc
                 from conftest import load_npz
 
                 z = load_npz("g6_digest.npz")
-                for res in (out,) if eager_out is None else (out, eager_out):
+                checked = []
+                for res, _name in results:
                     (bx, by), bst = res
-                    for f in (0, 4, 9):
-                        st = tuple(None if s is None else s[f] for s in bst)
-                        pc.check_digest(z, args.workload.lower(), f, bx[f], by[f], st, 1e-10)
-                parity = ("ok: folds 0,4,9 within 1e-10 norm-wise of the reference digests "
-                          "(lazy one-sweep and two-stage)")
+                    for i, f in enumerate(keys):
+                        if f in (0, 4, 9) or world > 1:
+                            st = tuple(None if s is None else s[i] for s in bst)
+                            pc.check_digest(z, args.workload.lower(), int(f), bx[i], by[i], st, 1e-10)
+                            checked.append(int(f))
+                notes.append(f"folds {sorted(set(checked))} of this rank within 1e-10 norm-wise of the "
+                             f"reference digests ({' and '.join(n for _, n in results)})")
             except AssertionError as e:  # pragma: no cover
-                parity = f"FAILED: {e}"
+                ok = False
+                notes.append(f"digest FAILED on rank {rank}: {e}")
+        # full-size property check on the last fold of rank 0 (a collective when world > 1)
+        if not ho and (mode == "row_sharded" or rank == 0):
+            # (replicated: rank 0 holds every row and checks alone, nothing collective)
+            cw = world if mode == "row_sharded" else 1
+            try:
+                got = None
+                if rank == 0 and out is not None:
+                    (bx, by), bst = out
+                    got = (bx[-1], by[-1], None if bst[0] is None else bst[0][-1],
+                           None if bst[1] is None else bst[1][-1])
+                vloc = torch.from_numpy(np.asarray(fold_lists[-1])).to(dev) if (rank == 0 and n_mine) else None
+                errs = direct_fold_check(torch, dist, cw, Xd, Yd, wd, vloc, 0, rank, 1, flags, got, dev)
+                if es == 8:
+                    bound = 1e-10
+                else:
+                    # float32: at most 2x the error NumPy's float32 path makes
+                    # on the same problem, or 1e-3; the stored scaled digest gives NumPy's error scale
+                    bound = 1e-3
+                good = all(e <= bound for e in errs[:2]) and all(e <= max(bound, 1e-10) for e in errs[2:])
+                ok = ok and good
+                notes.append(f"fold {keys[-1] if n_mine and rank == 0 else '?'} vs a from-scratch float64 "
+                             f"computation at full size: XTX {errs[0]:.1e}, XTY {errs[1]:.1e}, mean {errs[2]:.1e}, "
+                             f"std {errs[3]:.1e} (bound {bound:g}){'' if good else ' FAILED'}")
+            except Exception as e:  # noqa: BLE001  pragma: no cover
+                ok = False
+                notes.append(f"direct check raised: {e!r}")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        parity = ("ok: " if int(flag.item()) else "FAILED: ") + "; ".join(notes)
+
+    result = None
+    if rank == 0:
+        value = total_folds_per_step * args.steps / elapsed
+        n_val = np.diff(batch.host_offsets).astype(np.float64) if batch is not None else np.zeros(0)
+        # algorithmic flops of one fold-stage Gram launch ON THIS RANK.  SURVEY.md 8(d) gives two
+        # conventions; `achieved` uses the smaller, symmetric one (what has to be computed:
+        # upper triangle of XTX + XTY), the dense one (what the reference's dgemm executes,
+        # F = 2 n K (K+M)) is reported next to it.
+        f_tri = float((n_val * (K * (K + 1) + 2.0 * K * M)).sum())
+        f_dense = float((2.0 * n_val * K * (K + M)).sum())
+        b_alg = float((es * n_val * (K + M + 1) + 8 * n_val).sum() + 2.0 * es * K * (K + M) * n_mine)
+        gram_ms = ms_fold.value / max(n_fold.value, 1)
+        fms, fn = (ms_fit2.value, n_fit2.value) if n_fit2.value else (ms_fit.value, n_fit.value)
+        fit_gram_ms = fms / fn if fn else float("nan")
+        two_gram_ms = ms_fold2.value / max(n_fold2.value, 1) if n_fold2.value else float("nan")
+        peak = PEAK_TFLOPS[dtype]
+        achieved = f_tri / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else float("nan")
+        info = (C.c_int64 * 8)()
+        fl = 0x3F
+        executed = float("nan")
+        if n_mine:
+            lib.cvm_plan_fold(n_mine, int(n_val.max()), K, M, _lib.CVM_F64 if es == 8 else _lib.CVM_F32,
+                              fl, C.c_size_t(1 << 40), info)
+            executed = float(info[5]) * 2048.0 * float(np.ceil(n_val / 4.0).sum())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and world == 1 and not args.rows:
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.workload, {}).get("fold_gram_bytes_per_launch")
+        n_rows_local = int(Xd.shape[0])
+        roofline = {
+            "kernel": "wgram4_kernel<T,WEIGHTED,GATHER,FUSED> (gather + weighted Gram of this rank's folds, "
+                      "1 launch/step; in the sweep path the same launch also yields the full-data matrices)",
+            "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "`bench.py --headline-only` (not re-measured in this run)") if traffic else None,
+            "flops_per_launch": f_tri, "flops_convention": "n*K*(K+1) + 2*n*K*M per fold (symmetric)",
+            "achieved_dense_convention": round(f_dense / (gram_ms * 1e-3) / 1e12, 3) if gram_ms > 0 else None,
+            "mfma_executed_tflops": round(executed / (gram_ms * 1e-3) / 1e12, 3) if gram_ms > 0 else None,
+            "avg_launch_ms": round(gram_ms, 4), "launches_timed": int(n_fold.value),
+            "two_stage_fit_gram_avg_launch_ms": round(fit_gram_ms, 4),
+            "two_stage_fit_gram_achieved": round((n_rows_local * (K * (K + 1) + 2.0 * K * M)) / (fit_gram_ms * 1e-3) / 1e12, 3),
+            "two_stage_fold_gram_avg_launch_ms": round(two_gram_ms, 4),
+            "algorithmic_hbm_bytes_per_launch": b_alg,
+            "hbm_frac_if_bytes_bound": round(b_alg / (gram_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if gram_ms > 0 else None,
+        }
+        roofline = {k: (None if isinstance(v, float) and v != v else v) for k, v in roofline.items()}
+
+        # the reference's whole benchmark protocol (benchmarks/benchmark.py:101-158, 293-308):
+        # constructor + Partitioner + fit from HOST arrays + one call per fold, wall time of one
+        # cold pass -- the host->device copy of X, Y, weights is inside
+        proto = None
+        if world == 1 and not ho and X is not None:
+            def proto_run(batched):
+                a = time.perf_counter()
+                m_ = CVMatrix(*flags, ddof=1, dtype=dtype, copy=True)
+                p_ = Partitioner(np.arange(N) % P)
+                m_.fit(X, Y, w if weighted else None)
+                if batched:
+                    r_ = m_.training_XTX_XTY_batched(p_)
+                else:
+                    r_ = [m_.training_XTX_XTY(p_.get_validation_indices(f)) for f in p_.folds_dict]
+                torch.cuda.synchronize()
+                del r_
+                return time.perf_counter() - a
+            proto_run(False)
+            tl = sorted(proto_run(False) for _ in range(3))
+            tb = sorted(proto_run(True) for _ in range(3))
+            proto = {"what": "ctor + Partitioner + fit(host arrays, copy=True) + training_XTX_XTY per fold, "
+                             "median of 3 cold passes (host->device copy of X inside)",
+                     "loop_folds_per_s": round(P / tl[1], 1), "loop_s": round(tl[1], 5),
+                     "batched_folds_per_s": round(P / tb[1], 1), "batched_s": round(tb[1], 5)}
+
         # supplementary, HBM-bound regime (BASELINE.md section 2 "C5-hbm"): K=4096, M=1,
         # float32, folds of 16 rows -> the direct small-fold kernels; and leave-one-out at
         # the reference's published shape (N=1e5, K=500, M=10; benchmarks/README.md:11-20)
@@ -266,6 +481,7 @@ def main():
             supp = {}
             for name, (n_, k_, m_, nv_, nf_, dt_) in {
                 "C5-hbm (K=4096,M=1,f32,n_val=16)": (20000, 4096, 1, 16, 48, np.float32),
+                "K=4096,M=1,f64,n_val=16": (20000, 4096, 1, 16, 48, np.float64),
                 "LOOCV (K=500,M=10,f64,n_val=1)": (100000, 500, 10, 1, 2000, np.float64),
             }.items():
                 tt = torch.float64 if dt_ is np.float64 else torch.float32
@@ -273,7 +489,7 @@ def main():
                 Xs = torch.rand((n_, k_), dtype=tt, device=dev, generator=gen)
                 Ys = torch.rand((n_, m_), dtype=tt, device=dev, generator=gen)
                 ws_ = torch.rand((n_,), dtype=tt, device=dev, generator=gen)
-                ms_ = ShardedCVMatrix(dtype=dt_, copy=False, device=dev)
+                ms_ = CVMatrix(dtype=dt_, copy=False, device=dev, lazy_fit=False)
                 ms_.fit(Xs, Ys, ws_)
                 bs_ = ms_.prepare_folds([np.arange(i * nv_, (i + 1) * nv_) for i in range(nf_)])
                 o_ = ms_.training_XTX_XTY_batched(bs_); del o_
@@ -286,15 +502,19 @@ def main():
                 ms1 = float(np.median(tl))
                 sz = np.dtype(dt_).itemsize
                 bts = nf_ * (sz * nv_ * (k_ + m_ + 1) + 8 * nv_ + 2 * sz * k_ * (k_ + m_))
+                # what the memory system must move at least when the full-data matrices stay in
+                # cache (they are the same for every fold): the outputs + the rows, G and H once
+                bts_mem = nf_ * (sz * nv_ * (k_ + m_ + 1) + 8 * nv_ + sz * k_ * (k_ + m_)) + sz * k_ * (k_ + m_)
                 supp[name] = {"folds": nf_, "ms": round(ms1, 4), "folds_per_s": round(nf_ / ms1 * 1e3, 1),
                               "roofline": {"bound": "hbm", "achieved": round(bts / ms1 / 1e6, 1),
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                            "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
-                                           "bytes_per_fold": "s*n*(K+M+1) + 8n + 2*s*K*(K+M)"}}
+                                           "bytes_per_fold": "s*n*(K+M+1) + 8n + 2*s*K*(K+M)",
+                                           "frac_if_G_is_cache_resident": round(bts_mem / ms1 / 1e6 / PEAK_HBM_GBS, 4)}}
                 del Xs, Ys, ws_, ms_, bs_
         # statistics only (training_statistics): the column-statistics kernel
         # streams the validation rows once -> HBM-bound
-        if supp is not None:
+        if supp is not None and batch is not None:
             # (on the eager object: after a sweep the lazy one derives the statistics from the
             #  partials it still holds, without touching the rows)
             eager.training_statistics_batched(batch)
@@ -313,7 +533,7 @@ def main():
                              "bytes_per_fold": "s*n*(K+M+1) + 8n"}}
         # the step after the path: Improved Kernel PLS (20 components) on the
         # training matrices of this workload's folds, where the fold stage left them
-        if supp is not None:
+        if supp is not None and batch is not None:
             from cvmatrix_amd.pls import pls_fit_batched, pls_plan
             (bx, by), _ = model.training_XTX_XTY_batched(batch)
             A_pls = 20
@@ -340,13 +560,21 @@ def main():
                 thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
             except Exception:  # noqa: BLE001
                 thr = os.cpu_count()
+            # a BOUNDED sample of the same workload: the whole workload when one pass takes a few
+            # seconds (C2/C3), else the first rows of it (same K, M, P), scaled by rows
+            n_cpu = N if (X is not None and N * K * (K + M) <= 6e10) else max(P * 64, int(6e10 / (K * (K + M))))
+            if X is not None:
+                Xc, Yc, wc = X[:n_cpu], Y[:n_cpu], w[:n_cpu]
+            else:
+                Xc, Yc, wc = synth(n_cpu, K, M, dtype, 42)
+            fc = np.arange(n_cpu) % P
             times = []
             a0 = time.perf_counter()
             while len(times) < 3 or (time.perf_counter() - a0 < 10.0 and len(times) < 12):
                 a = time.perf_counter()
-                run_cv(X, Y, w if weighted else None, folds, *flags, ddof=1, dtype=dtype)
+                run_cv(Xc, Yc, wc if weighted else None, fc, *flags, ddof=1, dtype=dtype)
                 times.append(time.perf_counter() - a)
-            cpu_s = float(np.median(times))
+            cpu_s = float(np.median(times)) * (N / n_cpu)
             # one BLAS thread, one pass: lines up with the reference's published single-thread
             # numbers (benchmarks/README.md:5)
             one_thread = None
@@ -355,39 +583,60 @@ def main():
 
                 with threadpool_limits(limits=1):
                     a = time.perf_counter()
-                    run_cv(X, Y, w if weighted else None, folds, *flags, ddof=1, dtype=dtype)
-                    one_thread = round(P / (time.perf_counter() - a), 3)
+                    run_cv(Xc, Yc, wc if weighted else None, fc, *flags, ddof=1, dtype=dtype)
+                    one_thread = round(P / ((time.perf_counter() - a) * (N / n_cpu)), 3)
             except Exception:  # noqa: BLE001
                 pass
             cpu = {"value": round(P / cpu_s, 3), "unit": "folds/s", "cores": int(thr),
                    "single_thread_value": one_thread,
                    "kind": "port",
-                   "sample": f"the full {args.workload} workload (ctor+Partitioner+fit+{P} folds) "
-                             f"{len(times)} times, median {cpu_s:.2f} s per pass "
-                             f"({sum(times):.1f} s of CPU work), NumPy oracle "
-                             f"(oracle/cvmatrix_oracle.py) on the host, BLAS threads={thr}, "
-                             f"host cores={os.cpu_count()}"}
+                   "sample": (f"the {'full' if n_cpu == N else (f'first {n_cpu} rows of the' if X is not None else f'a host-generated {n_cpu}-row sample of the')} {args.workload} workload "
+                              f"(ctor+Partitioner+fit+{P} folds) {len(times)} times, median "
+                              f"{float(np.median(times)):.2f} s per pass ({sum(times):.1f} s of CPU work"
+                              f"{'' if n_cpu == N else f', scaled by N/{n_cpu} rows'}), NumPy oracle "
+                              f"(oracle/cvmatrix_oracle.py) on the host, BLAS threads={thr}, "
+                              f"host cores={os.cpu_count()}")}
+        Nfmt = f"{N:.0e}".replace("e+0", "e") if N in (100000, 1000000) else str(N)
+        if strong:
+            base_metric = ("folds/sec (training_XTX_XTY, center+scale) at N=1e5,K=512" if args.workload == "C3"
+                           and not args.rows else f"folds/sec (training_XTX_XTY) at N={Nfmt},K={K} [{args.workload}]")
+            par = (f"strong scaling: the {P} folds of ONE {N}-row problem dealt over {world} GPU(s) "
+                   f"({n_mine} on rank 0), " +
+                   ("each rank sweeps its own folds' rows, one all-reduce of [G|H|stats]" if mode == "row_sharded"
+                    else "all rows on every rank, rank 0 fits, one broadcast of [G|H|stats]"))
+            wl = (f"{args.workload}: N={N}, K={K}, M={M}, {P} folds (arange(N)%P), "
+                  f"{'weighted' if weighted else 'unweighted'}, center/scale X,Y={flags[0]}, "
+                  f"fit + batched training_XTX_XTY per step ({args.path} path)")
+        else:
+            base_metric = (f"folds/sec (training_XTX_XTY) at N={world}x{N} rows, K={K}, {world}x{P} folds "
+                           f"[{args.workload}, weak scaling]")
+            par = f"weak scaling: every GPU its own {N} rows and {P} folds; one all-reduce of [G|H|stats]"
+            wl = (f"{args.workload} x {world}: N={N} rows/GPU, K={K}, M={M}, {P} folds/GPU (arange(N)%P), "
+                  f"{'weighted' if weighted else 'unweighted'}, center/scale X,Y={flags[0]}, "
+                  f"fit + batched training_XTX_XTY per step ({args.path} path)")
+        ceiling = P / math.ceil(P / world) if strong else float(world)
         result = {
-            # BASELINE.json's metric string at its own workload (C3); other workloads say their shape
-            "metric": ("folds/sec (training_XTX_XTY, center+scale) at N=1e5,K=512" if args.workload == "C3"
-                       and not args.rows else f"folds/sec (training_XTX_XTY) at N={N},K={K} [{args.workload}]"),
+            "metric": base_metric,
             "value": round(value, 2), "unit": "folds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if es == 8 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: N={N} rows/GPU, K={K}, M={M}, {P} folds/GPU "
-                                   f"(arange(N)%P), {'weighted' if weighted else 'unweighted'}, "
-                                   f"center/scale X,Y={flags[0]}, fit + batched training_XTX_XTY per step "
-                                   "(lazy fit: one sweep serves both calls)",
-                       "parallelism": f"folds+rows sharded over {world} GPU(s); one all-reduce of [G|H|stats]"},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64" if es == 8 else "f32",
+            "data": "synthetic" + (" (device-generated, block-seeded)" if device_data else
+                                   " (default_rng(42), benchmarks/benchmark.py:223-233)"),
+            "config": {"workload": wl, "parallelism": par,
+                       "inputs": "resident in HBM before the timed region (torch tensors, copy=False)"},
+            "scaling_ceiling_vs_1gpu": round(ceiling, 3),
             "fit_ms": round(fit_ms, 4), "fold_stage_ms": round(fold_ms, 4),
-            "update_only_folds_per_s": round(P / (fold_ms * 1e-3), 1),
-            "two_stage_ms_per_step": round(two_ms, 4),
-            "two_stage_folds_per_s": round(P * world / (two_ms * 1e-3), 1),
+            "update_only_folds_per_s": round(total_folds_per_step / (fold_ms * 1e-3), 1),
+            ("two_stage_ms_per_step" if args.path == "sweep" else "sweep_ms_per_step"): round(two_ms, 4),
+            ("two_stage_folds_per_s" if args.path == "sweep" else "sweep_folds_per_s"):
+                round(total_folds_per_step / (two_ms * 1e-3), 1),
             "per_fold_call_ms_per_step": round(loop_ms, 4),
-            "per_fold_call_folds_per_s": round(P * world / (loop_ms * 1e-3), 1),
+            "per_fold_call_folds_per_s": round(total_folds_per_step / (loop_ms * 1e-3), 1),
+            "reference_protocol": proto,
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu,
             "supplementary_hbm_regime": supp,
+            "lib": lib.cvm_version().decode(),
         }
         result = {k: (None if isinstance(v, float) and v != v else v) for k, v in result.items()}
         print(json.dumps(result), flush=True)

@@ -21,7 +21,7 @@ CENTER_X, CENTER_Y, SCALE_X, SCALE_Y = 0x04, 0x08, 0x10, 0x20
 IDX_HOST = 0x40
 
 EXPORTS = (
-    "cvm_version", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
+    "cvm_version", "cvm_source_hash", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
     "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_plan_fold",
     "cvm_timing_enable", "cvm_timing_read",
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds",
@@ -43,9 +43,25 @@ def load():
             "(python -m cvmatrix_amd.build, or __graft_entry__.build()). "
             "cvmatrix_amd has no CPU fallback."
         )
+    # the binary must be the source next to it: a stale prebuilt library is rebuilt when a
+    # compiler is there, refused otherwise (CVM_SKIP_HASH_CHECK=1: use it as it is)
+    from . import build as _build
+
+    if os.environ.get("CVM_SKIP_HASH_CHECK", "0") == "0" and os.path.isdir(os.path.join(_HERE, "csrc")):
+        want, have = _build.source_hash(), _build._embedded_hash_without_loading(LIB_PATH)
+        if have != want:
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            if not os.path.exists(hipcc):
+                raise ImportError(
+                    f"{LIB_PATH} was built from other sources (library {have}, sources {want}) "
+                    "and there is no hipcc to rebuild it")
+            print(f"cvmatrix_amd: libcvmhip.so is stale (library {have}, sources {want}); rebuilding",
+                  flush=True)
+            _build.build(force=True, verbose=False)
     lib = C.CDLL(LIB_PATH)
     vp, i64, sz, u32, dbl = C.c_void_p, C.c_int64, C.c_size_t, C.c_uint, C.c_double
     lib.cvm_version.restype = C.c_char_p
+    lib.cvm_source_hash.restype = C.c_char_p
     lib.cvm_last_error.restype = C.c_char_p
     lib.cvm_gstats_len.restype = sz
     lib.cvm_gstats_len.argtypes = [C.c_int, C.c_int]

@@ -19,6 +19,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/cvmhip.h"
@@ -42,7 +44,14 @@ namespace {
 // ----------------------------------------------------------------------------------
 extern "C" {
 
-const char *cvm_version(void) { return "cvmhip 0.1.0 (gfx950) built " __DATE__ " " __TIME__; }
+// CVM_SRC_SHA: sha256 (first 16 hex digits) over the sources the library was built from
+// (cvmatrix_amd/build.py computes it; the Python loader compares it with the sources it finds
+// next to the library, so a stale prebuilt .so cannot be used by accident)
+#ifndef CVM_SRC_SHA
+#define CVM_SRC_SHA "unknown"
+#endif
+const char *cvm_version(void) { return "cvmhip 0.2.0 (gfx950) src " CVM_SRC_SHA; }
+const char *cvm_source_hash(void) { return CVM_SRC_SHA; }
 const char *cvm_last_error(void) { return g_err; }
 
 size_t cvm_gstats_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 2; }
@@ -229,12 +238,14 @@ int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info)
 }
 
 int cvm_timing_enable(int on) {
-  g_timing = on != 0;
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  g_timing.store(on != 0);
   g_ntimed = 0;
   return CVM_OK;
 }
 
 int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
   double ms[2] = {0, 0};
   int64_t n[2] = {0, 0};
   for (int i = 0; i < g_ntimed; ++i) {

@@ -111,24 +111,26 @@ __device__ __forceinline__ long long uni64(long long v) {
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 template <typename P> __device__ __forceinline__ P *unip(P *p) { return (P *)uni64((long long)p); }
-// by-value copy of the launch arguments with every field forced into scalar registers; a
-// body function that reads them through the caller's reference reloads them with flat
-// loads (and a full vmcnt wait) at every use
-template <typename T> __device__ __forceinline__ WgramArgs<T> scalarize(const WgramArgs<T> &r) {
+// The launch arguments of the Gram kernels, read where they are needed: the out-of-line wave-role
+// functions take NO parameters and fetch the kernel's one argument (a WgramArgs<T> at offset 0 of
+// the kernarg segment) through the kernarg segment pointer -- scalar loads from constant memory
+// into SGPRs.  (Passing the struct to a __noinline__ function by reference made the kernel spill
+// it to 224-232 bytes of private memory per lane and every role reload it with flat loads.)
+template <typename T> __device__ __forceinline__ WgramArgs<T> kernel_args() {
+  typedef const __attribute__((address_space(4))) WgramArgs<T> *kptr_t;
+  kptr_t r = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   WgramArgs<T> a;
-  a.X = unip(r.X); a.Y = unip(r.Y); a.w = unip(r.w); a.idx = unip(r.idx); a.offs = unip(r.offs);
-  a.N = uni64(r.N); a.seg0 = uni64(r.seg0); a.n_seg = uni(r.n_seg); a.splits = uni(r.splits);
-  a.g.K = uni(r.g.K); a.g.M = uni(r.g.M); a.g.P = uni(r.g.P); a.g.Kp = uni(r.g.Kp);
-  a.g.Yc = uni(r.g.Yc); a.g.Mp = uni(r.g.Mp); a.g.nTiles = uni(r.g.nTiles); a.g.nT = uni(r.g.nT);
-  a.g.diag_only = uni(r.g.diag_only);
-  a.g.tile_elems = (size_t)uni64((long long)r.g.tile_elems);
-  a.g.h_elems = (size_t)uni64((long long)r.g.h_elems);
-  a.g.stat_len = (size_t)uni64((long long)r.g.stat_len);
-  a.g.unit_bytes = (size_t)uni64((long long)r.g.unit_bytes);
-  a.n_items = uni64(r.n_items); a.items_per_xcd = uni64(r.items_per_xcd);
-  a.ws = unip(r.ws); a.dbg = uni(r.dbg);
-  a.fstats = unip(r.fstats); a.G = unip(r.G); a.H = unip(r.H);
-  a.out_XTX = unip(r.out_XTX); a.out_XTY = unip(r.out_XTY); a.flags = (unsigned)uni((int)r.flags);
+  a.X = r->X; a.Y = r->Y; a.w = r->w; a.idx = r->idx; a.offs = r->offs;
+  a.N = r->N; a.seg0 = r->seg0; a.n_seg = r->n_seg; a.splits = r->splits;
+  a.g.K = r->g.K; a.g.M = r->g.M; a.g.P = r->g.P; a.g.Kp = r->g.Kp;
+  a.g.Yc = r->g.Yc; a.g.Mp = r->g.Mp; a.g.nTiles = r->g.nTiles; a.g.nT = r->g.nT;
+  a.g.diag_only = r->g.diag_only;
+  a.g.tile_elems = r->g.tile_elems; a.g.h_elems = r->g.h_elems;
+  a.g.stat_len = r->g.stat_len; a.g.unit_bytes = r->g.unit_bytes;
+  a.n_items = r->n_items; a.items_per_xcd = r->items_per_xcd;
+  a.ws = r->ws; a.dbg = r->dbg;
+  a.fstats = r->fstats; a.G = r->G; a.H = r->H;
+  a.out_XTX = r->out_XTX; a.out_XTY = r->out_XTY; a.flags = r->flags;
   return a;
 }
 

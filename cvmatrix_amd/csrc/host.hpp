@@ -17,11 +17,26 @@ int fail(int code, const char *fmt, const char *detail = "") {
   } while (0)
 
 // ---- optional per-launch timing of the Gram kernel (bench.py's roofline figure) --------
+// One process-wide recorder (cvm_timing_enable / cvm_timing_read): a pair of events around every
+// Gram launch, recorded on that launch's own stream.  Calls from several threads may record
+// concurrently: slots are claimed under a mutex and the launch kind travels with the call, not in
+// a global.
 struct TimedLaunch { hipEvent_t a, b; int kind; };
-bool g_timing = false;
-TimedLaunch g_timed[8192];
-int g_ntimed = 0;
-int g_timing_kind = 0;   // 0: fit stage, 1: fold stage
+constexpr int MAX_TIMED = 8192;
+std::atomic<bool> g_timing{false};
+std::mutex g_timing_mu;
+TimedLaunch g_timed[MAX_TIMED];
+int g_ntimed = 0;        // slots handed out (guarded by g_timing_mu)
+enum { KIND_FIT = 0, KIND_FOLD = 1 };
+
+// once-per-device flags of hipFuncSetAttribute: a bit mask updated atomically (setting the
+// attribute twice from two racing threads is harmless, a torn read-modify-write is not)
+inline bool attr_needed(std::atomic<unsigned long long> &done, int dev) {
+  return !((done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull);
+}
+inline void attr_set(std::atomic<unsigned long long> &done, int dev) {
+  done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+}
 
 struct Plan {
   Geom g;
@@ -89,7 +104,7 @@ template <typename T> bool wgram4_ok(const WgramArgs<T> &a, bool aligned) {
 
 template <typename T>
 int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st,
-                 bool fused = false) {
+                 int kind, bool fused = false) {
   const long per_xcd = (a.n_items + 7) / 8;
   WgramArgs<T> args = a;
   args.items_per_xcd = per_xcd;
@@ -108,21 +123,24 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   HIP_OK(hipGetDevice(&dev));
 #define CVM_LAUNCH(W, GA, AL)                                                                 \
   do {                                                                                     \
-    static unsigned long long attr_done = 0;   /* one bit per device */                   \
-    if (!((attr_done >> (dev & 63)) & 1ull)) {                                             \
+    static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */       \
+    if (attr_needed(attr_done, dev)) {                                                     \
       HIP_OK(hipFuncSetAttribute((const void *)wgram_kernel<T, W, GA, AL>,                 \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-      attr_done |= 1ull << (dev & 63);                                                     \
+      attr_set(attr_done, dev);                                                            \
     }                                                                                      \
     hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL>), grid, block, lds, st, args);          \
   } while (0)
   TimedLaunch *tl = nullptr;
-  if (g_timing && g_ntimed < 8192) {
-    tl = &g_timed[g_ntimed];
-    if (!tl->a) { HIP_OK(hipEventCreate(&tl->a)); HIP_OK(hipEventCreate(&tl->b)); }
-    tl->kind = g_timing_kind;
-    HIP_OK(hipEventRecord(tl->a, st));
+  if (g_timing.load(std::memory_order_relaxed)) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (g_ntimed < MAX_TIMED) {
+      tl = &g_timed[g_ntimed++];
+      if (!tl->a) { HIP_OK(hipEventCreate(&tl->a)); HIP_OK(hipEventCreate(&tl->b)); }
+      tl->kind = kind;
+    }
   }
+  if (tl) HIP_OK(hipEventRecord(tl->a, st));
   const bool fast = wgram4_ok<T>(a, aligned) && !(dbg_env & 16);
   if (fused && !(fast && gather && sizeof(T) == 8))
     return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
@@ -131,11 +149,11 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     const size_t lds4 = lds4_bytes<T>();
 #define CVM_LAUNCH4(W, GA, FU)                                                              \
   do {                                                                                      \
-    static unsigned long long attr_done = 0;                                                \
-    if (!((attr_done >> (dev & 63)) & 1ull)) {                                              \
+    static std::atomic<unsigned long long> attr_done{0};                                    \
+    if (attr_needed(attr_done, dev)) {                                                      \
       HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<T, W, GA, FU>,                 \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));   \
-      attr_done |= 1ull << (dev & 63);                                                      \
+      attr_set(attr_done, dev);                                                             \
     }                                                                                       \
     hipLaunchKernelGGL((wgram4_kernel<T, W, GA, FU>), grid, block4, lds4, st, args);        \
   } while (0)
@@ -154,7 +172,7 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     else { if (aligned) CVM_LAUNCH(false, false, true); else CVM_LAUNCH(false, false, false); }
   }
 #undef CVM_LAUNCH
-  if (tl) { HIP_OK(hipEventRecord(tl->b, st)); ++g_ntimed; }
+  if (tl) HIP_OK(hipEventRecord(tl->b, st));
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
@@ -191,8 +209,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   a.n_seg = 1; a.splits = p.splits; a.g = p.g;
   a.n_items = (long)p.splits * p.g.nT; a.items_per_xcd = 0;
   a.ws = (char *)ws;
-  g_timing_kind = 0;
-  rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st);
+  rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st, KIND_FIT);
   if (rc != CVM_OK) return rc;
   FinArgs f;
   memset(&f, 0, sizeof(f));
@@ -404,8 +421,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
         a.ws = nullptr;
         a.fstats = f.fstats; a.G = G; a.H = H;
         a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
-        g_timing_kind = 1;
-        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, true);
+        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, true);
         if (rc != CVM_OK) return rc;
       }
       return CVM_OK;
@@ -424,8 +440,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     a.n_seg = (int)nb; a.splits = p.splits; a.g = p.g;
     a.n_items = (long)nb * p.splits * p.g.nT; a.items_per_xcd = 0;
     a.ws = units;
-    g_timing_kind = 1;
-    rc = launch_wgram<T>(a, w != nullptr, true, aligned, st);
+    rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD);
     if (rc != CVM_OK) return rc;
     FinArgs f;
     memset(&f, 0, sizeof(f));
@@ -478,8 +493,7 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   a.n_seg = (int)n_folds; a.splits = p.splits; a.g = p.g;
   a.n_items = (long)n_folds * p.splits * p.g.nT; a.items_per_xcd = 0;
   a.ws = (char *)ws;
-  g_timing_kind = 1;
-  rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st);
+  rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st, KIND_FOLD);
   if (rc != CVM_OK) return rc;
   FinArgs f;
   memset(&f, 0, sizeof(f));

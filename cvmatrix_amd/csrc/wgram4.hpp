@@ -77,13 +77,26 @@ __device__ __forceinline__ void diag_tile_finish(double (*Td)[TP], double *rs0, 
   }
 }
 
+// The role functions never return to the kernel (it has nothing left to do after them): they end
+// the wave themselves (s_endpgm) and are declared noreturn, so the compiler does not save and
+// restore the callee-saved registers they use around a call that is the wave's last act -- as
+// ordinary functions every role spilled 12-74 VGPRs to scratch in its prologue and read them back
+// in its epilogue (a wait for up to 74 loads at the end of every work item).  The exit is an
+// inline-asm s_endpgm: before the builtin the compiler still emits the restoring epilogue.  (The -DCVM_STAMPS diagnostic build returns: it stamps the clock after the call.)
+#ifdef CVM_STAMPS
+#define ROLE_EXIT() return
+#define ROLE_ATTR
+#else
+#define ROLE_EXIT() do { asm volatile("s_endpgm"); __builtin_unreachable(); } while (0)
+#define ROLE_ATTR __attribute__((noreturn))
+#endif
 template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
-__device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
+__device__ __noinline__ ROLE_ATTR void wgram4_body() {
   typedef typename MF<T>::acc_t acc_t;
 #ifdef CVM_STAMPS
   const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
 #endif
-  const WgramArgs<T> a = scalarize(a_ref);
+  const WgramArgs<T> a = kernel_args<T>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const Geom &g = a.g;
@@ -94,7 +107,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
 
   const long b = blockIdx.x;
   const long item = (b & 7) * a.items_per_xcd + (b >> 3);
-  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) ROLE_EXIT();
   const long u = item / g.nT;
   const int it = (int)(item - u * g.nT);
   const int seg = (int)(u / a.splits);
@@ -333,7 +346,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
       o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = (unsigned long long)nstages;
     }
 #endif
-    return;
+    ROLE_EXIT();
   }
 
   // ---- compute waves ----------------------------------------------------------------------
@@ -570,7 +583,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
       }
 #endif
     }
-    return;
+    ROLE_EXIT();
   }
 
   auto comb = [&](double v) -> double {
@@ -635,6 +648,7 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
     }
   }
 #endif
+  ROLE_EXIT();
 }
 
 // ----------------------------------------------------------------------------------
@@ -648,9 +662,9 @@ __device__ __noinline__ void wgram4_body(const WgramArgs<T> &a_ref) {
 //   YSTAT: this wave also sums the Y columns, sw and nz (wave 3 of panel 0)
 // ----------------------------------------------------------------------------------
 template <typename T, bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT, bool FUSEDR = false>
-__device__ __noinline__ void wgram4_diag_body(const WgramArgs<T> &a_ref) {
+__device__ __noinline__ ROLE_ATTR void wgram4_diag_body() {
   typedef typename MF<T>::acc_t acc_t;
-  const WgramArgs<T> a = scalarize(a_ref);
+  const WgramArgs<T> a = kernel_args<T>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const Geom &g = a.g;
@@ -807,7 +821,7 @@ __device__ __noinline__ void wgram4_diag_body(const WgramArgs<T> &a_ref) {
       __syncthreads();   // B_parked
       diag_tile_finish<TP>(Td, rs0, W, 1, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
     }
-    return;
+    ROLE_EXIT();
   }
 
   auto comb = [&](double v) -> double {
@@ -858,6 +872,7 @@ __device__ __noinline__ void wgram4_diag_body(const WgramArgs<T> &a_ref) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       tp[(16 * R1 + MF<T>::drow(lane, r)) * TILE + 16 * (R1 + j) + lc] = acc[NB0 + j][r];
+  ROLE_EXIT();
 }
 
 template <typename T, bool WEIGHTED, bool GATHER, bool FUSED = false>
@@ -878,9 +893,9 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
       o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
     }
   };
-  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(a); fin(); return; }
+  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(); fin(); return; }
 #else
-  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(a); return; }
+  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(); return; }
 #endif
   const int it = (int)(item % g.nT);
   int ti, tj, yc;
@@ -894,8 +909,8 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     const bool wide = g.M > 16;
 #define CVM_DIAGF(WV)                                                                        \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false, true>(a);                   \
-      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false, true>(a);                        \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false, true>();                   \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false, true>();                        \
     } while (0)
     if (wave == 0) CVM_DIAGF(0);
     else if (wave == 1) CVM_DIAGF(1);
@@ -908,9 +923,9 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     return;
   }
   if (FUSED) {   // statistics come from colstats_kernel: no summing roles
-    if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0, true>(a);
-    else if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0, true>(a);
-    else wgram4_body<T, WEIGHTED, GATHER, false, false, 0, true>(a);
+    if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0, true>();
+    else if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0, true>();
+    else wgram4_body<T, WEIGHTED, GATHER, false, false, 0, true>();
 #ifdef CVM_STAMPS
     fin();
 #endif
@@ -921,15 +936,15 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     const bool wide = g.M > 16, ys = (ti == 0);
 #define CVM_DIAG(WV)                                                                         \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false>(a);                         \
-      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false>(a);                              \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false>();                         \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false>();                              \
     } while (0)
     if (wave == 0) CVM_DIAG(0);
     else if (wave == 1) CVM_DIAG(1);
     else if (wave == 2) CVM_DIAG(2);
     else if (!ys) CVM_DIAG(3);
-    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true>(a);
-    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true>(a);
+    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true>();
+    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true>();
 #undef CVM_DIAG
 #ifdef CVM_STAMPS
     fin();
@@ -937,10 +952,10 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     return;
   }
   const int role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
-  if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0>(a);
-  else if (role == 1) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 1>(a); else wgram4_body<T, WEIGHTED, GATHER, false, false, 1>(a); }
-  else if (role == 2) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 2>(a); else wgram4_body<T, WEIGHTED, GATHER, false, false, 2>(a); }
-  else { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0>(a); else wgram4_body<T, WEIGHTED, GATHER, false, false, 0>(a); }
+  if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0>();
+  else if (role == 1) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 1>(); else wgram4_body<T, WEIGHTED, GATHER, false, false, 1>(); }
+  else if (role == 2) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 2>(); else wgram4_body<T, WEIGHTED, GATHER, false, false, 2>(); }
+  else { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0>(); else wgram4_body<T, WEIGHTED, GATHER, false, false, 0>(); }
 #ifdef CVM_STAMPS
   fin();
 #endif

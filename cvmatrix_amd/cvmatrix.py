@@ -44,10 +44,9 @@ def _resolve_backend(backend: str) -> str:
     """Counterpart of cvmatrix.py:58-96 for this package: the only backend is "hip"."""
     if backend == "hip":
         return backend
-    raise ValueError(
-        f"Invalid backend: {backend!r}. Must be 'hip' (the 'numpy' and 'jax' backends "
-        "live in the reference package)."
-    )
+    # same form as cvmatrix.py:96 ("Invalid backend: 'x'. Must be 'numpy' or 'jax'."); the
+    # reference's own backends live in the reference package
+    raise ValueError(f"Invalid backend: {backend!r}. Must be 'hip'.")
 
 
 class FoldBatch:
@@ -59,12 +58,13 @@ class FoldBatch:
     """
 
     def __init__(self, idx, offsets, host_offsets, nz_val, labels=None, host_idx=None, n_rows=0,
-                 device=None):
+                 device=None, w_gen=None):
         self._idx, self._offsets = idx, offsets
         self.host_offsets, self.nz_val, self.labels = host_offsets, nz_val, labels
         self._host_idx, self._n_rows, self._is_partition = host_idx, n_rows, None
         self._sizes = None
         self._device = device
+        self._w_gen = w_gen     # CVMatrix._w_gen the non-zero counts were computed for
 
     # one fold of at most 32 rows is created without device arrays: the matrix calls hand its
     # indices to the library from the host (CVM_IDX_HOST); anything else uploads them on demand
@@ -128,11 +128,24 @@ class CVMatrix:
         backend: str = "hip",
         device: Union[None, str, int, torch.device] = None,
         lazy_fit: Optional[bool] = None,
+        output: str = "torch",
     ) -> None:
-        # None: lazy unless the environment says CVM_LAZY_FIT=0 (the test-suite runs both ways)
+        # ``lazy_fit=None`` (default): ``fit`` may defer its arithmetic to the first use only
+        # when the object owns private copies of its inputs (``copy=True``, like the reference's
+        # default): nothing the caller does to its own arrays between ``fit`` and that first
+        # use can then change a result.  ``copy=False`` aliases caller memory
+        # (cvmatrix.py:1146-1148), so ``fit`` computes at once like cvmatrix.py:325-328.
+        # CVM_LAZY_FIT=0/1 overrides the default (the test-suite runs both ways).
         if lazy_fit is None:
-            lazy_fit = os.environ.get("CVM_LAZY_FIT", "1") != "0"
+            env = os.environ.get("CVM_LAZY_FIT")
+            lazy_fit = bool(copy) if env is None else env != "0"
         self.lazy_fit = bool(lazy_fit)
+        # ``output="numpy"``: every result (matrices, statistics, the XTX/XTY/sum_* attributes)
+        # is returned as a NumPy array like the reference's backend="numpy"; "torch" (default)
+        # leaves results on the device, like the reference's backend="jax" returns jax.Array
+        if output not in ("torch", "numpy"):
+            raise ValueError(f"Invalid output: {output!r}. Must be 'torch' or 'numpy'.")
+        self.output = output
         self._pending = False
         self.center_X, self.center_Y = center_X, center_Y
         self.scale_X, self.scale_Y = scale_X, scale_Y
@@ -171,16 +184,30 @@ class CVMatrix:
         self._sweep_ws = None
         self.sweep_folds = None
         self._w_checked = None
+        self._w_checked_src = None
+        self._w_gen = 0          # bumped whenever the validated weights change
+        self._np_cache = {}
 
     # ------------------------------------------------------------------ full-data matrices
     # ``fit`` may leave them pending (``lazy_fit``): they are computed on first use -- by the
     # fit-stage kernel, or, when the first use is a batched call whose folds partition the
     # rows, as the sum of the folds' validation matrices in the same sweep that serves the
     # folds (half the arithmetic; SURVEY.md 8(f) rank 1, "behind the same API").
+    def _out(self, t, key=None):
+        """A result in the form ``output`` asks for: the device tensor, or its NumPy copy
+        (attributes are copied once per fit: ``key``)."""
+        if t is None or self.output != "numpy":
+            return t
+        if key is None:
+            return t.cpu().numpy()
+        if key not in self._np_cache:
+            self._np_cache[key] = t.cpu().numpy()
+        return self._np_cache[key]
+
     @property
     def XTX(self):
         self._ensure_fit()
-        return self._G
+        return self._out(self._G, "XTX")
 
     @XTX.setter
     def XTX(self, v):
@@ -189,7 +216,7 @@ class CVMatrix:
     @property
     def XTY(self):
         self._ensure_fit()
-        return self._H
+        return self._out(self._H, "XTY")
 
     @XTY.setter
     def XTY(self, v):
@@ -310,7 +337,10 @@ class CVMatrix:
         """
         lib = _lib.load()
         self.device = self._pick_device()
+        # nothing of an earlier fit may survive a fit that raises half-way
         self._sweep = None
+        self._pending = False
+        self._np_cache = {}
         with torch.cuda.device(self.device):
             self.X = self._init_mat(X)
             self.N, self.K = self.X.shape
@@ -327,33 +357,20 @@ class CVMatrix:
                 if self.weights.shape != (self.N, 1):
                     raise ValueError("weights must have shape (N,) or (N, 1)")
             else:
-                self.weights, self._w_host, self._w_checked = None, None, None
+                if self.weights is not None or self._w_host is not None:
+                    self._w_gen += 1
+                self.weights, self._w_host, self._w_checked, self._w_checked_src = None, None, None, None
             M = self.M or 0
-            self._pending = False
             self._alloc_globals(lib.cvm_gstats_len(self.K, M))
+            self._neg = None
             if folds is not None:
                 neg = torch.empty(1, dtype=torch.int32, device=self.device)
                 self._fit_sweep(lib, folds, neg)
                 self._neg = neg
             elif self.lazy_fit:
-                self._neg = None
-                if self.weights is not None and self._w_host is None:
-                    # device-resident weights seen for the first time: sign check and the host
-                    # copy for the fold validity checks without waiting for a kernel
-                    self._w_host = self.weights.reshape(-1).cpu().numpy()
-                    if bool(np.any(self._w_host < 0)):
-                        raise ValueError(MSG_NEG_W)
-                    self._w_checked = self._weights_key(weights)
                 self._pending = True
             else:
                 self._launch_fit(lib)
-            if self.weights is not None and self._w_host is None:
-                # device-resident weights: one readback for the sign check and for the
-                # host-side fold validity checks (non-zero counts)
-                if int(self._neg.item()) != 0:
-                    raise ValueError(MSG_NEG_W)
-                self._w_host = self.weights.reshape(-1).cpu().numpy()
-                self._w_checked = self._weights_key(weights)
             self._publish_stats()
         if not self._pending:
             self._after_globals()
@@ -381,12 +398,6 @@ class CVMatrix:
     def _fit_sweep(self, lib, folds, neg) -> None:
         """One-sweep fit: Gram kernel over all folds once, full-data matrices = their sum
         (cvm_sweep_fit); the per-fold partials stay in a dedicated workspace."""
-        if self.weights is not None and self._w_host is None:
-            # device-resident weights seen for the first time: the fold bookkeeping needs
-            # their non-zero pattern on the host before the launch
-            self._w_host = self.weights.reshape(-1).cpu().numpy()
-            if bool(np.any(self._w_host < 0)):
-                raise ValueError(MSG_NEG_W)
         batch = self.prepare_folds(folds)
         if not batch.is_partition:
             raise ValueError("fit(folds=...) needs folds that contain every row exactly once")
@@ -411,26 +422,31 @@ class CVMatrix:
     @staticmethod
     def _weights_key(w):
         if isinstance(w, torch.Tensor):
-            return (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+            return (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), w.dtype)
         return None
 
     def _check_weights_host(self, weights) -> None:
-        """Sign check + host copy of the weights (used for per-fold validity checks)."""
-        if isinstance(weights, torch.Tensor):
-            if weights.device.type == "cpu":
-                h = weights.detach().numpy().reshape(-1)
-            else:
-                key = self._weights_key(weights)
-                if key == self._w_checked and self._w_host is not None:
-                    return  # same unmodified tensor as last fit: already validated
-                self._w_host = None  # validated after the kernel via its sign flag
+        """Sign check (cvmatrix.py:1188-1189) + host copy of the weights (per-fold validity
+        checks), before anything is launched.  A device tensor costs one read-back; the SAME
+        tensor object, unmodified since the last fit (identity + version counter -- the object is
+        kept referenced so its address cannot be recycled by another tensor), is not read again."""
+        if isinstance(weights, torch.Tensor) and weights.device.type != "cpu":
+            key = self._weights_key(weights)
+            if (weights is self._w_checked_src and key == self._w_checked
+                    and self._w_host is not None):
                 return
+            h = weights.detach().reshape(-1).cpu().numpy()
+            src = weights
         else:
-            h = np.asarray(weights, dtype=self._npdt).reshape(-1)
+            if isinstance(weights, torch.Tensor):
+                weights = weights.detach().numpy()
+            h = np.asarray(weights).reshape(-1)
+            key = src = None
         if bool(np.any(h < 0)):
             raise ValueError(MSG_NEG_W)
         self._w_host = np.array(h, dtype=self._npdt, copy=True)
-        self._w_checked = None
+        self._w_checked, self._w_checked_src = key, src
+        self._w_gen += 1
 
     def _publish_stats(self) -> None:
         """Host-side totals used by the per-fold validity checks.  ``_n_total`` /
@@ -441,10 +457,14 @@ class CVMatrix:
         self._nz_total = (self.N if self.weights is None
                           else int(np.count_nonzero(self._w_host)))
 
+    def _resolve_totals(self) -> None:
+        """Hook: make ``_n_total`` / ``_nz_total`` current (multi-GPU subclasses fetch the
+        all-reduced counts here)."""
+
     def _gslice(self, lo: int, hi: int, cond: bool):
         if not cond or self._gstats is None:
             return None
-        return self._gstats[lo:hi].to(self._tdt).reshape(1, -1)
+        return self._out(self._gstats[lo:hi].to(self._tdt).reshape(1, -1), ("gstats", lo, hi))
 
     # The reference's global statistics attributes, present under the reference's flag
     # conditions (cvmatrix.py:1223-1243), materialised from the float64 device vector on
@@ -477,7 +497,11 @@ class CVMatrix:
     @property
     def num_nonzero_w(self):
         """cvmatrix.py:1226/1229; ``None`` without centre/scale flags."""
-        return self._nz_total if (self._anyflag and self.X is not None) else None
+        if not self._anyflag or self.X is None:
+            return None
+        self._ensure_fit()
+        self._resolve_totals()
+        return self._nz_total
 
     @property
     def sum_w(self):
@@ -485,6 +509,8 @@ class CVMatrix:
         if not self._anyflag or self.X is None:
             return None
         if self.weights is None:
+            self._ensure_fit()
+            self._resolve_totals()
             return self._n_total
         if self._sum_w is None:
             K, M = self.K, self.M or 0
@@ -514,6 +540,15 @@ class CVMatrix:
         if self.X is None:
             raise RuntimeError("call fit() first")
         if isinstance(folds, FoldBatch):
+            # a prepared batch is tied to the row count it was bounds-checked against (the
+            # kernels do no bounds checks) and to the weights its non-zero counts came from
+            if folds._n_rows != self.N:
+                raise ValueError(
+                    f"this FoldBatch was prepared for {folds._n_rows} samples, the fitted "
+                    f"data has {self.N}: prepare the folds again after fit()")
+            if folds._w_gen != self._w_gen:
+                folds.nz_val = self._nz_counts(folds)
+                folds._w_gen = self._w_gen
             return folds
         labels = None
         if isinstance(folds, Partitioner):
@@ -539,18 +574,7 @@ class CVMatrix:
             idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
         host_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
         np.cumsum(sizes, out=host_offsets[1:])
-        if self._w_host is not None:
-            wh = self._w_host
-            if self._nz_mask is None or self._nz_mask[0] is not wh:
-                self._nz_mask = (wh, (wh != 0).astype(np.int64))   # once per fit
-            nzmask = self._nz_mask[1]
-            if len(parts) == 1:
-                nz_val = np.array([int(nzmask[idx].sum())], dtype=np.int64)
-            else:
-                csum = np.concatenate([[0], np.cumsum(nzmask[idx])])
-                nz_val = csum[host_offsets[1:]] - csum[host_offsets[:-1]]
-        else:
-            nz_val = sizes.copy()
+        nz_val = self._nz_counts_host(idx, host_offsets, sizes)
         # one host->device copy for both arrays, [offsets | idx], through a pinned staging
         # buffer and asynchronous on the stream: a pageable copy would hold the host until the
         # device has drained the stream, and the per-fold call pattern (one small copy per
@@ -562,10 +586,12 @@ class CVMatrix:
             if len(parts) == 1:
                 # the reference's call pattern, one small fold per call: no device copy at all
                 return FoldBatch(None, None, host_offsets, nz_val, labels,
-                                 np.ascontiguousarray(idx, dtype=np.int64), self.N, device=self.device)
+                                 np.ascontiguousarray(idx, dtype=np.int64), self.N, device=self.device,
+                                 w_gen=self._w_gen)
             with torch.cuda.device(self.device):
                 d_all = torch.from_numpy(np.concatenate([host_offsets, idx])).to(self.device)
-            return FoldBatch(d_all[n_off:], d_all[:n_off], host_offsets, nz_val, labels, idx, self.N)
+            return FoldBatch(d_all[n_off:], d_all[:n_off], host_offsets, nz_val, labels, idx, self.N,
+                             w_gen=self._w_gen)
         with torch.cuda.device(self.device):
             stage = self._staging(n_all)
             view = stage.numpy()
@@ -575,7 +601,32 @@ class CVMatrix:
             d_all.copy_(stage[:n_all], non_blocking=True)
             self._stage_events[self._stage_next - 1].record()
         d_off, d_idx = d_all[:n_off], d_all[n_off:]
-        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N)
+        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N, w_gen=self._w_gen)
+
+    def _nz_counts_host(self, idx: np.ndarray, host_offsets: np.ndarray, sizes: np.ndarray) -> np.ndarray:
+        """Non-zero weights among each fold's validation rows (exact integer counts for the
+        host-side raises, cvmatrix.py:612-630, 1074-1078)."""
+        if self._w_host is None:
+            return sizes.copy()
+        wh = self._w_host
+        if self._nz_mask is None or self._nz_mask[0] is not wh:
+            self._nz_mask = (wh, (wh != 0).astype(np.int64))   # once per fit
+        nzmask = self._nz_mask[1]
+        if sizes.size == 1:
+            return np.array([int(nzmask[idx].sum())], dtype=np.int64)
+        csum = np.concatenate([[0], np.cumsum(nzmask[idx])])
+        return csum[host_offsets[1:]] - csum[host_offsets[:-1]]
+
+    def _nz_counts(self, batch: "FoldBatch") -> np.ndarray:
+        """The same counts for an existing batch (after a refit with other weights)."""
+        if batch._host_idx is not None:
+            return self._nz_counts_host(batch._host_idx, batch.host_offsets, batch.sizes)
+        if self.weights is None:
+            return batch.sizes.copy()
+        nzmask = (self.weights.reshape(-1) != 0).to(torch.int64)
+        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=self.device),
+                          torch.cumsum(nzmask[batch.idx], 0)])
+        return (csum[batch.offsets[1:]] - csum[batch.offsets[:-1]]).cpu().numpy()
 
     def prepare_folds_from_labels(self, labels, n_labels: Optional[int] = None) -> FoldBatch:
         """Device-side ``Partitioner``: one integer fold label per row (NumPy array or tensor,
@@ -631,7 +682,8 @@ class CVMatrix:
                 nz_val = (csum[d_off[1:]] - csum[d_off[:-1]]).cpu().numpy()
             else:
                 nz_val = sizes.copy()
-        return FoldBatch(d_idx, d_off, host_offsets, nz_val, [int(v) for v in order], None, self.N)
+        return FoldBatch(d_idx, d_off, host_offsets, nz_val, [int(v) for v in order], None, self.N,
+                         w_gen=self._w_gen)
 
     def _staging(self, n: int) -> torch.Tensor:
         """Next pinned int64 staging buffer of a small ring (reused once the copy that last
@@ -657,6 +709,7 @@ class CVMatrix:
         only: cvmatrix.py:612-630; then ddof: 1074-1078), decided on exact host counts."""
         if not need_stats:
             return
+        self._resolve_totals()
         if self.weights is not None:
             nz_train = self._nz_total - batch.nz_val
             if np.any(nz_train == 0):
@@ -672,6 +725,7 @@ class CVMatrix:
         ``stats_only``: keep the return flags (they select which statistics the kernel
         derives, cvmatrix.py:828-831) but produce no matrices."""
         lib = _lib.load()
+        self._ensure_fit()
         K, M, P = self.K, self.M or 0, batch.n_folds
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         if stat_flags is not None:
@@ -695,7 +749,7 @@ class CVMatrix:
                 rc = lib.cvm_sweep_folds(
                     batch.offsets.data_ptr(), P, K, M, self._cdt, flags, float(self.ddof),
                     float(self.resolution), 1 if self.weights is not None else 0,
-                    self.XTX.data_ptr(), _lib.ptr(self.XTY), self._gstats.data_ptr(),
+                    self._G.data_ptr(), _lib.ptr(self._H), self._gs.data_ptr(),
                     _lib.ptr(out_XTX), _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(),
                     _lib.ptr(muY), _lib.ptr(sdY), out_fold.data_ptr(),
                     self._sweep_ws.data_ptr(), self._sweep_ws.numel(), sweep[1], self._stream(),
@@ -716,8 +770,8 @@ class CVMatrix:
                 self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights),
                 p_idx, p_off,
                 batch.host_offsets.ctypes.data, P, self.N, K, M, self._cdt, flags,
-                float(self.ddof), float(self.resolution), self.XTX.data_ptr(),
-                _lib.ptr(self.XTY), self._gstats.data_ptr(), _lib.ptr(out_XTX),
+                float(self.ddof), float(self.resolution), self._G.data_ptr(),
+                _lib.ptr(self._H), self._gs.data_ptr(), _lib.ptr(out_XTX),
                 _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(), _lib.ptr(muY),
                 _lib.ptr(sdY), out_fold.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(),
             )
@@ -741,11 +795,12 @@ class CVMatrix:
         r_sdY = rXTY and sY
         self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY)
         xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY)
-        stats = (muX if r_muX else None, sdX if r_sdX else None,
-                 muY if r_muY else None, sdY if r_sdY else None)
+        o = self._out
+        stats = (o(muX) if r_muX else None, o(sdX) if r_sdX else None,
+                 o(muY) if r_muY else None, o(sdY) if r_sdY else None)
         if rXTX and rXTY:
-            return (xtx, xty), stats
-        return (xtx if rXTX else xty), stats
+            return (o(xtx), o(xty)), stats
+        return (o(xtx) if rXTX else o(xty)), stats
 
     # ------------------------------------------------------------------ public API
     def training_XTX_batched(self, folds):
@@ -811,8 +866,9 @@ class CVMatrix:
         # this method's own map (cvmatrix.py:570-573); surplus statistics are dropped
         _, _, (muX, sdX, muY, sdY), _ = self._run(
             batch, False, hasY, stat_flags=(r_muX, r_muY, r_sdX, r_sdY), stats_only=True)
-        return (muX if r_muX else None, sdX if r_sdX else None,
-                muY if r_muY else None, sdY if r_sdY else None)
+        o = self._out
+        return (o(muX) if r_muX else None, o(sdX) if r_sdX else None,
+                o(muY) if r_muY else None, o(sdY) if r_sdY else None)
 
     def training_statistics(self, validation_indices):
         """(mean_X, std_X, mean_Y, std_Y) of the training set; cvmatrix.py:519-574."""

@@ -41,6 +41,30 @@ def assign_folds(sizes: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(o) for o in owned]
 
 
+def shard_folds(labels, world: int, rank: int):
+    """Strong-scaling layout of ONE cross-validation over ``world`` GPUs (the
+    reference's parallel shape is a vmap over folds, benchmarks/benchmark.py:144-152): fold
+    f -> rank by ``assign_folds`` on the fold sizes; a rank holds exactly the rows its folds
+    are made of.  ``labels``: one fold label per row of the whole data set.
+
+    Returns ``(keys, rows, local_labels)``: the fold labels this rank owns (in the
+    Partitioner's first-seen order), the global row numbers it holds (ascending) and those
+    rows' fold labels -- ``Partitioner(local_labels)`` then yields this rank's folds in LOCAL
+    row numbers, in the order of ``keys``."""
+    from .partitioner import Partitioner
+
+    p = Partitioner(labels)
+    all_keys = list(p.folds_dict)
+    sizes = [p.folds_dict[k].size for k in all_keys]
+    mine = assign_folds(sizes, world)[rank]
+    keys = [all_keys[f] for f in mine]
+    rows = (np.sort(np.concatenate([p.folds_dict[k] for k in keys])) if keys
+            else np.zeros(0, dtype=np.int64))
+    lab = np.asarray(labels)
+    local_labels = lab[rows] if lab.dtype != object else np.array([labels[i] for i in rows], dtype=object)
+    return keys, rows, local_labels
+
+
 def pack_globals(G: torch.Tensor, H: Optional[torch.Tensor], gstats: torch.Tensor) -> torch.Tensor:
     """One float64 buffer [G | H | gstats] so the exchange is a single collective
     (K(K+M)+2(K+M)+2 values: 2.2 MB at K=512,M=16; 67 MB at K=4096)."""
@@ -100,7 +124,8 @@ class ShardedCVMatrix(CVMatrix):
         if mode not in ("row_sharded", "replicated"):
             raise ValueError("mode must be 'row_sharded' or 'replicated'")
         self.mode, self.group, self.src = mode, group, src
-        self._fit_weights = None
+        self._tail_host = self._tail_event = None
+        self._tail_pending = False
 
     @property
     def world(self) -> int:
@@ -116,16 +141,12 @@ class ShardedCVMatrix(CVMatrix):
     def fit(self, X, Y=None, weights=None, folds=None) -> None:
         if self.world > 1 and self.mode == "replicated" and folds is not None:
             raise ValueError("fit(folds=...) needs mode='row_sharded' (or a single process)")
-        self._fit_weights = weights
+        self._tail_pending = False
         super().fit(X, Y, weights, folds=folds)     # row_sharded: this rank's rows (and folds)
 
     def _launch_fit(self, lib) -> None:
         if self.world > 1 and self.mode == "replicated" and self.rank != self.src:
             self._neg = torch.zeros(1, dtype=torch.int32, device=self.device)
-            if self.weights is not None and self._w_host is None:
-                self._w_host = self.weights.reshape(-1).cpu().numpy()
-                if bool(np.any(self._w_host < 0)):
-                    raise ValueError("Weights must be non-negative.")
             return                                  # the broadcast fills the matrices
         super()._launch_fit(lib)
 
@@ -135,33 +156,36 @@ class ShardedCVMatrix(CVMatrix):
         super()._lazy_sweep(batch)
 
     def _after_globals(self) -> None:
-        """The one exchange of the path: sum (row-sharded) or replicate the full-data matrices."""
+        """The one exchange of the path: sum (row-sharded) or replicate the full-data matrices.
+        Every rank issues exactly this one collective per fit, whatever its local data look
+        like (no collective may depend on rank-local state)."""
         if self.world == 1:
             return
         if self.mode == "row_sharded":
             allreduce_globals(self._G, self._H, self._gs, self.group, flat=self._globals)
-            # the global counts depend on the weights and the row counts only: when the same
-            # (unmodified) device tensors are fitted again, skip the device read-back
-            key = (self._weights_key(self._fit_weights), self.N, self.world)
-            if key[0] is not None and key == getattr(self, "_totals_key", None):
-                self._n_total, self._nz_total = self._totals_val
-                self._sum_w = None
-            else:
-                self._sync_totals()
-                self._totals_key, self._totals_val = key, (self._n_total, self._nz_total)
+            # the global sample / non-zero-weight counts for the host-side validity checks
+            # (cvmatrix.py:612-630, 1074-1078) ride in the all-reduced statistics vector
+            # ([... | sw | nz]: sw = N when unweighted): fetch them without stalling ``fit`` --
+            # an asynchronous copy into pinned memory, awaited by the first check that needs them
+            K, M = self.K, self.M or 0
+            if self._tail_host is None:
+                self._tail_host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+                self._tail_event = torch.cuda.Event()
+            with torch.cuda.device(self.device):
+                self._tail_host.copy_(self._gs[2 * K + 2 * M: 2 * K + 2 * M + 2], non_blocking=True)
+                self._tail_event.record()
+            self._tail_pending = True
         else:
             broadcast_globals(self._G, self._H, self._gs, self.src, self.group, flat=self._globals)
 
-    def _sync_totals(self) -> None:
-        """Global sample / non-zero-weight counts for the host-side validity checks
-        (cvmatrix.py:612-630, 1074-1078): they ride in the all-reduced gstats."""
-        K, M = self.K, self.M or 0
-        tail = self._gs[2 * K + 2 * M : 2 * K + 2 * M + 2].cpu()
-        self._nz_total = int(round(float(tail[1])))
-        if self.weights is None:
-            self._n_total = int(round(float(tail[0])))
-        else:
-            cnt = torch.tensor([self.N], dtype=torch.int64, device=self._gs.device)
-            dist.all_reduce(cnt, group=self.group)
-            self._n_total = int(cnt.item())
+    def _resolve_totals(self) -> None:
+        if not self._tail_pending:
+            return
+        self._tail_pending = False
+        self._tail_event.synchronize()
+        sw, nz = float(self._tail_host[0]), float(self._tail_host[1])
+        self._nz_total = int(round(nz))
+        # (weighted: the sample count is never consulted -- cvmatrix.py:612-615 is the
+        #  unweighted branch)
+        self._n_total = int(round(sw)) if self.weights is None else None
         self._sum_w = None

@@ -24,7 +24,11 @@
  *     calling thread;
  *   - dtype: CVM_F64 or CVM_F32 (the reference accepts any NumPy float; f16/f128 are not
  *     offered on the device).  Column statistics are always kept in float64.
- *   - results are deterministic: no floating-point atomics, fixed-order reductions.
+ *   - results are deterministic: no floating-point atomics, fixed-order reductions;
+ *   - threads: every entry point may be called concurrently from several host threads (one
+ *     per stream / device is the intended use).  The library's only process-wide state is the
+ *     optional launch-timing recorder below (mutex-guarded) and once-per-device kernel
+ *     attributes (atomic flags); planning depends on the arguments alone.
  */
 #ifndef CVMHIP_H
 #define CVMHIP_H
@@ -58,6 +62,10 @@ extern "C" {
 #define CVM_IDX_HOST 0x40u
 
 const char *cvm_version(void);
+/* sha256 (first 16 hex digits) over the source files the library was built from, as computed by
+ * cvmatrix_amd/build.py; the Python loader refuses (or rebuilds) a library whose hash differs from
+ * the sources lying next to it. */
+const char *cvm_source_hash(void);
 const char *cvm_last_error(void);
 
 /* Number of float64 entries of the global statistics vector written by cvm_gram_fit and
@@ -171,7 +179,8 @@ int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info)
  * every launch of the Gram kernel (at most 8192 pairs between reads).  cvm_timing_read
  * waits for the recorded events, returns the summed kernel milliseconds and launch counts
  * of the fit stage and of the fold stage since the last read, and resets the list.
- * Not thread-safe; meant for bench.py only. */
+ * One recorder per process (all streams, all threads; slots are handed out under a mutex):
+ * meant for bench.py. */
 int cvm_timing_enable(int on);
 int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold);
 

@@ -37,6 +37,36 @@ def test_assign_folds_balances_and_covers():
     assert assign_folds([7, 7], 1) == [[0, 1]]
 
 
+def test_shard_folds_strong_scaling_layout():
+    """bench.py --scaling strong: ONE problem's folds dealt over the ranks; a rank holds the
+    rows of its folds, renumbered locally, and a Partitioner over its local labels yields
+    those folds in the order of its keys."""
+    from cvmatrix_amd import Partitioner
+    from cvmatrix_amd.distributed import shard_folds
+
+    N, P = 103, 10
+    labels = np.arange(N) % P
+    for world in (1, 2, 4, 8, 16):
+        seen_rows, seen_keys = [], []
+        for rank in range(world):
+            keys, rows, local = shard_folds(labels, world, rank)
+            assert list(rows) == sorted(rows) and np.array_equal(labels[rows], local)
+            assert set(np.unique(local)) == set(keys)
+            lp = Partitioner(local)
+            assert list(lp.folds_dict) == keys
+            for k in keys:     # local validation indices map back to the global fold
+                assert np.array_equal(rows[lp.get_validation_indices(k)], np.flatnonzero(labels == k))
+            seen_rows += list(rows)
+            seen_keys += keys
+        assert sorted(seen_rows) == list(range(N)) and sorted(seen_keys) == list(range(P))
+        assert max(len(shard_folds(labels, world, r)[0]) for r in range(world)) == -(-P // world)
+    # ragged folds with non-integer labels: balanced by rows, first-seen order kept
+    lab = ["a"] * 50 + ["b"] * 10 + ["c"] * 30 + ["d"] * 10
+    k0, r0, _ = shard_folds(lab, 2, 0)
+    k1, r1, _ = shard_folds(lab, 2, 1)
+    assert k0 == ["a"] and k1 == ["b", "c", "d"] and r0.size == 50 and r1.size == 50
+
+
 def test_pack_unpack_roundtrip():
     G = torch.arange(9.0, dtype=torch.float64).reshape(3, 3)
     H = torch.arange(6.0, dtype=torch.float32).reshape(3, 2)

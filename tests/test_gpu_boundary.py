@@ -1,0 +1,168 @@
+"""GPU: the drop-in boundary -- NumPy-returning mode (the reference's README loop and example
+run with only the import changed), honest fit() defaults, input validation that cannot be
+fooled by recycled device addresses, prepared fold batches that outlive a refit."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_normwise, assert_stats
+from oracle.cvmatrix_oracle import OracleCVMatrix, OraclePartitioner
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd(hip_device):
+    import cvmatrix_amd
+    from cvmatrix_amd import _lib
+
+    _lib.load()
+    return cvmatrix_amd
+
+
+def test_readme_quick_start_runs_with_numpy_results(amd):
+    """The call sequence of the reference's quick start (README.md:96-141: N=100, K=50, M=10,
+    5 folds arange(100) % 5, weights U(0,1)+0.1, all flags on; per fold training_XTX_XTY, then
+    training_XTX, then training_XTY) with output="numpy": every result is an ndarray of the
+    reference's shape and dtype and equals the oracle."""
+    CVMatrix, Partitioner = amd.CVMatrix, amd.Partitioner
+    rng = np.random.default_rng(2024)
+    N, K, M = 100, 50, 10
+    X = rng.uniform(size=(N, K))
+    Y = rng.uniform(size=(N, M))
+    folds = np.arange(100) % 5
+    weights = rng.uniform(size=(N,)) + 0.1
+    cvm = CVMatrix(center_X=True, center_Y=True, scale_X=True, scale_Y=True, output="numpy")
+    cvm.fit(X=X, Y=Y, weights=weights)
+    ref = OracleCVMatrix()
+    ref.fit(X, Y, weights)
+    p = Partitioner(folds=folds)
+    for fold in p.folds_dict:
+        val_indices = p.get_validation_indices(fold)
+        result = cvm.training_XTX_XTY(val_indices)
+        (XTWX, XTWY) = result[0]
+        stats = result[1]
+        assert all(type(a) is np.ndarray and a.dtype == np.float64 for a in (XTWX, XTWY, *stats))
+        assert XTWX.shape == (K, K) and XTWY.shape == (K, M)
+        assert stats[0].shape == stats[1].shape == (1, K) and stats[2].shape == stats[3].shape == (1, M)
+        (rx, ry), rst = ref.training_XTX_XTY(val_indices)
+        assert_normwise(XTWX, rx, 1e-10, "readme XTX")
+        assert_normwise(XTWY, ry, 1e-10, "readme XTY")
+        assert_stats(stats, rst, 1e-10, "readme stats")
+        # NumPy on the results, as the reference's callers do (tests/test_cvmatrix.py:489-490)
+        assert np.allclose(XTWX, XTWX.T) and np.isfinite(XTWY / stats[1].T).all()
+        x_only, st_x = cvm.training_XTX(val_indices)
+        assert type(x_only) is np.ndarray and st_x[2] is None and st_x[3] is None
+        np.testing.assert_allclose(x_only, XTWX, rtol=0, atol=1e-9)
+        y_only, st_y = cvm.training_XTY(val_indices)
+        assert type(y_only) is np.ndarray and all(s is not None for s in st_y)
+        np.testing.assert_allclose(y_only, XTWY, rtol=0, atol=1e-9)
+        st_only = cvm.training_statistics(val_indices)
+        assert all(type(s) is np.ndarray for s in st_only)
+    # the fitted attributes are ndarrays too (cvmatrix.py:1215-1241)
+    for a, r in ((cvm.XTX, ref.XTX), (cvm.XTY, ref.XTY), (cvm.sum_X, ref.sum_X), (cvm.sum_sq_X, ref.sum_sq_X),
+                 (cvm.sum_Y, ref.sum_Y), (cvm.sum_sq_Y, ref.sum_sq_Y)):
+        assert type(a) is np.ndarray
+        assert_normwise(a, r, 1e-12, "attribute")
+    assert cvm.XTX is cvm.XTX                       # copied once per fit
+    # batched calls follow the same switch
+    (bx, by), bst = cvm.training_XTX_XTY_batched(p)
+    assert type(bx) is np.ndarray and bx.shape == (5, K, K) and bst[0].shape == (5, 1, K)
+
+
+def test_default_fit_is_eager_for_aliased_inputs_and_lazy_for_private_copies(amd, hip_device, monkeypatch):
+    import torch
+
+    monkeypatch.delenv("CVM_LAZY_FIT", raising=False)
+    rng = np.random.default_rng(3)
+    X = torch.from_numpy(rng.random((600, 40))).to(hip_device)
+    Y = torch.from_numpy(rng.random((600, 3))).to(hip_device)
+    eager = amd.CVMatrix(copy=False)
+    eager.fit(X, Y)
+    assert not eager._pending and eager.X.data_ptr() == X.data_ptr()
+    G = eager.XTX.clone()
+    lazy = amd.CVMatrix()                       # copy=True: private copies, deferral is safe
+    lazy.fit(X, Y)
+    assert lazy._pending and lazy.X.data_ptr() != X.data_ptr()
+    X.mul_(2.0)                                 # the caller scribbles over its array after fit()
+    assert torch.equal(lazy.XTX, G)             # the lazy object computes from its own copy
+    assert torch.equal(eager.XTX, G)            # the eager one computed inside fit()
+
+
+def test_weights_are_validated_again_when_a_new_tensor_reuses_the_address(amd, hip_device):
+    """the device-weights validation cache must not be fooled by a recycled address."""
+    import torch
+
+    rng = np.random.default_rng(4)
+    N = 5000
+    X = torch.from_numpy(rng.random((N, 16))).to(hip_device)
+    m = amd.CVMatrix(copy=True)
+    hit = False
+    for _ in range(20):
+        w = torch.rand(N, dtype=torch.float64, device=hip_device)
+        addr = w.data_ptr()
+        m.fit(X, None, w)
+        m.training_XTX(np.arange(10))
+        del w
+        w2 = torch.rand(N, dtype=torch.float64, device=hip_device)
+        w2[7] = -1.0
+        w2 = w2.clone() if w2.data_ptr() != addr else w2      # whatever address it got
+        hit = hit or (w2.data_ptr() == addr)
+        with pytest.raises(ValueError, match="Weights must be non-negative."):
+            m.fit(X, None, w2)
+        del w2
+    # the same unmodified tensor object IS recognised (no second read-back) ...
+    w = torch.rand(N, dtype=torch.float64, device=hip_device)
+    m.fit(X, None, w)
+    host = m._w_host
+    m.fit(X, None, w)
+    assert m._w_host is host
+    # ... until it is modified in place
+    w[3] = -2.0
+    with pytest.raises(ValueError, match="Weights must be non-negative."):
+        m.fit(X, None, w)
+
+
+def test_fold_batch_is_checked_against_the_fit_it_is_used_with(amd):
+    """a prepared FoldBatch used after a refit -- other row count: refused; other
+    weights: its non-zero counts are recomputed, so the reference's raises stay right."""
+    rng = np.random.default_rng(5)
+    X, Y = rng.random((400, 12)), rng.random((400, 2))
+    w = rng.random(400)
+    m = amd.CVMatrix(ddof=1)
+    m.fit(X, Y, w)
+    folds = [np.arange(0, 200), np.arange(200, 400)]
+    batch = m.prepare_folds(folds)
+    m.training_XTX_XTY_batched(batch)
+    m.fit(X[:300], Y[:300], w[:300])
+    with pytest.raises(ValueError, match="prepared for 400 samples"):
+        m.training_XTX_XTY_batched(batch)
+    # refit with weights that are zero outside fold 0: fold 1's training set = fold 0 keeps weights,
+    # fold 0's training set has none -> the reference's message (cvmatrix.py:626-629)
+    w2 = w.copy()
+    w2[200:] = 0.0
+    m.fit(X, Y, w2)
+    with pytest.raises(ValueError, match="greater than zero"):
+        m.training_XTX_XTY_batched(batch)
+    ref = OracleCVMatrix()
+    ref.fit(X, Y, w2)
+    with pytest.raises(ValueError, match="greater than zero"):
+        ref.training_XTX_XTY(folds[0])
+    # and back: the same batch is fine again with the first weights
+    m.fit(X, Y, w)
+    (bx, by), st = m.training_XTX_XTY_batched(batch)
+    ref.fit(X, Y, w)
+    (rx, ry), rst = ref.training_XTX_XTY(folds[1])
+    assert_normwise(bx[1], rx, 1e-10, "batch reuse")
+
+
+def test_fit_that_raises_leaves_no_pending_state(amd):
+    rng = np.random.default_rng(6)
+    m = amd.CVMatrix(lazy_fit=True)
+    m.fit(rng.random((300, 8)), rng.random((300, 2)))
+    assert m._pending
+    with pytest.raises(ValueError):
+        m.fit(rng.random((100, 8)), rng.random((90, 2)))          # row mismatch, raised after X is stored
+    assert not m._pending and m._sweep is None

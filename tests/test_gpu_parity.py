@@ -929,6 +929,43 @@ def test_two_ranks_share_one_gpu(amd, tmp_path, mode):
     assert (tmp_path / f"ok_{mode}_0").exists() and (tmp_path / f"ok_{mode}_1").exists()
 
 
+@pytest.mark.parametrize("mode,path", [("row_sharded", "sweep"), ("replicated", "sweep"),
+                                       ("row_sharded", "two_stage")])
+def test_bench_command_two_ranks_strong_scaling(amd, mode, path):
+    """The driver's multi-GPU command line, end to end: `python -m torch.distributed.run
+    --nproc-per-node 2 bench.py --gpus 2 ...` (gloo rendezvous, both ranks on cuda:0 -- a
+    1-GPU box; the 8-GPU node runs the same command over RCCL).  Strong scaling: the folds
+    of ONE problem dealt over the ranks; the JSON line names the same global workload as the
+    single-process run and carries the in-run parity gate (a fold recomputed from scratch)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29900 + (os.getpid() % 1000) + {"row_sharded": 0, "replicated": 3}[mode] + (5 if path != "sweep" else 0)
+    common = ["--rows", "4000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--mode", mode,
+              "--path", path]
+    two = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+         "--gpus", "2", *common], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *common], env=env,
+                         cwd=root, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    for line, n in ((line1, 1), (line2, 2)):
+        assert line["n_gpus"] == n and line["scaling"] == "strong" and line["unit"] == "folds/s"
+        assert line["parity"].startswith("ok"), line["parity"]
+        assert line["roofline"]["bound"] == "mfma" and line["value"] > 0
+    # the same global problem on both lines
+    assert line1["metric"] == line2["metric"]
+    assert line1["config"]["workload"] == line2["config"]["workload"]
+    assert line2["scaling_ceiling_vs_1gpu"] == 2.0 and line1["scaling_ceiling_vs_1gpu"] == 1.0
+
+
 @pytest.mark.parametrize("K,M,route", [(4, 1, "units"), (64, 3, "units"), (132, 1, "units"), (260, 34, "units"),
                                        (516, 16, "units"), (128, 5, "many"), (388, 0, "many"), (130, 2, "units")])
 def test_float32_shape_sweep(amd, K, M, route):

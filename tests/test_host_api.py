@@ -72,8 +72,42 @@ def test_constructor_surface_and_errors():
     assert CVMatrix().resolution == np.finfo(np.float64).resolution * 10  # ~1e-14
     assert m.X is None and m.XTX is None and m.sum_X is None and m.sum_w is None
     for bad in ("numpy", "jax", "tpu"):
-        with pytest.raises(ValueError, match="Invalid backend"):
+        # same form as the reference's message (cvmatrix.py:96)
+        with pytest.raises(ValueError) as ei:
             CVMatrix(backend=bad)
+        assert str(ei.value) == f"Invalid backend: {bad!r}. Must be 'hip'."
+    with pytest.raises(ValueError, match="Invalid output"):
+        CVMatrix(output="jax")
+    assert CVMatrix(output="numpy").output == "numpy" and CVMatrix().output == "torch"
+
+
+def test_lazy_fit_default_follows_copy(monkeypatch):
+    """fit() may defer its arithmetic only when the object owns private copies of its inputs
+    (copy=True, the reference's default); copy=False aliases caller memory and computes in
+    fit() like cvmatrix.py:325-328.  CVM_LAZY_FIT overrides, an explicit argument wins."""
+    monkeypatch.delenv("CVM_LAZY_FIT", raising=False)
+    assert CVMatrix().lazy_fit is True and CVMatrix(copy=False).lazy_fit is False
+    assert CVMatrix(copy=False, lazy_fit=True).lazy_fit is True
+    assert CVMatrix(copy=True, lazy_fit=False).lazy_fit is False
+    monkeypatch.setenv("CVM_LAZY_FIT", "0")
+    assert CVMatrix().lazy_fit is False and CVMatrix(lazy_fit=True).lazy_fit is True
+    monkeypatch.setenv("CVM_LAZY_FIT", "1")
+    assert CVMatrix(copy=False).lazy_fit is True
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """cvm_source_hash() == sha256 of csrc/* + include/cvmhip.h + flags as build.py computes it:
+    the binary the tests load is the committed source (the loader rebuilds or refuses otherwise)."""
+    from cvmatrix_amd import build
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    lib = _lib.load()
+    want = build.source_hash()
+    assert lib.cvm_source_hash().decode() == want == build._embedded_hash_without_loading()
+    assert want in lib.cvm_version().decode() and len(want) == 16
     for bad in (np.float16, np.longdouble, np.int32):
         with pytest.raises(TypeError):
             CVMatrix(dtype=bad)
