@@ -19,9 +19,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <atomic>
+#include <functional>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/cvmhip.h"
 
@@ -58,7 +63,7 @@ size_t cvm_gstats_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 2; 
 
 size_t cvm_fit_workspace_bytes(int64_t N, int K, int M, int dtype) {
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
-  return (size_t)choose_splits(1, N, g, target_wg(K, M, dtype == CVM_F64 ? 8 : 4)) * g.unit_bytes;
+  return (size_t)plan_stride(1, N, g, dtype == CVM_F64 ? 8 : 4) * g.unit_bytes;
 }
 
 int cvm_gram_fit(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
@@ -84,7 +89,7 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
     return (size_t)nb * fstat_len(K, M) * 8;
   }
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, !(flags & CVM_RET_XTX));
-  const int splits = choose_splits(n_folds, max_fold_rows, g, target_wg(K, M, dtype == CVM_F64 ? 8 : 4));
+  const int splits = plan_stride(n_folds, max_fold_rows, g, dtype == CVM_F64 ? 8 : 4);
   const size_t per_fold = (size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256);
   size_t want = per_fold * (size_t)(n_folds > 0 ? n_folds : 1);
   const size_t cap = (size_t)8 << 30;   // beyond 8 GiB walk the folds in batches
@@ -156,7 +161,7 @@ int cvm_debug_stamps2(unsigned long long *host_out) {
 
 size_t cvm_sweep_workspace_bytes(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype) {
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
-  const int splits = choose_splits(n_folds, max_fold_rows, g, target_wg(K, M, dtype == CVM_F64 ? 8 : 4));
+  const int splits = plan_stride(n_folds, max_fold_rows, g, dtype == CVM_F64 ? 8 : 4);
   return ((size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256)) * (size_t)(n_folds > 0 ? n_folds : 1);
 }
 
@@ -270,8 +275,13 @@ int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtyp
   const bool fold_mode = (flags & 0x80000000u) == 0;   // bit 31 set: plan the fit stage
   int rc = make_plan(n_folds, max_fold_rows, K, M, dtype, flags & 0x7fffffffu, ws_bytes, fold_mode, p);
   if (rc != CVM_OK) return fail(rc, "cvm_plan_fold: workspace too small%s");
-  info[0] = p.splits;
-  info[1] = (int64_t)p.folds_per_batch * p.splits * p.g.nT;
+  info[0] = p.s_off;
+  {
+    const int per0 = p.g.diag_only ? 0 : p.g.nTiles - p.g.P, per1 = p.g.P * p.g.Yc;
+    info[1] = (int64_t)p.folds_per_batch * ((int64_t)p.s_off * per0 + (int64_t)p.s_diag * per1);
+  }
+  info[6] = p.s_diag;
+  info[7] = p.splits;
   info[2] = p.g.P;
   info[3] = p.g.nT;
   info[4] = p.folds_per_batch;

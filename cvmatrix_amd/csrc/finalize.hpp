@@ -8,7 +8,9 @@
 // ----------------------------------------------------------------------------------
 struct FinArgs {
   Geom g;
-  int splits;
+  int splits;           // slot stride of the partial workspace: unit (seg, sp) = seg * splits + sp
+  int s_off, s_diag;    // row splits of the off-diagonal tiles / of everything else (WgramArgs)
+  int n_sum;            // fit mode: segments whose partials are summed (1; the sweep: every fold)
   int n_seg;            // segments (folds) in this batch
   int64_t seg0;         // first fold of the batch (for output addressing)
   const char *ws;       // unit partials
@@ -25,6 +27,12 @@ struct FinArgs {
   int gx, gy;           // apply_kernel<.., true>: sub-tiles + panels, folds of the launch
 };
 __host__ __device__ inline size_t fstat_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 4; }
+
+// q-th partial of a class with `nsp` splits per segment, segment-major: its unit slot
+__device__ __forceinline__ long sum_unit(int q, int nsp, int stride) {
+  const int sg = q / nsp;
+  return (long)sg * stride + (q - sg * nsp);
+}
 
 // column chunks (grid.y) of fold_stats_kernel: enough workgroups to fill the chip when there are
 // few folds and many columns, one when there are many folds
@@ -50,14 +58,15 @@ __device__ __forceinline__ void fit_stats_columns(const FinArgs &a, double *gsta
     // in split order; sixteen loads in flight at a time (the chain of adds stays sequential)
     double s = 0;
     int p = 0;
-    for (; p + 16 <= a.splits; p += 16) {
+    const int np = a.n_sum * a.s_diag;     // (the column sums come from the diagonal items)
+    for (; p + 16 <= np; p += 16) {
       double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = unit_stats<T>((char *)a.ws, g, p + u)[src];
+      for (int u = 0; u < 16; ++u) v[u] = unit_stats<T>((char *)a.ws, g, sum_unit(p + u, a.s_diag, a.splits))[src];
 #pragma unroll
       for (int u = 0; u < 16; ++u) s += v[u];
     }
-    for (; p < a.splits; ++p) s += unit_stats<T>((char *)a.ws, g, p)[src];
+    for (; p < np; ++p) s += unit_stats<T>((char *)a.ws, g, sum_unit(p, a.s_diag, a.splits))[src];
     if (c < total - 1) gstats[c] = s;
     else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
   }
@@ -76,7 +85,7 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
   const long u0 = (long)f * a.splits;
   double swv = 0, nzv = 0;
   if (weighted) {
-    for (int p = 0; p < a.splits; ++p) {
+    for (int p = 0; p < a.s_diag; ++p) {
       const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
       swv += st[2 * g.Kp + 2 * g.Mp + 0];
       nzv += st[2 * g.Kp + 2 * g.Mp + 1];
@@ -108,7 +117,7 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
     const int q_src = isX ? g.Kp + cc : 2 * g.Kp + g.Mp + cc;
     double sv = 0, qv = 0;
 #pragma unroll 4
-    for (int p = 0; p < a.splits; ++p) {
+    for (int p = 0; p < a.s_diag; ++p) {
       const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
       sv += st[s_src]; qv += st[q_src];
     }
@@ -376,13 +385,20 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     // UP splits' pieces requested before the first is added (fit mode runs on few workgroups:
     // it needs the loads of several splits in flight per thread)
     constexpr int UP = FOLD ? 2 : 8;
+    // the partials of this tile: one per row split of its class (fold mode: of this fold; fit
+    // mode: of every summed segment, segment-major)
+    const int nsp = (ti == tj) ? a.s_diag : a.s_off;
+    const int np = FOLD ? nsp : a.n_sum * nsp;
+    auto slot = [&](int q) -> size_t { return (size_t)(FOLD ? (long)q : sum_unit(q, nsp, a.splits)) * g.unit_bytes; };
     int p = 0;
-    for (; p + UP <= a.splits; p += UP) {
+    for (; p + UP <= np; p += UP) {
       vld_t qv[UP][NQ];
 #pragma unroll
-      for (int u = 0; u < UP; ++u)
+      for (int u = 0; u < UP; ++u) {
+        const size_t so = slot(p + u);
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)(p + u) * g.unit_bytes);
+        for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + so);
+      }
 #pragma unroll
       for (int u = 0; u < UP; ++u)
 #pragma unroll
@@ -390,10 +406,11 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
 #pragma unroll
           for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[u][j][e];
     }
-    for (; p < a.splits; ++p) {
+    for (; p < np; ++p) {
       vld_t qv[NQ];
+      const size_t so = slot(p);
 #pragma unroll
-      for (int j = 0; j < NQ; ++j) qv[j] = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)p * g.unit_bytes);
+      for (int j = 0; j < NQ; ++j) qv[j] = *reinterpret_cast<const vld_t *>(pp[j] + so);
 #pragma unroll
       for (int j = 0; j < NQ; ++j)
 #pragma unroll
@@ -422,8 +439,10 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
       if (ga >= K) continue;
       double v = 0;
       const char *pp = ws0 + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
+      const int np = FOLD ? a.s_diag : a.n_sum * a.s_diag;
 #pragma unroll 4
-      for (int p = 0; p < a.splits; ++p) v += (double)*reinterpret_cast<const T *>(pp + (size_t)p * g.unit_bytes);
+      for (int p = 0; p < np; ++p)
+        v += (double)*reinterpret_cast<const T *>(pp + (size_t)(FOLD ? (long)p : sum_unit(p, a.s_diag, a.splits)) * g.unit_bytes);
       if (FOLD) {
         v = (double)Ht[(size_t)ga * M + m] - v;
         if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
@@ -483,13 +502,17 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
       for (int e = 0; e < VW; ++e) v[j][e] = 0;
     }
     constexpr int UP = 8;                            // splits requested before the first is added
+    const int nsp = (ti == tj) ? a.s_diag : a.s_off;
+    const int np = a.n_sum * nsp;                    // segment-major, split order within a segment
     int p = 0;
-    for (; p + UP <= a.splits; p += UP) {
+    for (; p + UP <= np; p += UP) {
       vld_t qv[UP][NQ];
 #pragma unroll
-      for (int u = 0; u < UP; ++u)
+      for (int u = 0; u < UP; ++u) {
+        const size_t so = (size_t)sum_unit(p + u, nsp, a.splits) * g.unit_bytes;
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)(p + u) * g.unit_bytes);
+        for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + so);
+      }
 #pragma unroll
       for (int u = 0; u < UP; ++u)
 #pragma unroll
@@ -497,10 +520,11 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
 #pragma unroll
           for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[u][j][e];
     }
-    for (; p < a.splits; ++p) {
+    for (; p < np; ++p) {
+      const size_t so = (size_t)sum_unit(p, nsp, a.splits) * g.unit_bytes;
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
-        const vld_t qv = *reinterpret_cast<const vld_t *>(pp[j] + (size_t)p * g.unit_bytes);
+        const vld_t qv = *reinterpret_cast<const vld_t *>(pp[j] + so);
 #pragma unroll
         for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[e];
       }
@@ -564,14 +588,16 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
       double s = 0;
       const char *pp = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
       int p = 0;
-      for (; p + 8 <= a.splits; p += 8) {
+      const int np = a.n_sum * a.s_diag;
+      for (; p + 8 <= np; p += 8) {
         T t8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t8[u] = *reinterpret_cast<const T *>(pp + (size_t)(p + u) * g.unit_bytes);
+        for (int u = 0; u < 8; ++u)
+          t8[u] = *reinterpret_cast<const T *>(pp + (size_t)sum_unit(p + u, a.s_diag, a.splits) * g.unit_bytes);
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += (double)t8[u];
       }
-      for (; p < a.splits; ++p) s += (double)*reinterpret_cast<const T *>(pp + (size_t)p * g.unit_bytes);
+      for (; p < np; ++p) s += (double)*reinterpret_cast<const T *>(pp + (size_t)sum_unit(p, a.s_diag, a.splits) * g.unit_bytes);
       out[(size_t)ga * M + m] = (T)s;
     }
   }

@@ -74,15 +74,28 @@ Geom make_geom(int K, int M, int esize, int diag_only) {
   return g;
 }
 
+// Work items of a Gram launch.  A segment (a fold, or all rows in the fit stage) is cut into row
+// splits; unit u = seg * splits + sp owns one slot of the partial workspace.  The items of a unit
+// come in two CLASSES with their own split counts, because they cost differently per row:
+//   class 0  off-diagonal 128x128 tiles (i < j): 16 MFMAs per wave and k-step; rows cut s_off ways
+//   class 1  diagonal tiles with the first Y chunk (9 + 2 MFMAs per wave and k-step in the LDS-DMA
+//            kernel, they also produce XTY and the column sums) and the further Y chunks;
+//            rows cut s_diag ways
+// `splits` = max(s_off, s_diag) is the slot stride; class-0 partials exist for sp < s_off, class-1
+// partials (diagonal tiles, XTY panels, column sums) for sp < s_diag.  The grid lists all class-0
+// items first, then all class-1 items (longest first: the hardware hands workgroups to free CUs in
+// order), each list spread over the 8 XCDs in contiguous ranges.
 template <typename T> struct WgramArgs {
   const T *X, *Y, *w;
   const int64_t *idx;   // nullptr: rows are offs[seg]..offs[seg+1] themselves
   const int64_t *offs;  // device; nullptr: one segment [0, N)
   int64_t N;
   int64_t seg0;         // first segment of this batch
-  int n_seg, splits;
+  int n_seg, splits;    // splits: slot stride = max(s_off, s_diag)
+  int s_off, s_diag;
   Geom g;
-  long n_items, items_per_xcd;
+  long n_items0, ipx0;  // class 0: items, items per XCD
+  long n_items1, ipx1;  // class 1
   char *ws;             // unit u at ws + u*unit_bytes
   // fused single-split fold update (wgram4_kernel<.., FUSED>): finish in the epilogue
   const double *fstats; // per fold of the batch: means / stds / sw_train (fold_stats_kernel)
@@ -112,22 +125,28 @@ __device__ __forceinline__ long long uni64(long long v) {
 }
 template <typename P> __device__ __forceinline__ P *unip(P *p) { return (P *)uni64((long long)p); }
 // The launch arguments of the Gram kernels, read where they are needed: the out-of-line wave-role
-// functions take NO parameters and fetch the kernel's one argument (a WgramArgs<T> at offset 0 of
-// the kernarg segment) through the kernarg segment pointer -- scalar loads from constant memory
-// into SGPRs.  (Passing the struct to a __noinline__ function by reference made the kernel spill
-// it to 224-232 bytes of private memory per lane and every role reload it with flat loads.)
-template <typename T> __device__ __forceinline__ WgramArgs<T> kernel_args() {
-  typedef const __attribute__((address_space(4))) WgramArgs<T> *kptr_t;
-  kptr_t r = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+// functions receive the ADDRESS of the kernel's one argument (a WgramArgs<T> at offset 0 of the
+// kernarg segment, constant address space) and load the fields with scalar loads into SGPRs.
+// (Passing the struct itself to a __noinline__ function by reference made the kernel spill it to
+// 224-232 bytes of private memory per lane and every role reload it with flat loads.  The kernarg
+// pointer intrinsic itself only works inside the kernel function: a callee gets null.)
+template <typename T> using kargs_ptr = const __attribute__((address_space(4))) WgramArgs<T> *;
+template <typename T> __device__ __forceinline__ kargs_ptr<T> kernarg_address() {
+  return (kargs_ptr<T>)__builtin_amdgcn_kernarg_segment_ptr();
+}
+template <typename T> __device__ __forceinline__ WgramArgs<T> kernel_args(kargs_ptr<T> rv) {
+  // the pointer arrives in vector registers (function argument): make it scalar again
+  kargs_ptr<T> r = (kargs_ptr<T>)(unsigned long long)uni64((long long)(unsigned long long)rv);
   WgramArgs<T> a;
   a.X = r->X; a.Y = r->Y; a.w = r->w; a.idx = r->idx; a.offs = r->offs;
   a.N = r->N; a.seg0 = r->seg0; a.n_seg = r->n_seg; a.splits = r->splits;
+  a.s_off = r->s_off; a.s_diag = r->s_diag;
   a.g.K = r->g.K; a.g.M = r->g.M; a.g.P = r->g.P; a.g.Kp = r->g.Kp;
   a.g.Yc = r->g.Yc; a.g.Mp = r->g.Mp; a.g.nTiles = r->g.nTiles; a.g.nT = r->g.nT;
   a.g.diag_only = r->g.diag_only;
   a.g.tile_elems = r->g.tile_elems; a.g.h_elems = r->g.h_elems;
   a.g.stat_len = r->g.stat_len; a.g.unit_bytes = r->g.unit_bytes;
-  a.n_items = r->n_items; a.items_per_xcd = r->items_per_xcd;
+  a.n_items0 = r->n_items0; a.ipx0 = r->ipx0; a.n_items1 = r->n_items1; a.ipx1 = r->ipx1;
   a.ws = r->ws; a.dbg = r->dbg;
   a.fstats = r->fstats; a.G = r->G; a.H = r->H;
   a.out_XTX = r->out_XTX; a.out_XTY = r->out_XTY; a.flags = r->flags;
@@ -142,6 +161,55 @@ __device__ __forceinline__ void decode_tile(int t, int P, int &ti, int &tj) {
 }
 __host__ __device__ __forceinline__ int tile_id(int i, int j, int P) {
   return i * P - i * (i - 1) / 2 + (j - i);
+}
+
+// k-th strictly-upper tile in row-major order: (0,1),(0,2)..(0,P-1),(1,2)...
+__device__ __forceinline__ void decode_off_tile(int k, int P, int &ti, int &tj) {
+  int i = 0, rem = k;
+  while (rem >= P - 1 - i) { rem -= P - 1 - i; ++i; }
+  ti = i; tj = i + 1 + rem;
+}
+
+// Which work item a workgroup owns (see WgramArgs).  Returns false for the padding workgroups of
+// the grid.  `it`: the item's tile slot in the unit's partials (G tiles), `nsp`: the split count
+// of its class.
+struct Item { int seg, sp, nsp, it, ti, tj, yc; long u; };
+template <typename T> __device__ __forceinline__ bool decode_item(const WgramArgs<T> &a, long b, Item &o) {
+  const Geom &g = a.g;
+  const long b0 = 8 * a.ipx0;
+  long item, cu;   // cu: unit number within the class (seg * nsp + sp)
+  int k;
+  if (b < b0) {
+    if ((b >> 3) >= a.ipx0) return false;
+    item = (b & 7) * a.ipx0 + (b >> 3);
+    if (item >= a.n_items0) return false;
+    const int per = g.nTiles - g.P;
+    cu = item / per; k = (int)(item - cu * per);
+    o.nsp = a.s_off;
+    decode_off_tile(k, g.P, o.ti, o.tj);
+    o.yc = 0;
+    o.it = tile_id(o.ti, o.tj, g.P);
+  } else {
+    const long bb = b - b0;
+    if ((bb >> 3) >= a.ipx1) return false;
+    item = (bb & 7) * a.ipx1 + (bb >> 3);
+    if (item >= a.n_items1) return false;
+    const int per = g.P * g.Yc;                 // P first-chunk items, then P * (Yc - 1) further chunks
+    cu = item / per; k = (int)(item - cu * per);
+    o.nsp = a.s_diag;
+    if (g.diag_only) { o.ti = o.tj = k / g.Yc; o.yc = k - o.ti * g.Yc; }
+    else if (k < g.P) { o.ti = o.tj = k; o.yc = 0; }
+    else { const int e = k - g.P; o.ti = o.tj = e / (g.Yc - 1); o.yc = 1 + e - o.ti * (g.Yc - 1); }
+    o.it = tile_id(o.ti, o.ti, g.P);
+  }
+  o.seg = (int)(cu / o.nsp);
+  o.sp = (int)(cu - (long)o.seg * o.nsp);
+  // wave-uniform by construction (the 64-bit divisions run on the VALU): say so, the loader waves
+  // want every address in scalar registers
+  o.seg = uni(o.seg); o.sp = uni(o.sp); o.nsp = uni(o.nsp); o.it = uni(o.it);
+  o.ti = uni(o.ti); o.tj = uni(o.tj); o.yc = uni(o.yc);
+  o.u = (long)o.seg * a.splits + o.sp;
+  return true;
 }
 
 // rows of segment `seg` handled by split `sp`

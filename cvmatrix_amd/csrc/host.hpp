@@ -40,57 +40,174 @@ inline void attr_set(std::atomic<unsigned long long> &done, int dev) {
 
 struct Plan {
   Geom g;
-  int splits;
+  int splits;            // slot stride of the partial workspace = max(s_off, s_diag)
+  int s_off, s_diag;     // row splits of the off-diagonal tiles / of the diagonal-class items
   int64_t folds_per_batch;
   size_t fstat_bytes_per_fold;
 };
 
-// Row splits per segment.  Model: TARGET_WG workgroups are resident at a time and take
-// equal time, so W = items*splits workgroups cost ceil(W/TARGET_WG) rounds; pick the split
-// count with the best fill, lightly preferring fewer splits (less partial traffic).
-int choose_splits(int64_t n_seg, int64_t max_rows, const Geom &g, int TARGET_WG) {
-  const int64_t items = (n_seg > 0 ? n_seg : 1) * g.nT;
+// which Gram kernel variant a problem gets (pointers from torch are 256-byte aligned; a
+// misaligned X falls back to the register path at launch: same plan, it only balances less well)
+bool fast_shape(int K, int M, int esize) {
+  return ((size_t)K * esize) % 16 == 0 && (esize == 4 || M % 2 == 0);
+}
+
+// ---- row splits ---------------------------------------------------------------------------
+// The launch is a list of work items (geometry.hpp: all off-diagonal-tile items, then the
+// diagonal-class items) that the hardware hands to free CUs in order; TARGET_WG workgroups are
+// resident at a time (one 8-wave workgroup per CU).  An item costs its 16-row stages times the
+// per-stage cost of its kind plus a fixed prologue/epilogue (~6 stages: pipeline fill, partial
+// store).  Per-stage costs, in units of an off-diagonal tile's stage (16 MFMAs per wave and
+// k-step): a diagonal tile in the LDS-DMA kernel issues 9 + 2*NBY (the upper triangle of its 8x8
+// grid of MFMA tiles shared out evenly + XTY), a further-Y-chunk item keeps one wave busy with 16;
+// in the general kernel every wave of every item runs the same loop.
+// Because the two classes cost differently they get their own split counts: at C3 (10 folds x
+// (6 off-diagonal + 4 diagonal tiles)) 4 and 7 give 240 long + 280 short items that pack 256 CUs
+// to 93 % -- any common count leaves a second round of workgroups a quarter empty.
+// The estimate is a simulation of that in-order hand-out, evaluated for a few hundred
+// (s_off, s_diag) candidates and cached per shape.
+struct SplitKey {
+  int64_t n_seg, max_rows; int K, M, esize, diag_only, target; int64_t cap;
+  bool operator<(const SplitKey &o) const {
+    return std::tie(n_seg, max_rows, K, M, esize, diag_only, target, cap) <
+           std::tie(o.n_seg, o.max_rows, o.K, o.M, o.esize, o.diag_only, o.target, o.cap);
+  }
+};
+struct SplitChoice { int s_off, s_diag; };
+
+double simulate_launch(int64_t n_seg, int64_t max_rows, const Geom &g, int s_off, int s_diag, double c_diag,
+                       int target) {
+  const int nOff = g.diag_only ? 0 : g.nTiles - g.P;
+  const int nFirst = g.diag_only ? 0 : g.P;                 // diagonal tiles with the first Y chunk
+  const int nY = g.diag_only ? g.P * g.Yc : g.P * (g.Yc - 1); // XTY-only items (one busy wave, 16 MFMAs)
+  auto stages_of = [&](int s) {
+    int64_t per = (max_rows + s - 1) / s;
+    return (double)((per + STAGE_ROWS - 1) / STAGE_ROWS);
+  };
+  const double fixed = 6.0;
+  const double c_off = stages_of(s_off) + fixed;
+  const double c_first = stages_of(s_diag) * c_diag + fixed, c_y = stages_of(s_diag) + fixed;
+  // in-order hand-out to `target` CUs: a min-heap of the CUs' free times
+  std::vector<double> heap((size_t)target, 0.0);
+  auto run = [&](int64_t count, double cost) {
+    for (int64_t i = 0; i < count; ++i) {
+      std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
+      heap.back() += cost;
+      std::push_heap(heap.begin(), heap.end(), std::greater<double>());
+    }
+  };
+  const int64_t u_off = n_seg * s_off, u_diag = n_seg * s_diag;
+  // (the items of one unit are adjacent in the list; with equal costs per class the order within
+  //  a class does not matter to the estimate)
+  run(u_off * nOff, c_off);
+  // class 1: per unit nFirst items of c_first and nY of c_y, interleaved unit by unit
+  if (nY == 0) run(u_diag * nFirst, c_first);
+  else if (nFirst == 0) run(u_diag * nY, c_y);
+  else for (int64_t u = 0; u < u_diag; ++u) { run(nFirst, c_first); run(nY, c_y); }
+  double t = 0;
+  for (double v : heap) t = v > t ? v : t;
+  return t;
+}
+
+SplitChoice choose_splits2(int64_t n_seg, int64_t max_rows, const Geom &g, int esize, int target) {
+  if (n_seg < 1) n_seg = 1;
   int64_t cap = max_rows / 64;                       // >= 64 rows per split
-  const int64_t mem_cap = (int64_t)(((size_t)3 << 30) / ((size_t)(n_seg > 0 ? n_seg : 1) * g.unit_bytes));
+  const int64_t mem_cap = (int64_t)(((size_t)3 << 30) / ((size_t)n_seg * g.unit_bytes));
   if (cap > mem_cap) cap = mem_cap;
   if (cap > 64) cap = 64;
   if (cap < 1) cap = 1;
-  // estimated launch time in 16-row stages: rounds of workgroups x (stages of one split + a
-  // fixed per-workgroup cost: prologue, epilogue, partial store ~ 6 stages); fewest splits on
-  // near-ties (less partial traffic; one split per fold also lets the float64 kernel finish
-  // folds in its epilogue)
-  int best = 1;
-  double best_score = 1e300;
-  for (int64_t s = 1; s <= cap; ++s) {
-    const int64_t W = items * s;
-    const int64_t rounds = (W + TARGET_WG - 1) / TARGET_WG;
-    const int64_t stages = ((max_rows + s - 1) / s + STAGE_ROWS - 1) / STAGE_ROWS;
-    const double score = (double)rounds * (double)(stages + 6) + 0.5 * (double)s;
-    if (score < best_score) { best_score = score; best = (int)s; }
+  // CVM_FORCE_SPLITS="s_off,s_diag": experiments (tools/) pin the plan; clamped to the caps
+  static const char *force = getenv("CVM_FORCE_SPLITS");
+  if (force && !g.diag_only && g.nTiles > g.P) {
+    int so = 0, sd = 0;
+    if (sscanf(force, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1)
+      return SplitChoice{(int)(so > cap ? cap : so), (int)(sd > cap ? cap : sd)};
   }
+  static std::mutex mu;
+  static std::map<SplitKey, SplitChoice> cache;
+  const SplitKey key{n_seg, max_rows, g.K, g.M, esize, g.diag_only, target, cap};
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
+  const bool fast = fast_shape(g.K, g.M, esize);
+  const double c_diag = fast ? (9.0 + 2.0 * (g.M > 16 ? 2 : 1)) / 16.0 : 1.0;
+  const int64_t items1 = n_seg * (int64_t)g.nT;
+  SplitChoice best{1, 1};
+  double best_score = 1e300;
+  auto consider = [&](int so, int sd) {
+    if (so < 1 || sd < 1 || so > cap || sd > cap) return;
+    // fewest splits on near-ties: less partial traffic, and one split per fold lets the float64
+    // kernel finish folds in its epilogue
+    const double score = simulate_launch(n_seg, max_rows, g, so, sd, c_diag, target) + 0.5 * (so > sd ? so : sd);
+    if (score < best_score - 1e-9) { best_score = score; best = SplitChoice{so, sd}; }
+  };
+  if (items1 >= 8 * (int64_t)target || g.diag_only || g.nTiles == g.P) {
+    // many rounds of workgroups (or a single class): the tail is a small part of the launch
+    for (int sx = 1; sx <= cap && sx <= 8; ++sx) consider(sx, sx);
+  } else {
+    static const double ratios[] = {0.5, 0.6, 0.6875, 0.75, 0.875, 1.0, 1.25, 1.4, 1.5, 1.75, 2.0};
+    for (int so = 1; so <= cap; ++so) {
+      if ((int64_t)so * items1 > 16 * (int64_t)target && so > 1) break;   // far more rounds than needed
+      int last = 0;
+      for (double r : ratios) {
+        int sd = (int)(so * r + 0.5);
+        if (sd < 1) sd = 1;
+        if (sd == last) continue;
+        last = sd;
+        consider(so, sd);
+      }
+    }
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  if (cache.size() > 4096) cache.clear();
+  cache[key] = best;
   return best;
 }
 
-// which Gram kernel variant a problem gets (pointers from torch are 256-byte aligned; a
-// misaligned X falls back to the register path at launch, only the split heuristic differs)
-int target_wg(int K, int M, int esize) {
-  const bool fastshape = ((size_t)K * esize) % 16 == 0 && (esize == 4 || M % 2 == 0);
-  return fastshape ? TARGET_WG_2 : TARGET_WG_1;
+int target_wg(int K, int M, int esize) { return fast_shape(K, M, esize) ? TARGET_WG_2 : TARGET_WG_1; }
+
+// partial slots per segment the plan of a problem needs (workspace sizing)
+int plan_stride(int64_t n_seg, int64_t max_rows, const Geom &g, int esize) {
+  const SplitChoice c = choose_splits2(n_seg, max_rows, g, esize, target_wg(g.K, g.M, esize));
+  return c.s_off > c.s_diag ? c.s_off : c.s_diag;
 }
+
+void set_plan_splits(Plan &p, int s_off, int s_diag) {
+  p.s_off = s_off; p.s_diag = s_diag;
+  p.splits = s_off > s_diag ? s_off : s_diag;
+}
+
 int make_plan(int64_t n_folds, int64_t max_rows, int K, int M, int dtype, unsigned flags,
               size_t ws_bytes, bool fold_mode, Plan &p) {
   const int esize = dtype == CVM_F64 ? 8 : 4;
   const int diag_only = fold_mode && !(flags & CVM_RET_XTX);
   p.g = make_geom(K, M, esize, diag_only);
-  p.splits = choose_splits(n_folds, max_rows, p.g, target_wg(K, M, esize));
+  const SplitChoice c = choose_splits2(n_folds, max_rows, p.g, esize, target_wg(K, M, esize));
+  set_plan_splits(p, c.s_off, c.s_diag);
   p.fstat_bytes_per_fold = fold_mode ? align_up(fstat_len(K, M) * 8, 256) : 0;
   for (;;) {
     const size_t per_fold = (size_t)p.splits * p.g.unit_bytes + p.fstat_bytes_per_fold;
     int64_t nb = (int64_t)(ws_bytes / per_fold);
     if (nb >= 1) { p.folds_per_batch = nb < n_folds ? nb : n_folds; return CVM_OK; }
     if (p.splits == 1) return CVM_EWORKSPACE;
-    p.splits = (p.splits + 1) / 2;
+    set_plan_splits(p, (p.s_off + 1) / 2, (p.s_diag + 1) / 2);
   }
+}
+
+// item counts and grid of a launch over n_seg segments
+template <typename T> void set_items(WgramArgs<T> &a, const Plan &p, int64_t n_seg) {
+  const Geom &g = p.g;
+  a.n_seg = (int)n_seg; a.splits = p.splits; a.s_off = p.s_off; a.s_diag = p.s_diag; a.g = g;
+  const int per0 = g.diag_only ? 0 : g.nTiles - g.P, per1 = g.P * g.Yc;
+  a.n_items0 = (long)n_seg * p.s_off * per0;
+  a.n_items1 = (long)n_seg * p.s_diag * per1;
+  a.ipx0 = (a.n_items0 + 7) / 8;
+  a.ipx1 = (a.n_items1 + 7) / 8;
+}
+void set_fin_splits(FinArgs &f, const Plan &p, int n_sum) {
+  f.splits = p.splits; f.s_off = p.s_off; f.s_diag = p.s_diag; f.n_sum = n_sum;
 }
 
 // can this problem take the float64 LDS-DMA kernel (wgram4_kernel)?
@@ -105,9 +222,7 @@ template <typename T> bool wgram4_ok(const WgramArgs<T> &a, bool aligned) {
 template <typename T>
 int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st,
                  int kind, bool fused = false) {
-  const long per_xcd = (a.n_items + 7) / 8;
   WgramArgs<T> args = a;
-  args.items_per_xcd = per_xcd;
   // CVM_FORCE_FALLBACK=1 sends float64 problems through the general (register-staged)
   // kernel too -- used by the tests to cover both kernels.  The ablation switches of
   // CVM_DEBUG (wrong results by design) exist in the -DCVM_STAMPS diagnostic build only.
@@ -117,7 +232,7 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   static const int dbg_env = 0;
 #endif
   args.dbg = dbg_env;
-  const dim3 grid((unsigned)(per_xcd * 8)), block(NTHREADS);
+  const dim3 grid((unsigned)((a.ipx0 + a.ipx1) * 8)), block(NTHREADS);
   const size_t lds = 2 * BUF_ELEMS * sizeof(T) + 3 * STAGE_ROWS * sizeof(int64_t);
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -206,14 +321,13 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   memset(&a, 0, sizeof(a));
   a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
   a.idx = nullptr; a.offs = nullptr; a.N = N; a.seg0 = 0;
-  a.n_seg = 1; a.splits = p.splits; a.g = p.g;
-  a.n_items = (long)p.splits * p.g.nT; a.items_per_xcd = 0;
+  set_items(a, p, 1);
   a.ws = (char *)ws;
   rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st, KIND_FIT);
   if (rc != CVM_OK) return rc;
   FinArgs f;
   memset(&f, 0, sizeof(f));
-  f.g = p.g; f.splits = p.splits; f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
+  f.g = p.g; set_fin_splits(f, p, 1); f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
   launch_fit_apply<T>(f, p.g, gstats, st);
   HIP_OK(hipGetLastError());
@@ -337,7 +451,8 @@ int fold_statistics_impl(const void *X, const void *Y, const void *w, const int6
     }
     FinArgs f;
     memset(&f, 0, sizeof(f));
-    f.g = g; f.splits = (int)splits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
+    f.g = g; f.splits = f.s_off = f.s_diag = (int)splits; f.n_sum = 1;
+    f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
     f.fstats = (double *)((char *)ws + (size_t)nb * splits * g.unit_bytes);
     f.offs = offsets; f.w = w; f.gstats = gstats;
     f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
@@ -405,7 +520,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
         else hipLaunchKernelGGL((colstats_kernel<T, false, true>), cgrid, dim3(COL_THREADS), 0, st, c);
         FinArgs f;
         memset(&f, 0, sizeof(f));
-        f.g = gs; f.splits = (int)csplits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
+        f.g = gs; f.splits = f.s_off = f.s_diag = (int)csplits; f.n_sum = 1;
+        f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
         f.fstats = (double *)((char *)ws + (size_t)nb * csplits * gs.unit_bytes);
         f.offs = offsets; f.w = w; f.gstats = gstats;
         f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
@@ -416,8 +532,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
         memset(&a, 0, sizeof(a));
         a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
         a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
-        a.n_seg = (int)nb; a.splits = 1; a.g = p.g;
-        a.n_items = (long)nb * p.g.nT; a.items_per_xcd = 0;
+        set_items(a, p, nb);               // (one unit per fold: p.s_off == p.s_diag == 1)
         a.ws = nullptr;
         a.fstats = f.fstats; a.G = G; a.H = H;
         a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
@@ -437,14 +552,13 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     memset(&a, 0, sizeof(a));
     a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
     a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
-    a.n_seg = (int)nb; a.splits = p.splits; a.g = p.g;
-    a.n_items = (long)nb * p.splits * p.g.nT; a.items_per_xcd = 0;
+    set_items(a, p, nb);
     a.ws = units;
     rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD);
     if (rc != CVM_OK) return rc;
     FinArgs f;
     memset(&f, 0, sizeof(f));
-    f.g = p.g; f.splits = p.splits; f.n_seg = (int)nb; f.seg0 = f0; f.ws = units;
+    f.g = p.g; set_fin_splits(f, p, 1); f.n_seg = (int)nb; f.seg0 = f0; f.ws = units;
     f.fstats = (double *)((char *)fstats);
     f.offs = offsets; f.w = w; f.G = G; f.H = H; f.gstats = gstats;
     f.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
@@ -490,19 +604,18 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   memset(&a, 0, sizeof(a));
   a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
   a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = 0;
-  a.n_seg = (int)n_folds; a.splits = p.splits; a.g = p.g;
-  a.n_items = (long)n_folds * p.splits * p.g.nT; a.items_per_xcd = 0;
+  set_items(a, p, n_folds);
   a.ws = (char *)ws;
   rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st, KIND_FOLD);
   if (rc != CVM_OK) return rc;
   FinArgs f;
   memset(&f, 0, sizeof(f));
-  f.g = p.g; f.splits = (int)(n_folds * p.splits);   // every unit of every fold, fold-major
+  f.g = p.g; set_fin_splits(f, p, (int)n_folds);      // every unit of every fold, fold-major
   f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
   launch_fit_apply<T>(f, p.g, gstats, st);
   HIP_OK(hipGetLastError());
-  if (splits_out) *splits_out = p.splits;
+  if (splits_out) *splits_out = (int64_t)p.s_off | ((int64_t)p.s_diag << 20);   // plan token for cvm_sweep_folds
   return CVM_OK;
 }
 
@@ -513,12 +626,16 @@ int sweep_folds_impl(const int64_t *offsets, int64_t n_folds, int K, int M, int 
                      void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
                      int64_t splits, hipStream_t st) {
   const Geom g = make_geom(K, M, sizeof(T), 0);
-  const size_t units = (size_t)n_folds * (size_t)splits * g.unit_bytes;
+  Plan p;
+  p.g = g;
+  set_plan_splits(p, (int)(splits & 0xfffff), (int)(splits >> 20));
+  if (p.s_off < 1 || p.s_diag < 1) return fail(CVM_EINVAL, "cvm_sweep_folds: not a plan token of cvm_sweep_fit%s");
+  const size_t units = (size_t)n_folds * (size_t)p.splits * g.unit_bytes;
   if (units + (size_t)n_folds * fstat_len(K, M) * 8 > ws_bytes)
     return fail(CVM_EWORKSPACE, "cvm_sweep_folds: workspace smaller than the one cvm_sweep_fit filled%s");
   FinArgs f;
   memset(&f, 0, sizeof(f));
-  f.g = g; f.splits = (int)splits; f.n_seg = (int)n_folds; f.seg0 = 0; f.ws = (const char *)ws;
+  f.g = g; set_fin_splits(f, p, 1); f.n_seg = (int)n_folds; f.seg0 = 0; f.ws = (const char *)ws;
   f.fstats = (double *)((char *)ws + units);
   f.offs = offsets; f.w = weighted ? (const void *)G : nullptr;   // non-null = weighted
   f.G = G; f.H = H; f.gstats = gstats;

@@ -91,12 +91,12 @@ __device__ __forceinline__ void diag_tile_finish(double (*Td)[TP], double *rs0, 
 #define ROLE_ATTR __attribute__((noreturn))
 #endif
 template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
-__device__ __noinline__ ROLE_ATTR void wgram4_body() {
+__device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs) {
   typedef typename MF<T>::acc_t acc_t;
 #ifdef CVM_STAMPS
   const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
 #endif
-  const WgramArgs<T> a = kernel_args<T>();
+  const WgramArgs<T> a = kernel_args<T>(kargs);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const Geom &g = a.g;
@@ -105,17 +105,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body() {
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave_all & 3;
 
-  const long b = blockIdx.x;
-  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
-  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) ROLE_EXIT();
-  const long u = item / g.nT;
-  const int it = (int)(item - u * g.nT);
-  const int seg = (int)(u / a.splits);
-  const int sp = (int)(u - (long)seg * a.splits);
-  int ti, tj, yc;
-  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
-  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
-  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  Item wi;
+  if (!decode_item(a, (long)blockIdx.x, wi)) ROLE_EXIT();
+  const long u = wi.u;
+  const int it = wi.it, seg = wi.seg, sp = wi.sp, ti = wi.ti, tj = wi.tj, yc = wi.yc;
   const bool diag = (ti == tj);
   const int wr = wave >> 1, wc = wave & 1;
   const bool h_wave = diag && wave == 2;
@@ -125,7 +118,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body() {
   if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
   else { seg_begin = 0; seg_rows = a.N; }
   int64_t r0, r1;
-  split_range(seg_rows, a.splits, sp, r0, r1);
+  split_range(seg_rows, wi.nsp, sp, r0, r1);
   // wave-uniform by construction; the 64-bit division above runs on the VALU, so say so
   r0 = uni64(r0); r1 = uni64(r1); seg_begin = uni64(seg_begin);
   const int nstages = uni((int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS));
@@ -662,26 +655,22 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body() {
 //   YSTAT: this wave also sums the Y columns, sw and nz (wave 3 of panel 0)
 // ----------------------------------------------------------------------------------
 template <typename T, bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT, bool FUSEDR = false>
-__device__ __noinline__ ROLE_ATTR void wgram4_diag_body() {
+__device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs) {
   typedef typename MF<T>::acc_t acc_t;
-  const WgramArgs<T> a = kernel_args<T>();
+  const WgramArgs<T> a = kernel_args<T>(kargs);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const Geom &g = a.g;
   const int lane = threadIdx.x & 63;
-  const long b = blockIdx.x;
-  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
-  const long u = item / g.nT;
-  const int it = (int)(item - u * g.nT);
-  const int seg = (int)(u / a.splits);
-  const int sp = (int)(u - (long)seg * a.splits);
-  int ti, tj;
-  decode_tile(it, g.P, ti, tj);                   // diagonal: ti == tj, Y chunk 0
+  Item wi;
+  decode_item(a, (long)blockIdx.x, wi);           // diagonal tile, Y chunk 0 (the kernel checked)
+  const long u = wi.u;
+  const int it = wi.it, seg = wi.seg, sp = wi.sp, ti = wi.ti;
   int64_t seg_begin, seg_rows;
   if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
   else { seg_begin = 0; seg_rows = a.N; }
   int64_t r0, r1;
-  split_range(seg_rows, a.splits, sp, r0, r1);
+  split_range(seg_rows, wi.nsp, sp, r0, r1);
   r0 = uni64(r0); r1 = uni64(r1);
   const int nstages = uni((int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS));
 
@@ -879,11 +868,11 @@ template <typename T, bool WEIGHTED, bool GATHER, bool FUSED = false>
 __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
   // role of this wave (same decode as in the body)
   const Geom &g = a.g;
+  const kargs_ptr<T> kargs = kernarg_address<T>();
   const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wave = wave_all & 3;
-  const long b = blockIdx.x;
-  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
-  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
+  Item wi;
+  if (!decode_item(a, (long)blockIdx.x, wi)) return;
 #ifdef CVM_STAMPS
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), q0 = __builtin_amdgcn_s_memrealtime();
   auto fin = [&]() {
@@ -893,15 +882,11 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
       o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
     }
   };
-  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(); fin(); return; }
+  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(kargs); fin(); return; }
 #else
-  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(); return; }
+  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(kargs); return; }
 #endif
-  const int it = (int)(item % g.nT);
-  int ti, tj, yc;
-  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
-  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
-  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  const int ti = wi.ti, tj = wi.tj, yc = wi.yc;
   const bool diag = (ti == tj);
   const bool do_g = !g.diag_only && yc == 0;
   if (FUSED && diag && do_g) {
@@ -909,8 +894,8 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     const bool wide = g.M > 16;
 #define CVM_DIAGF(WV)                                                                        \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false, true>();                   \
-      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false, true>();                        \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false, true>(kargs);                   \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false, true>(kargs);                        \
     } while (0)
     if (wave == 0) CVM_DIAGF(0);
     else if (wave == 1) CVM_DIAGF(1);
@@ -923,9 +908,9 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     return;
   }
   if (FUSED) {   // statistics come from colstats_kernel: no summing roles
-    if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0, true>();
-    else if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0, true>();
-    else wgram4_body<T, WEIGHTED, GATHER, false, false, 0, true>();
+    if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0, true>(kargs);
+    else if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0, true>(kargs);
+    else wgram4_body<T, WEIGHTED, GATHER, false, false, 0, true>(kargs);
 #ifdef CVM_STAMPS
     fin();
 #endif
@@ -936,15 +921,15 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     const bool wide = g.M > 16, ys = (ti == 0);
 #define CVM_DIAG(WV)                                                                         \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false>();                         \
-      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false>();                              \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false>(kargs);                         \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false>(kargs);                              \
     } while (0)
     if (wave == 0) CVM_DIAG(0);
     else if (wave == 1) CVM_DIAG(1);
     else if (wave == 2) CVM_DIAG(2);
     else if (!ys) CVM_DIAG(3);
-    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true>();
-    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true>();
+    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true>(kargs);
+    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true>(kargs);
 #undef CVM_DIAG
 #ifdef CVM_STAMPS
     fin();
@@ -952,10 +937,10 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     return;
   }
   const int role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
-  if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0>();
-  else if (role == 1) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 1>(); else wgram4_body<T, WEIGHTED, GATHER, false, false, 1>(); }
-  else if (role == 2) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 2>(); else wgram4_body<T, WEIGHTED, GATHER, false, false, 2>(); }
-  else { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0>(); else wgram4_body<T, WEIGHTED, GATHER, false, false, 0>(); }
+  if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0>(kargs);
+  else if (role == 1) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 1>(kargs); else wgram4_body<T, WEIGHTED, GATHER, false, false, 1>(kargs); }
+  else if (role == 2) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 2>(kargs); else wgram4_body<T, WEIGHTED, GATHER, false, false, 2>(kargs); }
+  else { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0>(kargs); else wgram4_body<T, WEIGHTED, GATHER, false, false, 0>(kargs); }
 #ifdef CVM_STAMPS
   fin();
 #endif

@@ -49,17 +49,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- which work item: contiguous ranges of the (unit, tile) list per XCD ----------
-  const long b = blockIdx.x;
-  const long item = (b & 7) * a.items_per_xcd + (b >> 3);
-  if ((b >> 3) >= a.items_per_xcd || item >= a.n_items) return;
-  const long u = item / g.nT;
-  const int it = (int)(item - u * g.nT);
-  const int seg = (int)(u / a.splits);
-  const int sp = (int)(u - (long)seg * a.splits);
-  int ti, tj, yc;
-  if (g.diag_only) { ti = tj = it / g.Yc; yc = it - ti * g.Yc; }
-  else if (it < g.nTiles) { decode_tile(it, g.P, ti, tj); yc = 0; }
-  else { int e = it - g.nTiles; ti = tj = e / (g.Yc - 1); yc = 1 + e - ti * (g.Yc - 1); }
+  Item wi;
+  if (!decode_item(a, (long)blockIdx.x, wi)) return;
+  const long u = wi.u;
+  const int it = wi.it, seg = wi.seg, sp = wi.sp, ti = wi.ti, tj = wi.tj, yc = wi.yc;
   const bool diag = (ti == tj);
   const int wr = wave >> 2, wc = wave & 3;
   const bool h_wave = diag && wr == 1 && wc < 2;
@@ -69,7 +62,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   if (a.offs) { seg_begin = a.offs[a.seg0 + seg]; seg_rows = a.offs[a.seg0 + seg + 1] - seg_begin; }
   else { seg_begin = 0; seg_rows = a.N; }
   int64_t r0, r1;
-  split_range(seg_rows, a.splits, sp, r0, r1);
+  split_range(seg_rows, wi.nsp, sp, r0, r1);
   const int nstages = (int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS);
 
   // ---- per-thread staging coordinates -----------------------------------------------

@@ -125,7 +125,8 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
  * full-data matrices of cvm_gram_fit are the sum of the folds' validation matrices.
  *   cvm_sweep_fit    runs the Gram kernel once over all folds (rows gathered by idx), writes
  *                    G, H, gstats, neg_flag exactly like cvm_gram_fit (summation order: fold-
- *                    major) and leaves the per-fold partials in ws; *splits_out identifies them
+ *                    major) and leaves the per-fold partials in ws; *splits_out receives an
+ *                    opaque token (the row-split plan) to be handed back to cvm_sweep_folds
  *   cvm_sweep_folds  = the finalize half of cvm_fold_update on those partials (same outputs),
  *                    valid while ws is untouched; `weighted` = 1 if cvm_sweep_fit got w != NULL
  * Together they do half the arithmetic of cvm_gram_fit + cvm_fold_update.  The caller
@@ -184,11 +185,15 @@ int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info)
 int cvm_timing_enable(int on);
 int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold);
 
-/* Introspection for benchmarks/profiles: geometry chosen for a problem.
- * info[0]=row splits per fold, [1]=workgroups of the Gram kernel per batch, [2]=column
- * panels, [3]=work items per (fold, split), [4]=folds per batch, [5]=MFMA instructions the
- * kernel issues per 4 rows of one fold (executed work, 2048 flop each).  Bit 31 of `flags`
- * set: plan the fit stage instead.  Same decision procedure as the real calls. */
+/* Introspection for benchmarks/profiles: geometry chosen for a problem (info: int64[8]).
+ * info[0]=row splits per fold of the off-diagonal 128x128 tiles, [6]=row splits of the diagonal
+ * tiles (which also produce XTY and the column sums and cost less per row: the two kinds are cut
+ * differently so that all workgroups of a launch take about the same time), [7]=partial slots per
+ * fold in the workspace (the larger of the two), [1]=workgroups of the Gram kernel per batch,
+ * [2]=column panels, [3]=work items per (fold, split) if both kinds were cut alike, [4]=folds per
+ * batch, [5]=MFMA instructions the kernel issues per 4 rows of one fold (executed work, 2048 flop
+ * each).  Bit 31 of `flags` set: plan the fit stage instead.  Same decision procedure as the real
+ * calls. */
 int cvm_plan_fold(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype,
                   unsigned flags, size_t ws_bytes, int64_t *info);
 

@@ -938,6 +938,7 @@ def test_bench_command_two_ranks_strong_scaling(amd, mode, path):
     of ONE problem dealt over the ranks; the JSON line names the same global workload as the
     single-process run and carries the in-run parity gate (a fold recomputed from scratch)."""
     import json
+    import os
     import subprocess
     import sys
 

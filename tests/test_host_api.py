@@ -157,18 +157,21 @@ def test_cabi_library_exports_every_declared_symbol():
     assert loaded.cvm_fold_workspace_bytes(10, 100000, 10000, 512, 16, _lib.CVM_F64, 0x3F) > 0
     info = (ctypes.c_int64 * 8)()
     assert loaded.cvm_plan_fold(10, 10000, 512, 16, _lib.CVM_F64, 0x3F, 1 << 40, info) == 0
-    splits, wgs, panels, items = info[0], info[1], info[2], info[3]
-    assert panels == 4 and items == 10 and wgs == 10 * splits * items and splits >= 1
+    s_off, s_diag, wgs, panels, items = info[0], info[6], info[1], info[2], info[3]
+    assert panels == 4 and items == 10 and wgs == 10 * (6 * s_off + 4 * s_diag) and s_off >= 1 and s_diag >= 1
+    assert info[7] == max(s_off, s_diag)
     # bad arguments are refused with a message, not a crash
     assert loaded.cvm_gram_fit(None, None, None, 1, 1, 0, 1, None, None, None, None, None, 0, None) == 1
     assert b"null pointer" in loaded.cvm_last_error()
 
 
 def test_launch_planning_is_host_logic():
-    """The row-split planner (cvm_plan_fold, pure host code): it fills the 256 CUs with as few
-    splits as the launch-time estimate allows -- C3's 10 folds x 10 tiles get 5 splits (two rounds
-    of workgroups), the fit stage one round, and many mid-size folds one unit per fold (the
-    route that finishes folds in the Gram kernel's epilogue)."""
+    """The row-split planner (cvm_plan_fold, pure host code) packs the 256 CUs by simulating the
+    in-order hand-out of workgroups: off-diagonal tiles (16 MFMAs per wave and k-step) and diagonal
+    tiles (11) get their own split counts -- C3's 10 folds x (6 + 4) tiles: 4 and 7, i.e. 240 long
+    and 280 short workgroups instead of 500 alike in two ragged rounds; the fit stage one round;
+    many mid-size folds one unit per fold (the route that finishes folds in the Gram kernel's
+    epilogue)."""
     if not os.path.exists(_lib.LIB_PATH):
         import __graft_entry__
 
@@ -178,16 +181,21 @@ def test_launch_planning_is_host_logic():
 
     def plan(n_folds, rows, K, M, dtype=_lib.CVM_F64, flags=0x3F, ws=1 << 40):
         assert lib.cvm_plan_fold(n_folds, rows, K, M, dtype, flags, ws, info) == 0
-        return dict(splits=info[0], wgs=info[1], panels=info[2], items=info[3], batch=info[4],
-                    mfma_per_4_rows=info[5])
+        return dict(splits=info[7], s_off=info[0], s_diag=info[6], wgs=info[1], panels=info[2], items=info[3],
+                    batch=info[4], mfma_per_4_rows=info[5])
 
     c3 = plan(10, 10000, 512, 16)
-    assert c3["splits"] == 5 and c3["wgs"] == 500 and c3["batch"] == 10
+    assert (c3["s_off"], c3["s_diag"]) == (4, 7) and c3["wgs"] == 10 * (6 * 4 + 4 * 7) and c3["batch"] == 10
+    # estimated makespan: off-diagonal items of 2500 rows first, diagonal items of 1429 rows at
+    # 11/16 of the cost per row fill in behind them -- within 10 % of the 256-CU ideal
+    ideal = 10 * 10000 * (6 + 4 * 11 / 16) / 256
+    assert 2500 + 1429 * 11 / 16 <= 1.10 * ideal
     # executed MFMAs per 4 rows: 6 off-diagonal tiles x 64, 4 diagonal x 36 (upper triangle of the
     # tile's 8 x 8 grid of MFMA tiles), 4 x 8 for XTY (M = 16: one column tile)
     assert c3["mfma_per_4_rows"] == 6 * 64 + 4 * 36 + 4 * 8
     fit = plan(1, 100000, 512, 16, flags=0x3F | 0x80000000)
     assert fit["wgs"] <= 256 and fit["wgs"] >= 240                 # one round, nearly full
+    assert fit["s_off"] > fit["s_diag"]                            # longer row ranges for the cheaper tiles
     for P in (100, 300, 1000):
         assert plan(P, 100000 // P, 512, 16)["splits"] == 1
     # a workspace that holds three folds' partials: three folds per batch, same splits or fewer
