@@ -63,7 +63,7 @@ size_t cvm_gstats_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 2; 
 
 size_t cvm_fit_workspace_bytes(int64_t N, int K, int M, int dtype) {
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
-  return (size_t)plan_stride(1, N, g, dtype == CVM_F64 ? 8 : 4) * g.unit_bytes;
+  return (size_t)plan_stride(1, N, g, dtype == CVM_F64 ? 8 : 4) * g.unit_bytes + QUEUE_RESERVE;
 }
 
 int cvm_gram_fit(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
@@ -86,7 +86,7 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
   (void)n_idx;
   if (max_fold_rows <= SMALL_ROWS) {   // direct path: only the per-fold statistics live in ws
     const int64_t nb = n_folds < 32768 ? (n_folds > 0 ? n_folds : 1) : 32768;
-    return (size_t)nb * fstat_len(K, M) * 8;
+    return (size_t)nb * fstat_len(K, M) * 8 + QUEUE_RESERVE;
   }
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, !(flags & CVM_RET_XTX));
   const int splits = plan_stride(n_folds, max_fold_rows, g, dtype == CVM_F64 ? 8 : 4);
@@ -94,7 +94,7 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
   size_t want = per_fold * (size_t)(n_folds > 0 ? n_folds : 1);
   const size_t cap = (size_t)8 << 30;   // beyond 8 GiB walk the folds in batches
   if (want > cap) want = (cap / per_fold > 0 ? cap / per_fold : 1) * per_fold;
-  return want;
+  return want + QUEUE_RESERVE;
 }
 
 int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *idx,
@@ -162,7 +162,8 @@ int cvm_debug_stamps2(unsigned long long *host_out) {
 size_t cvm_sweep_workspace_bytes(int64_t n_folds, int64_t max_fold_rows, int K, int M, int dtype) {
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 0);
   const int splits = plan_stride(n_folds, max_fold_rows, g, dtype == CVM_F64 ? 8 : 4);
-  return ((size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256)) * (size_t)(n_folds > 0 ? n_folds : 1);
+  return ((size_t)splits * g.unit_bytes + align_up(fstat_len(K, M) * 8, 256)) * (size_t)(n_folds > 0 ? n_folds : 1) +
+         QUEUE_RESERVE;
 }
 
 int cvm_sweep_fit(const void *X, const void *Y, const void *w, const int64_t *idx,

@@ -16,6 +16,8 @@ constexpr int PANEL_ELEMS = STAGE_ROWS * PITCH;             // 2304
 constexpr int BUF_ELEMS = 2 * PANEL_ELEMS + STAGE_ROWS;     // A panel, B panel | Y tile, w
 constexpr int TARGET_WG_1 = 256;  // resident workgroups (both Gram kernels: one 8-wave workgroup per CU)
 constexpr int TARGET_WG_2 = 256;
+constexpr int QUEUE_STRIDE = 32;       // unsigneds between the 8 queue heads (one 128-byte line each)
+constexpr size_t QUEUE_BYTES = 8 * QUEUE_STRIDE * sizeof(unsigned);
 // LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
 // f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
 // the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
@@ -96,6 +98,8 @@ template <typename T> struct WgramArgs {
   Geom g;
   long n_items0, ipx0;  // class 0: items, items per XCD
   long n_items1, ipx1;  // class 1
+  unsigned *queue;      // wgram4_kernel: 8 work-queue heads (one per XCD, QUEUE_STRIDE apart), zeroed
+                        // before the launch
   char *ws;             // unit u at ws + u*unit_bytes
   // fused single-split fold update (wgram4_kernel<.., FUSED>): finish in the epilogue
   const double *fstats; // per fold of the batch: means / stds / sw_train (fold_stats_kernel)
@@ -147,6 +151,7 @@ template <typename T> __device__ __forceinline__ WgramArgs<T> kernel_args(kargs_
   a.g.tile_elems = r->g.tile_elems; a.g.h_elems = r->g.h_elems;
   a.g.stat_len = r->g.stat_len; a.g.unit_bytes = r->g.unit_bytes;
   a.n_items0 = r->n_items0; a.ipx0 = r->ipx0; a.n_items1 = r->n_items1; a.ipx1 = r->ipx1;
+  a.queue = r->queue;
   a.ws = r->ws; a.dbg = r->dbg;
   a.fstats = r->fstats; a.G = r->G; a.H = r->H;
   a.out_XTX = r->out_XTX; a.out_XTY = r->out_XTY; a.flags = r->flags;
@@ -174,14 +179,13 @@ __device__ __forceinline__ void decode_off_tile(int k, int P, int &ti, int &tj) 
 // the grid.  `it`: the item's tile slot in the unit's partials (G tiles), `nsp`: the split count
 // of its class.
 struct Item { int seg, sp, nsp, it, ti, tj, yc; long u; };
-template <typename T> __device__ __forceinline__ bool decode_item(const WgramArgs<T> &a, long b, Item &o) {
+// Position q of XCD `xcd`'s list: its class-0 items [0, ipx0), then its class-1 items.
+template <typename T> __device__ __forceinline__ bool decode_slot(const WgramArgs<T> &a, int xcd, long q, Item &o) {
   const Geom &g = a.g;
-  const long b0 = 8 * a.ipx0;
   long item, cu;   // cu: unit number within the class (seg * nsp + sp)
   int k;
-  if (b < b0) {
-    if ((b >> 3) >= a.ipx0) return false;
-    item = (b & 7) * a.ipx0 + (b >> 3);
+  if (q < a.ipx0) {
+    item = (long)xcd * a.ipx0 + q;
     if (item >= a.n_items0) return false;
     const int per = g.nTiles - g.P;
     cu = item / per; k = (int)(item - cu * per);
@@ -190,9 +194,9 @@ template <typename T> __device__ __forceinline__ bool decode_item(const WgramArg
     o.yc = 0;
     o.it = tile_id(o.ti, o.tj, g.P);
   } else {
-    const long bb = b - b0;
-    if ((bb >> 3) >= a.ipx1) return false;
-    item = (bb & 7) * a.ipx1 + (bb >> 3);
+    const long q1 = q - a.ipx0;
+    if (q1 >= a.ipx1) return false;
+    item = (long)xcd * a.ipx1 + q1;
     if (item >= a.n_items1) return false;
     const int per = g.P * g.Yc;                 // P first-chunk items, then P * (Yc - 1) further chunks
     cu = item / per; k = (int)(item - cu * per);
@@ -210,6 +214,14 @@ template <typename T> __device__ __forceinline__ bool decode_item(const WgramArg
   o.ti = uni(o.ti); o.tj = uni(o.tj); o.yc = uni(o.yc);
   o.u = (long)o.seg * a.splits + o.sp;
   return true;
+}
+// Static launch (wgram_kernel, one workgroup per item): the grid lists the class-0 positions of
+// all XCDs, then the class-1 positions; the hardware deals workgroups to the XCDs round-robin.
+template <typename T> __device__ __forceinline__ bool decode_item(const WgramArgs<T> &a, long b, Item &o) {
+  const long b0 = 8 * a.ipx0;
+  if (b < b0) return decode_slot(a, (int)(b & 7), b >> 3, o);
+  const long bb = b - b0;
+  return decode_slot(a, (int)(bb & 7), a.ipx0 + (bb >> 3), o);
 }
 
 // rows of segment `seg` handled by split `sp`

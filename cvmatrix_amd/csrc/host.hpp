@@ -54,16 +54,18 @@ bool fast_shape(int K, int M, int esize) {
 
 // ---- row splits ---------------------------------------------------------------------------
 // The launch is a list of work items (geometry.hpp: all off-diagonal-tile items, then the
-// diagonal-class items) that the hardware hands to free CUs in order; TARGET_WG workgroups are
-// resident at a time (one 8-wave workgroup per CU).  An item costs its 16-row stages times the
-// per-stage cost of its kind plus a fixed prologue/epilogue (~6 stages: pipeline fill, partial
-// store).  Per-stage costs, in units of an off-diagonal tile's stage (16 MFMAs per wave and
+// diagonal-class items) that TARGET_WG persistent workgroups (one 8-wave workgroup per CU) take in
+// order, each as soon as it is free (wgram4_kernel's work queues).  An item costs its 16-row
+// stages times the per-stage cost of its kind plus a fixed prologue/epilogue (~3 stages: pipeline
+// fill, partial store, fetching the next item; fitted to measured launch times of eleven split
+// pairs at C3, as is the diagonal tiles' relative cost 0.66-0.69).  Per-stage costs, in units of an off-diagonal tile's stage (16 MFMAs per wave and
 // k-step): a diagonal tile in the LDS-DMA kernel issues 9 + 2*NBY (the upper triangle of its 8x8
 // grid of MFMA tiles shared out evenly + XTY), a further-Y-chunk item keeps one wave busy with 16;
 // in the general kernel every wave of every item runs the same loop.
 // Because the two classes cost differently they get their own split counts: at C3 (10 folds x
 // (6 off-diagonal + 4 diagonal tiles)) 4 and 7 give 240 long + 280 short items that pack 256 CUs
-// to 93 % -- any common count leaves a second round of workgroups a quarter empty.
+// to 94 % (measured: 0.467 ms against 0.507 ms with 5 and 5) -- any common count leaves a second
+// round of workgroups a quarter empty.
 // The estimate is a simulation of that in-order hand-out, evaluated for a few hundred
 // (s_off, s_diag) candidates and cached per shape.
 struct SplitKey {
@@ -84,7 +86,7 @@ double simulate_launch(int64_t n_seg, int64_t max_rows, const Geom &g, int s_off
     int64_t per = (max_rows + s - 1) / s;
     return (double)((per + STAGE_ROWS - 1) / STAGE_ROWS);
   };
-  const double fixed = 6.0;
+  const double fixed = 3.0;
   const double c_off = stages_of(s_off) + fixed;
   const double c_first = stages_of(s_diag) * c_diag + fixed, c_y = stages_of(s_diag) + fixed;
   // in-order hand-out to `target` CUs: a min-heap of the CUs' free times
@@ -219,10 +221,31 @@ template <typename T> bool wgram4_ok(const WgramArgs<T> &a, bool aligned) {
   return ((uintptr_t)a.Y % 4 == 0) && ((uintptr_t)a.w % 4 == 0);   // float32: Y and w by dwords
 }
 
+// The persistent LDS-DMA kernel pulls its work items from 8 queue heads in device memory: they
+// live in the last QUEUE_BYTES of the caller's workspace (128-byte aligned) and are zeroed on the
+// stream before every launch.
+struct WsCarve { size_t usable; unsigned *queue; };
+WsCarve carve_queue(void *ws, size_t ws_bytes) {
+  if (!ws || ws_bytes < QUEUE_BYTES + 256) return WsCarve{0, nullptr};
+  const size_t off = (ws_bytes - QUEUE_BYTES) & ~(size_t)127;
+  return WsCarve{off, (unsigned *)((char *)ws + off)};
+}
+constexpr size_t QUEUE_RESERVE = QUEUE_BYTES + 256;   // what the workspace-size functions add for it
+
+int device_cu_count(int dev) {
+  static std::atomic<int> cus[64];
+  int c = cus[dev & 63].load(std::memory_order_relaxed);
+  if (c > 0) return c;
+  if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+  cus[dev & 63].store(c, std::memory_order_relaxed);
+  return c;
+}
+
 template <typename T>
 int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st,
-                 int kind, bool fused = false) {
+                 int kind, unsigned *queue, bool fused = false) {
   WgramArgs<T> args = a;
+  args.queue = queue;
   // CVM_FORCE_FALLBACK=1 sends float64 problems through the general (register-staged)
   // kernel too -- used by the tests to cover both kernels.  The ablation switches of
   // CVM_DEBUG (wrong results by design) exist in the -DCVM_STAMPS diagnostic build only.
@@ -260,6 +283,13 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   if (fused && !(fast && gather && sizeof(T) == 8))
     return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
   if (fast) {
+    if (!queue) return fail(CVM_EWORKSPACE, "launch_wgram: no room for the work-queue heads in the workspace%s");
+    HIP_OK(hipMemsetAsync(queue, 0, QUEUE_BYTES, st));
+    // persistent workgroups: one per CU (fewer when the lists are shorter than that)
+    long wgs = 8 * (a.ipx0 + a.ipx1);
+    const long cus = device_cu_count(dev);
+    if (wgs > cus) wgs = cus;
+    const dim3 grid((unsigned)wgs);
     const dim3 block4(NT4);
     const size_t lds4 = lds4_bytes<T>();
 #define CVM_LAUNCH4(W, GA, FU)                                                              \
@@ -314,6 +344,8 @@ template <typename T>
 int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K, int M, int dtype,
                   void *G, void *H, double *gstats, int32_t *neg_flag, void *ws, size_t ws_bytes,
                   hipStream_t st) {
+  const WsCarve wq = carve_queue(ws, ws_bytes);
+  ws_bytes = wq.usable;
   Plan p;
   int rc = make_plan(1, N, K, M, dtype, CVM_RET_XTX | CVM_RET_XTY, ws_bytes, false, p);
   if (rc != CVM_OK) return fail(rc, "cvm_gram_fit: workspace too small%s");
@@ -323,7 +355,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   a.idx = nullptr; a.offs = nullptr; a.N = N; a.seg0 = 0;
   set_items(a, p, 1);
   a.ws = (char *)ws;
-  rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st, KIND_FIT);
+  rc = launch_wgram<T>(a, w != nullptr, false, rows_aligned(X, K, sizeof(T)), st, KIND_FIT, wq.queue);
   if (rc != CVM_OK) return rc;
   FinArgs f;
   memset(&f, 0, sizeof(f));
@@ -476,6 +508,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     if (n < 0) return fail(CVM_EINVAL, "cvm_fold_update: offsets must be non-decreasing%s");
     if (n > max_rows) max_rows = n;
   }
+  const WsCarve wq = carve_queue(ws, ws_bytes);
+  ws_bytes = wq.usable;
   if (max_rows <= SMALL_ROWS)
     return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
@@ -536,7 +570,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
         a.ws = nullptr;
         a.fstats = f.fstats; a.G = G; a.H = H;
         a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
-        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, true);
+        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, wq.queue, true);
         if (rc != CVM_OK) return rc;
       }
       return CVM_OK;
@@ -554,7 +588,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
     set_items(a, p, nb);
     a.ws = units;
-    rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD);
+    rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, wq.queue);
     if (rc != CVM_OK) return rc;
     FinArgs f;
     memset(&f, 0, sizeof(f));
@@ -595,6 +629,8 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   }
   if (host_offsets[n_folds] - host_offsets[0] != N)
     return fail(CVM_EINVAL, "cvm_sweep_fit: the folds must cover each of the N rows exactly once%s");
+  const WsCarve wq = carve_queue(ws, ws_bytes);
+  ws_bytes = wq.usable;
   Plan p;
   const unsigned flags = CVM_RET_XTX | CVM_RET_XTY;
   int rc = make_plan(n_folds, max_rows, K, M, dtype, flags, ws_bytes, true, p);
@@ -606,7 +642,7 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = 0;
   set_items(a, p, n_folds);
   a.ws = (char *)ws;
-  rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st, KIND_FOLD);
+  rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st, KIND_FOLD, wq.queue);
   if (rc != CVM_OK) return rc;
   FinArgs f;
   memset(&f, 0, sizeof(f));

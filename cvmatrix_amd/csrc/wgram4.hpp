@@ -77,21 +77,11 @@ __device__ __forceinline__ void diag_tile_finish(double (*Td)[TP], double *rs0, 
   }
 }
 
-// The role functions never return to the kernel (it has nothing left to do after them): they end
-// the wave themselves (s_endpgm) and are declared noreturn, so the compiler does not save and
-// restore the callee-saved registers they use around a call that is the wave's last act -- as
-// ordinary functions every role spilled 12-74 VGPRs to scratch in its prologue and read them back
-// in its epilogue (a wait for up to 74 loads at the end of every work item).  The exit is an
-// inline-asm s_endpgm: before the builtin the compiler still emits the restoring epilogue.  (The -DCVM_STAMPS diagnostic build returns: it stamps the clock after the call.)
-#ifdef CVM_STAMPS
+// (the role functions are called once per work item from the persistent loop of wgram4_kernel)
 #define ROLE_EXIT() return
 #define ROLE_ATTR
-#else
-#define ROLE_EXIT() do { asm volatile("s_endpgm"); __builtin_unreachable(); } while (0)
-#define ROLE_ATTR __attribute__((noreturn))
-#endif
 template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
-__device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs) {
+__device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q, int slot_q) {
   typedef typename MF<T>::acc_t acc_t;
 #ifdef CVM_STAMPS
   const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
@@ -106,7 +96,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs) {
   const int wave = wave_all & 3;
 
   Item wi;
-  if (!decode_item(a, (long)blockIdx.x, wi)) ROLE_EXIT();
+  if (!decode_slot(a, uni(xcd_q), (long)uni(slot_q), wi)) ROLE_EXIT();
   const long u = wi.u;
   const int it = wi.it, seg = wi.seg, sp = wi.sp, ti = wi.ti, tj = wi.tj, yc = wi.yc;
   const bool diag = (ti == tj);
@@ -655,7 +645,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs) {
 //   YSTAT: this wave also sums the Y columns, sw and nz (wave 3 of panel 0)
 // ----------------------------------------------------------------------------------
 template <typename T, bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT, bool FUSEDR = false>
-__device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs) {
+__device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int xcd_q, int slot_q) {
   typedef typename MF<T>::acc_t acc_t;
   const WgramArgs<T> a = kernel_args<T>(kargs);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -663,7 +653,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs) {
   const Geom &g = a.g;
   const int lane = threadIdx.x & 63;
   Item wi;
-  decode_item(a, (long)blockIdx.x, wi);           // diagonal tile, Y chunk 0 (the kernel checked)
+  decode_slot(a, uni(xcd_q), (long)uni(slot_q), wi);   // diagonal tile, Y chunk 0 (the kernel checked)
   const long u = wi.u;
   const int it = wi.it, seg = wi.seg, sp = wi.sp, ti = wi.ti;
   int64_t seg_begin, seg_rows;
@@ -864,28 +854,13 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs) {
   ROLE_EXIT();
 }
 
-template <typename T, bool WEIGHTED, bool GATHER, bool FUSED = false>
-__global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
-  // role of this wave (same decode as in the body)
+// One wave's part of one work item: pick the role function of (tile kind, wave).
+template <typename T, bool WEIGHTED, bool GATHER, bool FUSED>
+__device__ __forceinline__ void wgram4_item(const WgramArgs<T> &a, kargs_ptr<T> kargs, const Item &wi, int wave_all,
+                                            int xq, int sq) {
   const Geom &g = a.g;
-  const kargs_ptr<T> kargs = kernarg_address<T>();
-  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wave = wave_all & 3;
-  Item wi;
-  if (!decode_item(a, (long)blockIdx.x, wi)) return;
-#ifdef CVM_STAMPS
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), q0 = __builtin_amdgcn_s_memrealtime();
-  auto fin = [&]() {
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
-      unsigned long long *o = g_stamps2 + ((size_t)blockIdx.x * 8 + wave_all) * 4;
-      o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
-    }
-  };
-  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(kargs); fin(); return; }
-#else
-  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(kargs); return; }
-#endif
+  if (wave_all >= 4) { wgram4_body<T, WEIGHTED, GATHER, false, false, 3, FUSED>(kargs, xq, sq); return; }
   const int ti = wi.ti, tj = wi.tj, yc = wi.yc;
   const bool diag = (ti == tj);
   const bool do_g = !g.diag_only && yc == 0;
@@ -894,26 +869,20 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     const bool wide = g.M > 16;
 #define CVM_DIAGF(WV)                                                                        \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false, true>(kargs);                   \
-      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false, true>(kargs);                        \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false, true>(kargs, xq, sq);       \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false, true>(kargs, xq, sq);            \
     } while (0)
     if (wave == 0) CVM_DIAGF(0);
     else if (wave == 1) CVM_DIAGF(1);
     else if (wave == 2) CVM_DIAGF(2);
     else CVM_DIAGF(3);
 #undef CVM_DIAGF
-#ifdef CVM_STAMPS
-    fin();
-#endif
     return;
   }
   if (FUSED) {   // statistics come from colstats_kernel: no summing roles
-    if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0, true>(kargs);
-    else if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0, true>(kargs);
-    else wgram4_body<T, WEIGHTED, GATHER, false, false, 0, true>(kargs);
-#ifdef CVM_STAMPS
-    fin();
-#endif
+    if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0, true>(kargs, xq, sq);
+    else if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0, true>(kargs, xq, sq);
+    else wgram4_body<T, WEIGHTED, GATHER, false, false, 0, true>(kargs, xq, sq);
     return;
   }
   if (diag && do_g) {
@@ -921,27 +890,92 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     const bool wide = g.M > 16, ys = (ti == 0);
 #define CVM_DIAG(WV)                                                                         \
     do {                                                                                     \
-      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false>(kargs);                         \
-      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false>(kargs);                              \
+      if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, WV, 2, false>(kargs, xq, sq);             \
+      else wgram4_diag_body<T, WEIGHTED, GATHER, WV, 1, false>(kargs, xq, sq);                  \
     } while (0)
     if (wave == 0) CVM_DIAG(0);
     else if (wave == 1) CVM_DIAG(1);
     else if (wave == 2) CVM_DIAG(2);
     else if (!ys) CVM_DIAG(3);
-    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true>(kargs);
-    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true>(kargs);
+    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true>(kargs, xq, sq);
+    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true>(kargs, xq, sq);
 #undef CVM_DIAG
-#ifdef CVM_STAMPS
-    fin();
-#endif
     return;
   }
   const int role = !diag ? 0 : ((yc == 0 && (wave == 0 || wave == 3)) ? 1 : ((ti == 0 && wave == 1) ? 2 : 0));
-  if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0>(kargs);
-  else if (role == 1) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 1>(kargs); else wgram4_body<T, WEIGHTED, GATHER, false, false, 1>(kargs); }
-  else if (role == 2) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 2>(kargs); else wgram4_body<T, WEIGHTED, GATHER, false, false, 2>(kargs); }
-  else { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0>(kargs); else wgram4_body<T, WEIGHTED, GATHER, false, false, 0>(kargs); }
+  if (diag && wave == 2) wgram4_body<T, WEIGHTED, GATHER, true, true, 0>(kargs, xq, sq);
+  else if (role == 1) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 1>(kargs, xq, sq); else wgram4_body<T, WEIGHTED, GATHER, false, false, 1>(kargs, xq, sq); }
+  else if (role == 2) { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 2>(kargs, xq, sq); else wgram4_body<T, WEIGHTED, GATHER, false, false, 2>(kargs, xq, sq); }
+  else { if (do_g) wgram4_body<T, WEIGHTED, GATHER, false, true, 0>(kargs, xq, sq); else wgram4_body<T, WEIGHTED, GATHER, false, false, 0>(kargs, xq, sq); }
+}
+
+// PERSISTENT workgroups, one per CU, that pull work items from per-XCD queues.
+// Why not one workgroup per item: the hardware deals the workgroups of a launch to the XCDs and,
+// inside an XCD, to its four shader engines strictly round-robin and IN ORDER -- a workgroup
+// whose turn falls on a full shader engine holds up every later one of its XCD even while CUs of
+// the other engines idle (tools/dispatch_probe.hip: 240 long + 280 short workgroups take three
+// rounds, not two).  With items of two durations (off-diagonal and diagonal tiles) that costs
+// 15-40 % of a launch; equal durations would need split counts the tile counts do not divide.
+// Here a workgroup reads the XCD it runs on (XCC_ID), takes the next position of THAT XCD's list
+// with one integer atomic (the lists: geometry.hpp -- contiguous ranges, longest items first, the
+// tiles that share rows next to each other) and, when its own list is empty, helps the other
+// XCDs.  Results do not depend on who computes an item (every partial has its own slot, sums are
+// taken in slot order).  The next position is fetched by an idle loader wave while the compute
+// waves store the current item's partials.
+__device__ __forceinline__ int fetch_position(unsigned *queue, int xcd) {
+  return (int)__hip_atomic_fetch_add(queue + xcd * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T, bool WEIGHTED, bool GATHER, bool FUSED = false>
+__global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
+  __shared__ int s_next[2][2];                   // [parity]: {xcd, position} of the next item, xcd < 0: none
+  const kargs_ptr<T> kargs = kernarg_address<T>();
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int home = (int)(xcc & 7u);
+  const long per_xcd = a.ipx0 + a.ipx1;
+  // next real item of the lists, starting with the home XCD's: {xcd, position} or xcd = -1
+  auto fetch = [&](int &fx, int &fq, int &probe) {
+    Item tmp;
+    while (probe < 8) {
+      const int x = (home + probe) & 7;
+      const int q = fetch_position(a.queue, x);
+      if (q >= per_xcd) { ++probe; continue; }        // that list is exhausted: next XCD's
+      if (decode_slot(a, x, (long)q, tmp)) { fx = x; fq = q; return; }
+      // (a padding position of a list shorter than the others: take the next one)
+    }
+    fx = -1; fq = 0;
+  };
+  int probe = 0;                                 // lists already found empty (kept by the fetching thread)
+  if (threadIdx.x == 4 * 64) {
+    int fx, fq;
+    fetch(fx, fq, probe);
+    s_next[0][0] = fx; s_next[0][1] = fq;
+  }
+  __syncthreads();
 #ifdef CVM_STAMPS
-  fin();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), q0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int n = 0;; ++n) {
+    const int xq = uni(s_next[n & 1][0]), sq = uni(s_next[n & 1][1]);
+    if (xq < 0) break;
+    Item wi;
+    decode_slot(a, xq, (long)sq, wi);
+    wgram4_item<T, WEIGHTED, GATHER, FUSED>(a, kargs, wi, wave_all, xq, sq);
+    if (threadIdx.x == 4 * 64) {                 // loader wave 4 is done first: it fetches
+      int fx, fq;
+      fetch(fx, fq, probe);
+      s_next[(n + 1) & 1][0] = fx; s_next[(n + 1) & 1][1] = fq;
+    }
+    __syncthreads();                             // the item is finished with the LDS ring; s_next is visible
+  }
+#ifdef CVM_STAMPS
+  {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
+      unsigned long long *o = g_stamps2 + ((size_t)blockIdx.x * 8 + wave_all) * 4;
+      o[0] = c1 - c0; o[1] = q1 - q0; o[2] = q0; o[3] = q1;
+    }
+  }
 #endif
 }
