@@ -21,6 +21,11 @@ the reference's ``CVMatrix(backend="numpy")`` ("fast") and of its test oracle
   g6_digest.npz    per-fold digests at the BASELINE.json shapes C2/C3 and scaled C4/C5,
                    inputs from default_rng(42) exactly as benchmarks/benchmark.py:223-233
   g7_none.json     which statistics come back None
+  g3_loo.npz       the reference's whole leave-one-out sweep (tests/test_cvmatrix.py:1357-1396):
+                   16 flag combos x {weighted, unweighted} x ddof{0,1} x {Y, None}, first 20 folds
+  g6_strips.npz    for a few folds of the g6 configurations: 64 whole rows of XTX (16 for the
+                   K=4096 case) and the whole XTY, so that the comparison is the norm of the
+                   DIFFERENCE over a strip, not a difference of norms
 """
 
 import itertools
@@ -160,6 +165,69 @@ def g3_sweep():
     np.savez_compressed(os.path.join(HERE, "g3_sweep.npz"), **out)
 
 
+def stack_stats(stats_list):
+    """[(muX, sdX, muY, sdY)] of several folds -> (mask[4], one 2-D array per present statistic)."""
+    mask = np.array([s is not None for s in stats_list[0]])
+    arrs = [np.stack([np.asarray(st[i]).reshape(-1) for st in stats_list]) if mask[i] else None
+            for i in range(4)]
+    return mask, arrs
+
+
+def put_stacked_stats(out, key, stats_list):
+    mask, arrs = stack_stats(stats_list)
+    out[f"{key}/mask"] = mask
+    for n, a in zip(STAT_NAMES, arrs):
+        if a is not None:
+            out[f"{key}/{n}"] = a
+
+
+def g3_loo():
+    """The reference's leave-one-out sweep (tests/test_cvmatrix.py:1357-1396), on the g3 inputs:
+    every flag combination x weights x ddof x Y/None, folds = arange(N), the first 20 folds.
+    Stored stacked over the folds (one array per case and quantity)."""
+    z = np.load(os.path.join(HERE, "g3_sweep.npz"))
+    X, Xw, Y, w = z["X"], z["Xw"], z["Y"], z["w"]
+    N = X.shape[0]
+    out, cases = {}, []
+    nf = 20
+    for flags in FLAGS16:
+        for weighted in (False, True):
+            for ddof in (0, 1):
+                for hasY in (True, False):
+                    name = "loo_f{}{}{}{}_w{}_d{}_y{}".format(
+                        *[int(b) for b in flags], int(weighted), ddof, int(hasY))
+                    cases.append(name)
+                    Xc, Yc, wc = (Xw if weighted else X), (Y if hasY else None), (w if weighted else None)
+                    cX, cY, sX, sY = flags
+                    fast = CVMatrix(cX, cY, sX, sY, ddof, np.float64, True, backend="numpy")
+                    naive = NaiveCVMatrix(cX, cY, sX, sY, ddof, np.float64, True)
+                    fast.fit(Xc, Yc, wc)
+                    naive.fit(Xc, Yc, wc)
+                    fx, fy, nx, ny, st_joint, st_xtx, st_xty, st_stat = [], [], [], [], [], [], [], []
+                    for f in range(nf):
+                        v = np.array([f])
+                        t = np.delete(np.arange(N), f)
+                        if hasY:
+                            (a, b), s1 = fast.training_XTX_XTY(v)
+                            (c, d), _ = naive.training_XTX_XTY(t)
+                            fx.append(a); fy.append(b); nx.append(c); ny.append(d); st_joint.append(s1)
+                            st_xty.append(fast.training_XTY(v)[1])
+                        a, s2 = fast.training_XTX(v)
+                        st_xtx.append(s2)
+                        if not hasY:
+                            fx.append(a); nx.append(naive.training_XTX(t)[0])
+                        st_stat.append(fast.training_statistics(v))
+                    out[f"{name}/fast_XTX"], out[f"{name}/naive_XTX"] = np.stack(fx), np.stack(nx)
+                    if hasY:
+                        out[f"{name}/fast_XTY"], out[f"{name}/naive_XTY"] = np.stack(fy), np.stack(ny)
+                        put_stacked_stats(out, f"{name}/joint", st_joint)
+                        put_stacked_stats(out, f"{name}/xty", st_xty)
+                    put_stacked_stats(out, f"{name}/xtx", st_xtx)
+                    put_stacked_stats(out, f"{name}/stat", st_stat)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "g3_loo.npz"), **out)
+
+
 def g4_example():
     out = {}
     X = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9], [10, 11, 12]])
@@ -295,6 +363,34 @@ def g6_digest():
     np.savez_compressed(os.path.join(HERE, "g6_digest.npz"), **out)
 
 
+def g6_strips():
+    """Whole rows of the reference's outputs at the g6 configurations (same inputs, same runs)."""
+    out = {}
+    cfgs = [
+        ("c2", 100000, 512, 16, 10, False, (False,) * 4, np.float64, (0, 4, 9), 64),
+        ("c3", 100000, 512, 16, 10, True, (True,) * 4, np.float64, (0, 4, 9), 64),
+        ("c4s", 20000, 1024, 32, 64, True, (True,) * 4, np.float64, (0, 63), 64),
+        ("c5s", 8000, 4096, 1, 20, True, (True,) * 4, np.float32, (0, 19), 16),
+    ]
+    for name, N, K, M, P, weighted, flags, dt, folds_kept, nrows in cfgs:
+        rng = np.random.default_rng(42)
+        X = rng.random((N, K), dtype=dt)
+        Y = rng.random((N, M), dtype=dt)
+        w = rng.random((N,), dtype=dt)
+        folds = np.arange(N) % P
+        rows = np.unique(np.linspace(0, K - 1, nrows).round().astype(np.int64))
+        out[f"{name}/rows"] = rows
+        ref = CVMatrix(*flags, ddof=1, dtype=np.float64, copy=False)
+        ref.fit(X.astype(np.float64), Y.astype(np.float64), w.astype(np.float64) if weighted else None)
+        p = Partitioner(folds)
+        for f in folds_kept:
+            (xtx, xty), _ = ref.training_XTX_XTY(p.get_validation_indices(f))
+            out[f"{name}/fold{f}/XTX_rows"] = xtx[rows]
+            out[f"{name}/fold{f}/XTY"] = xty
+        print("g6 strips", name, "done", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g6_strips.npz"), **out)
+
+
 def g7_none():
     X = np.arange(1.0, 25.0).reshape(8, 3) ** 1.1
     Y = np.arange(16.0).reshape(8, 2) ** 0.9
@@ -321,5 +417,5 @@ if __name__ == "__main__":
         warnings.simplefilter("ignore", RuntimeWarning)
         for g in which:
             dict(g1=g1_inline, g2=g2_readme, g3=g3_sweep, g4=g4_example, g5=g5_errors,
-                 g6=g6_digest, g7=g7_none)[g]()
+                 g6=g6_digest, g7=g7_none, g3loo=g3_loo, g6strips=g6_strips)[g]()
             print("wrote", g, flush=True)

@@ -83,6 +83,60 @@ def run_g3_case(name, make, part, tol):
                    ddof, tol)
 
 
+def g3loo_cases():
+    z = load_npz("g3_loo.npz")
+    return [str(c) for c in z["cases"]]
+
+
+def _stacked_stats(z, key, f):
+    mask = z[f"{key}/mask"]
+    return tuple(z[f"{key}/{n}"][f].reshape(1, -1) if m else None for n, m in zip(("muX", "sdX", "muY", "sdY"), mask))
+
+
+def run_g3loo_case(name, make, tol, batched=False):
+    """One configuration of the reference's leave-one-out sweep (tests/test_cvmatrix.py:1357-1396;
+    tests/golden/g3_loo.npz): every method for the first 20 one-sample folds, against the reference's
+    fast outputs (norm-wise ``tol``) and its naive outputs (the reference's own atol 1e-8).
+    ``batched``: ask for the 20 folds in one ``*_batched`` call (product only)."""
+    z = load_npz("g3_loo.npz")
+    g = load_npz("g3_sweep.npz")
+    fl = tuple(c == "1" for c in name[5:9])
+    weighted, ddof, hasY = name[11] == "1", int(name[14]), name[17] == "1"
+    X = g["Xw"] if weighted else g["X"]
+    Y = g["Y"] if hasY else None
+    w = g["w"] if weighted else None
+    m = make(fl, ddof)
+    m.fit(X, Y, w)
+    nf = z[f"{name}/fast_XTX"].shape[0]
+    if batched:
+        folds = [np.array([f]) for f in range(nf)]
+        if hasY:
+            (bx, by), bst = m.training_XTX_XTY_batched(folds)
+            _, bst_y = m.training_XTY_batched(folds)
+        bx1, bst_x = m.training_XTX_batched(folds)
+        bstat = m.training_statistics_batched(folds)
+        pick = lambda st, f: tuple(None if s is None else s[f] for s in st)  # noqa: E731
+    for f in range(nf):
+        v = np.array([f])
+        k = f"{name} fold {f}"
+        if hasY:
+            (xtx, xty), st = ((bx[f], by[f]), pick(bst, f)) if batched else m.training_XTX_XTY(v)
+            assert_normwise(xtx, z[f"{name}/fast_XTX"][f], tol, k + " XTX")
+            assert_normwise(xty, z[f"{name}/fast_XTY"][f], tol, k + " XTY")
+            assert_stats(st, _stacked_stats(z, f"{name}/joint", f), tol, k)
+            np.testing.assert_allclose(to_np(xtx), z[f"{name}/naive_XTX"][f], atol=1e-8)
+            np.testing.assert_allclose(to_np(xty), z[f"{name}/naive_XTY"][f], atol=1e-8)
+            st_y = pick(bst_y, f) if batched else m.training_XTY(v)[1]
+            assert_stats(st_y, _stacked_stats(z, f"{name}/xty", f), tol, k + " xty")
+        xtx1, st1 = (bx1[f], pick(bst_x, f)) if batched else m.training_XTX(v)
+        assert_normwise(xtx1, z[f"{name}/fast_XTX"][f], tol, k + " xtx-only")
+        assert_stats(st1, _stacked_stats(z, f"{name}/xtx", f), tol, k + " xtx")
+        if not hasY:
+            np.testing.assert_allclose(to_np(xtx1), z[f"{name}/naive_XTX"][f], atol=1e-8)
+        st4 = pick(bstat, f) if batched else m.training_statistics(v)
+        assert_stats(st4, _stacked_stats(z, f"{name}/stat", f), tol, k + " stat")
+
+
 def run_g4(make, part, tol):
     z = load_npz("g4_example.npz")
     folds = load_json("g4_example_folds.json")
@@ -178,3 +232,26 @@ def check_digest(z, name, f, xtx, xty, st, tol, stat_rtol=None):
     assert np.abs(y64.sum(axis=0) - z[f"{k}/XTY_colsum"]).max() <= tol * my * K
     assert abs(np.trace(x64) - z[f"{k}/XTX_trace"]) <= tol * mx * K
     assert_stats(st, golden_stats(z, k), stat_rtol or max(tol, 1e-10), k)
+    check_strips(name, f, x64, y64, tol)
+
+
+_STRIPS = None
+
+
+def check_strips(name, f, x64, y64, tol):
+    """Whole rows of the reference's XTX (64 of them, spread over the matrix) and its whole XTY
+    (tests/golden/g6_strips.npz, the folds it holds): the norm of the DIFFERENCE, max-norm and
+    Frobenius, against ``tol`` times the reference's."""
+    global _STRIPS
+    if _STRIPS is None:
+        _STRIPS = load_npz("g6_strips.npz")
+    zs = _STRIPS
+    key = f"{name}/fold{f}/XTX_rows"
+    if key not in zs.files:
+        return False
+    rows, rx, ry = zs[f"{name}/rows"], zs[key], zs[f"{name}/fold{f}/XTY"]
+    for got, ref, what in ((x64[rows], rx, "XTX rows"), (y64, ry, "XTY")):
+        d = got - ref
+        assert np.abs(d).max() <= tol * np.abs(ref).max(), f"{name} fold {f} {what}: max {np.abs(d).max():.3e}"
+        assert np.linalg.norm(d) <= tol * np.linalg.norm(ref), f"{name} fold {f} {what}: Frobenius"
+    return True

@@ -65,6 +65,55 @@ def test_g3_flag_sweep(amd, name):
     pc.run_g3_case(name, make_factory(amd), amd.Partitioner, TOL)
 
 
+@pytest.mark.parametrize("chunk", range(8))
+def test_g3_leave_one_out_sweep(amd, chunk):
+    """The reference's whole leave-one-out sweep (tests/test_cvmatrix.py:1357-1396: 16 flag sets x
+    weights x ddof x Y/None, first 20 folds) against its golden outputs: one call per fold (the
+    reference's loop, indices inside the kernel arguments) and all 20 folds in one batched call."""
+    cases = pc.g3loo_cases()
+    assert len(cases) == 128
+    for name in cases[chunk::8]:
+        pc.run_g3loo_case(name, make_factory(amd), TOL)
+        pc.run_g3loo_case(name, make_factory(amd), TOL, batched=True)
+
+
+@pytest.mark.parametrize("K,weighted", [(70, True), (70, False), (500, True)])
+def test_leave_one_out_flag_sweep_rows_kernel(amd, K, weighted):
+    """Every flag combination x ddof x Y/None on the route the reference's published
+    leave-one-out benchmark takes (small_rows_kernel: one-row folds, rows that are not whole
+    128-byte lines), against the oracle (which test_oracle_golden.py pins to the reference on
+    the same 128 configurations at K = 8)."""
+    import itertools
+
+    rng = np.random.default_rng(1000 + K)
+    N, M = 90, 3
+    X = rng.random((N, K)) * 2.0 + rng.random((1, K))
+    Y = rng.standard_normal((N, M)) + 1.0
+    w = rng.random(N) + 0.05
+    w[rng.choice(N, size=9, replace=False)] = 0.0
+    folds = [np.array([f]) for f in range(24)]
+    for flags in itertools.product([False, True], repeat=4):
+        for ddof in (0, 1):
+            for hasY in (True, False):
+                m = amd.CVMatrix(*flags, ddof=ddof)
+                o = OracleCVMatrix(*flags, ddof=ddof)
+                m.fit(X, Y if hasY else None, w if weighted else None)
+                o.fit(X, Y if hasY else None, w if weighted else None)
+                what = f"K={K} flags={flags} ddof={ddof} Y={hasY}"
+                if hasY:
+                    (bx, by), bst = m.training_XTX_XTY_batched(folds)
+                else:
+                    bx, bst = m.training_XTX_batched(folds)
+                for f in (0, 7, 23):
+                    if hasY:
+                        (rx, ry), rst = o.training_XTX_XTY(folds[f])
+                        assert_normwise(by[f], ry, TOL, what + " XTY")
+                    else:
+                        rx, rst = o.training_XTX(folds[f])
+                    assert_normwise(bx[f], rx, TOL, what + " XTX")
+                    assert_stats(tuple(None if s is None else s[f] for s in bst), rst, TOL, what)
+
+
 def test_g4_example_zero_weight_and_str_label(amd):
     pc.run_g4(make_factory(amd), amd.Partitioner, TOL)
 
@@ -124,14 +173,70 @@ def test_g6_digest_fp32_c5_scaled(amd):
         y64 = to_np(by[i]).astype(np.float64)
         bound_x = max(2 * float(z[f"{k}/ref32_XTX_relfro"]), 1e-5)
         bound_y = max(2 * float(z[f"{k}/ref32_XTY_relfro"]), 1e-5)
-        # sampled entries and row sums stand in for the full matrix
+        # sampled entries everywhere; whole rows of XTX and the whole XTY where the fixtures hold
+        # them (folds 0 and 19): the norm of the difference against BASELINE.md section 4's bound,
+        # twice NumPy's own float32 error -- no extra slack
         ex = np.abs(x64[sx[:, 0], sx[:, 1]] - z[f"{k}/XTX_samp"]).max() / z[f"{k}/XTX_max"]
         ey = np.abs(y64[sy[:, 0], sy[:, 1]] - z[f"{k}/XTY_samp"]).max() / z[f"{k}/XTY_max"]
-        assert ex <= bound_x * 8 and ey <= bound_y * 8, (f, ex, ey, bound_x, bound_y)
+        assert ex <= bound_x and ey <= bound_y, (f, ex, ey, bound_x, bound_y)
+        pc.check_strips(name, f, x64, y64, min(bound_x, bound_y))
         assert abs(np.linalg.norm(x64) - z[f"{k}/XTX_fro"]) <= bound_x * z[f"{k}/XTX_fro"]
         assert abs(np.linalg.norm(y64) - z[f"{k}/XTY_fro"]) <= bound_y * z[f"{k}/XTY_fro"]
         for n_, g_ in zip(("muX", "sdX", "muY", "sdY"), bst):
             np.testing.assert_allclose(to_np(g_[i]), z[f"{k}/{n_}"], rtol=2e-5)
+
+
+# ---------------------------------------------------------------- BASELINE shapes at FULL size
+@pytest.mark.parametrize("wl", ["C4", "C5"])
+def test_full_size_properties_c4_c5(amd, hip_device, wl):
+    """C4 (N=1e6, K=1024, M=32, 64 folds, fp64) and C5 (N=2e5, K=4096, M=1, 20 folds, fp32) at
+    their FULL sizes, inputs generated on the device (bench.py's generator), checked through
+    size-independent properties:
+      (i)   partition linearity with all flags off: sum_f (G - XTX_f) = G (and the same for XTY);
+      (ii)  two folds with all flags on against a from-scratch float64 computation of the centred
+            and scaled training-set matrices (bench.direct_fold_check: library GEMMs, the naive
+            definition) -- 1e-10 norm-wise for fp64, twice NumPy's float32 error for fp32;
+      (iii) exact symmetry of every XTX, and a bitwise identical repeat."""
+    import torch
+
+    import bench
+
+    N, K, M, P, weighted, flags, npdt = bench.WORKLOADS[wl]
+    tdt = torch.float64 if npdt is np.float64 else torch.float32
+    dev = hip_device
+    Xd, Yd, wd = bench.synth_device_rows(torch, dev, torch.arange(N, device=dev), N, K, M, tdt, 42)
+    labels = torch.arange(N, device=dev) % P
+    # (i) linearity, flags off
+    m0 = amd.CVMatrix(False, False, False, False, dtype=npdt, copy=False)
+    m0.fit(Xd, Yd, wd)
+    batch = m0.prepare_folds_from_labels(labels, P)
+    (bx, by), _ = m0.training_XTX_XTY_batched(batch)
+    G, H = m0.XTX.double(), m0.XTY.double()
+    lin_x = (P * G - bx.double().sum(0) - G).abs().max() / G.abs().max()
+    lin_y = (P * H - by.double().sum(0) - H).abs().max() / H.abs().max()
+    lin_tol = 1e-11 if npdt is np.float64 else 5e-6   # (20 float32 roundings of magnitude |G|)
+    assert float(lin_x) <= lin_tol and float(lin_y) <= lin_tol, (float(lin_x), float(lin_y))
+    del bx, by, m0
+    torch.cuda.empty_cache()
+    # (ii) + (iii), all flags on
+    m = amd.CVMatrix(*flags, ddof=1, dtype=npdt, copy=False)
+    m.fit(Xd, Yd, wd)
+    batch = m.prepare_folds_from_labels(labels, P)
+    (bx, by), st = m.training_XTX_XTY_batched(batch)
+    assert bool((bx == bx.transpose(1, 2)).all())
+    if npdt is np.float64:
+        bound = 1e-10
+    else:
+        z = load_npz("g6_digest.npz")
+        bound = 2 * min(float(z["c5s/fold0/ref32_XTX_relfro"]), float(z["c5s/fold0/ref32_XTY_relfro"]))
+    for f in (0, P - 1):
+        val = torch.nonzero(labels == batch.labels[f]).reshape(-1)
+        got = (bx[f], by[f], st[0][f], st[1][f])
+        errs = bench.direct_fold_check(torch, None, 1, Xd, Yd, wd, val, 0, 0, 1, flags, got, dev)
+        assert errs[0] <= bound and errs[1] <= bound, (wl, f, errs, bound)
+        assert errs[2] <= max(bound * 1e-2, 1e-10) and errs[3] <= max(bound * 1e-2, 1e-10), (wl, f, errs)
+    (cx, cy), _ = m.training_XTX_XTY_batched(batch)
+    assert torch.equal(cx, bx) and torch.equal(cy, by)
 
 
 # ---------------------------------------------------------------- oracle on seeded inputs

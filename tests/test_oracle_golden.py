@@ -36,6 +36,14 @@ def test_g3_flag_sweep():
         pc.run_g3_case(name, make, OraclePartitioner, TOL)
 
 
+def test_g3_leave_one_out_sweep():
+    """The reference's whole leave-one-out sweep (tests/test_cvmatrix.py:1357-1396): 128 cases."""
+    cases = pc.g3loo_cases()
+    assert len(cases) == 128
+    for name in cases:
+        pc.run_g3loo_case(name, make, TOL)
+
+
 def test_g3_naive_restatement_matches_reference_naive():
     """The oracle's direct (training-index) computation vs the reference's NaiveCVMatrix."""
     z = load_npz("g3_sweep.npz")
