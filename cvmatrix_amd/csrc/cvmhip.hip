@@ -183,24 +183,35 @@ int cvm_sweep_fit(const void *X, const void *Y, const void *w, const int64_t *id
   return fail(CVM_EINVAL, "cvm_sweep_fit: dtype must be CVM_F32 or CVM_F64%s");
 }
 
+int cvm_sweep_fold_range(const int64_t *offsets, int64_t n_total, int64_t fold0, int64_t n_folds, int K, int M,
+                         int dtype, unsigned flags, double ddof, double resolution, int weighted, const void *G,
+                         const void *H, const double *gstats, void *out_XTX, void *out_XTY, void *out_muX,
+                         void *out_sdX, void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
+                         int64_t splits, void *stream) {
+  if (!offsets || !G || !gstats || !ws) return fail(CVM_EINVAL, "cvm_sweep_folds: null pointer%s");
+  if (n_total <= 0 || fold0 < 0 || n_folds <= 0 || fold0 + n_folds > n_total || K <= 0 || M < 0 || splits <= 0)
+    return fail(CVM_EINVAL, "cvm_sweep_folds: bad shape%s");
+  if ((flags & CVM_RET_XTY) && (M == 0 || !H))
+    return fail(CVM_EINVAL, "cvm_sweep_folds: CVM_RET_XTY needs Y and H%s");
+  if (dtype == CVM_F64)
+    return sweep_folds_impl<double>(offsets, n_total, fold0, n_folds, K, M, dtype, flags, ddof, resolution, weighted,
+                                    G, H, gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold,
+                                    ws, ws_bytes, splits, (hipStream_t)stream);
+  if (dtype == CVM_F32)
+    return sweep_folds_impl<float>(offsets, n_total, fold0, n_folds, K, M, dtype, flags, ddof, resolution, weighted,
+                                   G, H, gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold,
+                                   ws, ws_bytes, splits, (hipStream_t)stream);
+  return fail(CVM_EINVAL, "cvm_sweep_folds: dtype must be CVM_F32 or CVM_F64%s");
+}
+
 int cvm_sweep_folds(const int64_t *offsets, int64_t n_folds, int K, int M, int dtype, unsigned flags,
                     double ddof, double resolution, int weighted, const void *G, const void *H,
                     const double *gstats, void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX,
                     void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
                     int64_t splits, void *stream) {
-  if (!offsets || !G || !gstats || !ws) return fail(CVM_EINVAL, "cvm_sweep_folds: null pointer%s");
-  if (n_folds <= 0 || K <= 0 || M < 0 || splits <= 0) return fail(CVM_EINVAL, "cvm_sweep_folds: bad shape%s");
-  if ((flags & CVM_RET_XTY) && (M == 0 || !H))
-    return fail(CVM_EINVAL, "cvm_sweep_folds: CVM_RET_XTY needs Y and H%s");
-  if (dtype == CVM_F64)
-    return sweep_folds_impl<double>(offsets, n_folds, K, M, dtype, flags, ddof, resolution, weighted, G, H,
-                                    gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold,
-                                    ws, ws_bytes, splits, (hipStream_t)stream);
-  if (dtype == CVM_F32)
-    return sweep_folds_impl<float>(offsets, n_folds, K, M, dtype, flags, ddof, resolution, weighted, G, H,
-                                   gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold,
-                                   ws, ws_bytes, splits, (hipStream_t)stream);
-  return fail(CVM_EINVAL, "cvm_sweep_folds: dtype must be CVM_F32 or CVM_F64%s");
+  return cvm_sweep_fold_range(offsets, n_folds, 0, n_folds, K, M, dtype, flags, ddof, resolution, weighted, G, H,
+                              gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes,
+                              splits, stream);
 }
 
 size_t cvm_partition_workspace_bytes(int64_t N, int n_labels) { return partition_workspace_bytes(N, n_labels); }

@@ -656,24 +656,27 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
 }
 
 template <typename T>
-int sweep_folds_impl(const int64_t *offsets, int64_t n_folds, int K, int M, int dtype, unsigned flags,
-                     double ddof, double resolution, int weighted, const void *G, const void *H,
+int sweep_folds_impl(const int64_t *offsets, int64_t n_total, int64_t fold0, int64_t n_folds, int K, int M, int dtype,
+                     unsigned flags, double ddof, double resolution, int weighted, const void *G, const void *H,
                      const double *gstats, void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX,
                      void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
                      int64_t splits, hipStream_t st) {
+  // folds [fold0, fold0 + n_folds) of the n_total folds whose partials cvm_sweep_fit left in ws;
+  // outputs are written from index 0
   const Geom g = make_geom(K, M, sizeof(T), 0);
   Plan p;
   p.g = g;
   set_plan_splits(p, (int)(splits & 0xfffff), (int)(splits >> 20));
   if (p.s_off < 1 || p.s_diag < 1) return fail(CVM_EINVAL, "cvm_sweep_folds: not a plan token of cvm_sweep_fit%s");
-  const size_t units = (size_t)n_folds * (size_t)p.splits * g.unit_bytes;
-  if (units + (size_t)n_folds * fstat_len(K, M) * 8 > ws_bytes)
+  const size_t units = (size_t)n_total * (size_t)p.splits * g.unit_bytes;
+  if (units + (size_t)n_total * fstat_len(K, M) * 8 > ws_bytes)
     return fail(CVM_EWORKSPACE, "cvm_sweep_folds: workspace smaller than the one cvm_sweep_fit filled%s");
   FinArgs f;
   memset(&f, 0, sizeof(f));
-  f.g = g; set_fin_splits(f, p, 1); f.n_seg = (int)n_folds; f.seg0 = 0; f.ws = (const char *)ws;
-  f.fstats = (double *)((char *)ws + units);
-  f.offs = offsets; f.w = weighted ? (const void *)G : nullptr;   // non-null = weighted
+  f.g = g; set_fin_splits(f, p, 1); f.n_seg = (int)n_folds; f.seg0 = 0;
+  f.ws = (const char *)ws + (size_t)fold0 * (size_t)p.splits * g.unit_bytes;
+  f.fstats = (double *)((char *)ws + units) + (size_t)fold0 * fstat_len(K, M);
+  f.offs = offsets + fold0; f.w = weighted ? (const void *)G : nullptr;   // non-null = weighted
   f.G = G; f.H = H; f.gstats = gstats;
   f.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
   f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .partitioner import Partitioner
+from .partitioner import Partitioner, partitioner_of
 
 MSG_NEG_W = "Weights must be non-negative."
 MSG_NZ_ZERO = (
@@ -65,6 +65,7 @@ class FoldBatch:
         self._sizes = None
         self._device = device
         self._w_gen = w_gen     # CVMatrix._w_gen the non-zero counts were computed for
+        self._source = None     # the Partitioner the batch was prepared from, if any
 
     # one fold of at most 32 rows is created without device arrays: the matrix calls hand its
     # indices to the library from the host (CVM_IDX_HOST); anything else uploads them on demand
@@ -182,6 +183,8 @@ class CVMatrix:
         self._ws = None
         self._sweep = None
         self._sweep_ws = None
+        self._sweep_ids = None
+        self._auto_sweep_tried = None
         self.sweep_folds = None
         self._w_checked = None
         self._w_checked_src = None
@@ -339,6 +342,8 @@ class CVMatrix:
         self.device = self._pick_device()
         # nothing of an earlier fit may survive a fit that raises half-way
         self._sweep = None
+        self._sweep_ids = None
+        self._auto_sweep_tried = None
         self._pending = False
         self._np_cache = {}
         with torch.cuda.device(self.device):
@@ -418,6 +423,15 @@ class CVMatrix:
         _lib.check(rc, "cvm_sweep_fit")
         self._sweep = (batch, int(splits.value))
         self.sweep_folds = batch
+        # the folds of a Partitioner can later be asked for one at a time with the very arrays it
+        # holds (the reference's loop): remember them by identity + a cheap fingerprint
+        src = batch._source
+        self._sweep_ids = None
+        if src is not None and len(src._fold_arrays) == P:
+            arrs = src._fold_arrays
+            self._sweep_ids = ({id(a): i for i, a in enumerate(arrs)},
+                               [(a.size, int(a[0]) if a.size else -1, int(a[-1]) if a.size else -1) for a in arrs],
+                               arrs)
 
     @staticmethod
     def _weights_key(w):
@@ -551,7 +565,9 @@ class CVMatrix:
                 folds._w_gen = self._w_gen
             return folds
         labels = None
+        source = None
         if isinstance(folds, Partitioner):
+            source = folds
             labels = list(folds.folds_dict)
             folds = list(folds.folds_dict.values())
         if not isinstance(folds, (list, tuple)):
@@ -601,7 +617,9 @@ class CVMatrix:
             d_all.copy_(stage[:n_all], non_blocking=True)
             self._stage_events[self._stage_next - 1].record()
         d_off, d_idx = d_all[:n_off], d_all[n_off:]
-        return FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N, w_gen=self._w_gen)
+        fb = FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N, w_gen=self._w_gen)
+        fb._source = source
+        return fb
 
     def _nz_counts_host(self, idx: np.ndarray, host_offsets: np.ndarray, sizes: np.ndarray) -> np.ndarray:
         """Non-zero weights among each fold's validation rows (exact integer counts for the
@@ -704,29 +722,31 @@ class CVMatrix:
             self._stage_events[k] = torch.cuda.Event()
         return buf
 
-    def _validate(self, batch: FoldBatch, need_stats: bool, need_std: bool) -> None:
+    def _validate(self, batch, need_stats: bool, need_std: bool, only: Optional[int] = None) -> None:
         """The reference's data-dependent raises, in its order (zero check first, weighted
-        only: cvmatrix.py:612-630; then ddof: 1074-1078), decided on exact host counts."""
+        only: cvmatrix.py:612-630; then ddof: 1074-1078), decided on exact host counts.
+        ``only``: check fold ``only`` of the batch alone."""
         if not need_stats:
             return
         self._resolve_totals()
+        sel = slice(None) if only is None else slice(only, only + 1)
         if self.weights is not None:
-            nz_train = self._nz_total - batch.nz_val
+            nz_train = self._nz_total - batch.nz_val[sel]
             if np.any(nz_train == 0):
                 raise ValueError(MSG_NZ_ZERO)
         else:
-            nz_train = self._n_total - batch.sizes
+            nz_train = self._n_total - batch.sizes[sel]
         if need_std and np.any(nz_train <= self.ddof):
             raise ValueError(MSG_NZ_DDOF)
 
     def _run(self, batch: FoldBatch, rXTX: bool, rXTY: bool, stat_flags=None,
-             stats_only: bool = False):
+             stats_only: bool = False, sweep_fold: Optional[int] = None):
         """One cvm_fold_update call over ``batch``.  Returns raw stacked device tensors.
         ``stats_only``: keep the return flags (they select which statistics the kernel
         derives, cvmatrix.py:828-831) but produce no matrices."""
         lib = _lib.load()
         self._ensure_fit()
-        K, M, P = self.K, self.M or 0, batch.n_folds
+        K, M, P = self.K, self.M or 0, (batch.n_folds if sweep_fold is None else 1)
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         if stat_flags is not None:
             cX, cY, sX, sY = stat_flags
@@ -746,15 +766,16 @@ class CVMatrix:
             sweep = getattr(self, "_sweep", None)
             if sweep is not None and sweep[0] is batch:
                 # the partials of exactly these folds are still in the sweep workspace
-                rc = lib.cvm_sweep_folds(
-                    batch.offsets.data_ptr(), P, K, M, self._cdt, flags, float(self.ddof),
+                rc = lib.cvm_sweep_fold_range(
+                    batch.offsets.data_ptr(), batch.n_folds, 0 if sweep_fold is None else sweep_fold, P,
+                    K, M, self._cdt, flags, float(self.ddof),
                     float(self.resolution), 1 if self.weights is not None else 0,
                     self._G.data_ptr(), _lib.ptr(self._H), self._gs.data_ptr(),
                     _lib.ptr(out_XTX), _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(),
                     _lib.ptr(muY), _lib.ptr(sdY), out_fold.data_ptr(),
                     self._sweep_ws.data_ptr(), self._sweep_ws.numel(), sweep[1], self._stream(),
                 )
-                _lib.check(rc, "cvm_sweep_folds")
+                _lib.check(rc, "cvm_sweep_fold_range")
                 return out_XTX, out_XTY, (muX, sdX, muY, sdY), out_fold
             sizes = batch.sizes
             want = lib.cvm_fold_workspace_bytes(P, int(batch.host_offsets[-1]),
@@ -788,13 +809,18 @@ class CVMatrix:
             raise ValueError(MSG_NO_Y)
         batch = self.prepare_folds(folds)
         self._lazy_sweep(batch)
+        return self._finish(batch, rXTX, rXTY)
+
+    def _finish(self, batch, rXTX: bool, rXTY: bool, sweep_fold: Optional[int] = None):
+        """Validity checks + the fold-stage launch for ``batch`` (or for fold ``sweep_fold`` of the
+        batch the sweep served)."""
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         r_muX = cX or (rXTY and cY)                 # cvmatrix.py:828-831
         r_muY = rXTY and (cX or cY)
         r_sdX = sX
         r_sdY = rXTY and sY
-        self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY)
-        xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY)
+        self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
+        xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY, sweep_fold=sweep_fold)
         o = self._out
         stats = (o(muX) if r_muX else None, o(sdX) if r_sdX else None,
                  o(muY) if r_muY else None, o(sdY) if r_sdY else None)
@@ -826,14 +852,85 @@ class CVMatrix:
             mats = mats[0]
         return mats, tuple(None if s is None else s[0] for s in stats)
 
+    def _sweep_fold_of(self, v) -> Optional[int]:
+        """Is ``v`` -- handed to a one-fold call -- the very index array a ``Partitioner`` holds
+        for one of the folds a sweep has served (or can serve: a lazy fit is pending and the
+        Partitioner's folds partition the rows)?  Then its number in that sweep, else None.
+        This is what makes the reference's loop (README.md:120-141)
+        ``for fold in p.folds_dict: cvm.training_XTX_XTY(p.get_validation_indices(fold))``
+        cost one pass over the data plus two small kernels per call."""
+        if type(v) is not np.ndarray:
+            return None
+        if self.__dict__.get("_pending", False):
+            p = partitioner_of(v)
+            if p is not None and p is not self._auto_sweep_tried:
+                self._auto_sweep_tried = p          # (one attempt per fit and Partitioner)
+                batch = self.prepare_folds(p)
+                self._lazy_sweep(batch)             # sweeps if the folds partition the rows and are large
+        ids = self._sweep_ids
+        if ids is None or self._sweep is None:
+            return None
+        i = ids[0].get(id(v))
+        if i is None or ids[2][i] is not v:
+            return None
+        size, first, last = ids[1][i]
+        if v.size != size or (size and (int(v[0]) != first or int(v[-1]) != last)):
+            return None                             # the array was changed since the sweep: recompute
+        return i
+
     def _training_matrices(self, return_XTX: bool, return_XTY: bool, val_indices):
         """cvmatrix.py:754-896 for one fold."""
         if not return_XTX and not return_XTY:
             raise ValueError(MSG_NEITHER)
         if self.X is not None and return_XTY and self.Y is None:
             raise ValueError(MSG_NO_Y)
+        if self.X is not None:
+            i = self._sweep_fold_of(val_indices)
+            if i is not None:
+                return self._finish_sweep_fold(i, return_XTX, return_XTY)
         return self._first(
             self._training_matrices_batched(return_XTX, return_XTY, [val_indices]))
+
+    def _finish_sweep_fold(self, i: int, rXTX: bool, rXTY: bool):
+        """One fold of the sweep, finished on its own (cvm_sweep_fold_range): the short path of
+        the reference's per-fold loop -- validity verdicts cached per sweep, one allocation for
+        the statistics, results without a fold axis."""
+        lib = _lib.load()
+        batch, token = self._sweep
+        K, M = self.K, self.M or 0
+        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
+        r_muX = cX or (rXTY and cY)                 # cvmatrix.py:828-831
+        r_muY = rXTY and (cX or cY)
+        r_sdX = sX
+        r_sdY = rXTY and sY
+        self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=i)
+        flags = ((_lib.RET_XTX if rXTX else 0) | (_lib.RET_XTY if rXTY else 0)
+                 | (_lib.CENTER_X if cX else 0) | (_lib.CENTER_Y if cY else 0)
+                 | (_lib.SCALE_X if sX else 0) | (_lib.SCALE_Y if sY else 0))
+        dev, dt = self.device, self._tdt
+        if torch.cuda.current_device() != dev.index:
+            torch.cuda.set_device(dev)
+        xtx = torch.empty((K, K), dtype=dt, device=dev) if rXTX else None
+        xty = torch.empty((K, M), dtype=dt, device=dev) if rXTY else None
+        stat = torch.empty(2 * K + 2 * M, dtype=dt, device=dev)
+        base, es = stat.data_ptr(), stat.element_size()
+        rc = lib.cvm_sweep_fold_range(
+            batch.offsets.data_ptr(), batch.n_folds, i, 1, K, M, self._cdt, flags, float(self.ddof),
+            float(self.resolution), 1 if self.weights is not None else 0,
+            self._G.data_ptr(), _lib.ptr(self._H), self._gs.data_ptr(),
+            _lib.ptr(xtx), _lib.ptr(xty), base, base + K * es,
+            (base + 2 * K * es) if M else 0, (base + (2 * K + M) * es) if M else 0, 0,
+            self._sweep_ws.data_ptr(), self._sweep_ws.numel(), token, self._stream(),
+        )
+        _lib.check(rc, "cvm_sweep_fold_range")
+        o = self._out
+        stats = (o(stat[:K].view(1, K)) if r_muX else None,
+                 o(stat[K:2 * K].view(1, K)) if r_sdX else None,
+                 o(stat[2 * K:2 * K + M].view(1, M)) if r_muY else None,
+                 o(stat[2 * K + M:].view(1, M)) if r_sdY else None)
+        if rXTX and rXTY:
+            return (o(xtx), o(xty)), stats
+        return (o(xtx) if rXTX else o(xty)), stats
 
     def training_XTX(self, validation_indices):
         """Training-set ``XᵀWX`` for every sample except ``validation_indices`` and

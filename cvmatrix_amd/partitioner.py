@@ -8,11 +8,30 @@ offsets, the layout ``cvm_fold_update`` (include/cvmhip.h) consumes."""
 
 from __future__ import annotations
 
+import weakref
 from collections.abc import Hashable
-from typing import Iterable, Tuple
+from typing import Iterable, Optional, Tuple
 
 import numpy as np
 import numpy.typing as npt
+
+# id(index array) -> the Partitioner that owns it (entries vanish with the Partitioner).  It lets
+# ``CVMatrix.training_*(p.get_validation_indices(fold))`` -- the reference's call pattern,
+# README.md:120-141 -- recognise that the indices it was handed are one fold of a known partition
+# of the rows, and serve all of that partition's folds from one sweep over the data.
+_OWNER: "weakref.WeakValueDictionary[int, Partitioner]" = weakref.WeakValueDictionary()
+_REGISTER_MAX_FOLDS = 4096
+
+
+def partitioner_of(indices) -> "Optional[Partitioner]":
+    """The live ``Partitioner`` whose ``folds_dict`` holds exactly this array object, if any."""
+    p = _OWNER.get(id(indices))
+    if p is None:
+        return None
+    pos = p._fold_pos.get(id(indices))
+    if pos is None or p._fold_arrays[pos] is not indices:
+        return None
+    return p
 
 
 class Partitioner:
@@ -28,6 +47,12 @@ class Partitioner:
     def __init__(self, folds: Iterable[Hashable]) -> None:
         self.folds_dict: dict[Hashable, npt.NDArray[np.int_]] = {}
         self._init_folds_dict(folds)
+        self._fold_arrays = list(self.folds_dict.values())
+        self._fold_pos: dict = {}
+        if len(self._fold_arrays) <= _REGISTER_MAX_FOLDS:
+            for i, a in enumerate(self._fold_arrays):
+                self._fold_pos[id(a)] = i
+                _OWNER[id(a)] = self
 
     def get_validation_indices(self, fold: Hashable) -> npt.NDArray[np.int_]:
         """Index array of the samples labelled ``fold`` (partitioner.py:61-87)."""

@@ -142,6 +142,15 @@ int cvm_sweep_folds(const int64_t *offsets, int64_t n_folds, int K, int M, int d
                     void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
                     int64_t splits, void *stream);
 
+/* The same for folds [fold0, fold0 + n_folds) of the n_total folds of the sweep; outputs are written
+ * from index 0.  Serves the reference's one-call-per-fold loop (README.md:120-141) from the sweep's
+ * partials: training_XTX_XTY(p.get_validation_indices(fold)) then costs two small finalize kernels. */
+int cvm_sweep_fold_range(const int64_t *offsets, int64_t n_total, int64_t fold0, int64_t n_folds, int K, int M,
+                         int dtype, unsigned flags, double ddof, double resolution, int weighted, const void *G,
+                         const void *H, const double *gstats, void *out_XTX, void *out_XTY, void *out_muX,
+                         void *out_sdX, void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
+                         int64_t splits, void *stream);
+
 /* Device-side Partitioner (replaces cvmatrix/partitioner.py:89-107 for integer labels):
  *   labels      int64[N], one fold label per row, each in [0, n_labels), n_labels <= 4096
  *   idx_out     int64[N]           row numbers grouped by label, ascending inside a group

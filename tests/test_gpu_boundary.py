@@ -166,3 +166,62 @@ def test_fit_that_raises_leaves_no_pending_state(amd):
     with pytest.raises(ValueError):
         m.fit(rng.random((100, 8)), rng.random((90, 2)))          # row mismatch, raised after X is stored
     assert not m._pending and m._sweep is None
+
+
+def test_reference_loop_is_served_from_one_sweep(amd, hip_device):
+    """The reference's loop -- fit, then training_XTX_XTY(p.get_validation_indices(fold)) per fold --
+    with the default (lazy, private copies) object: the first call recognises the Partitioner's
+    own index array, sweeps all folds once, and every call returns the batched path's bits.  Other
+    index arrays (copies, other folds, a second Partitioner) take the ordinary route and agree to
+    rounding; statistics-only and XTX-only / XTY-only calls work from the same sweep."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    N, K, M, P = 6000, 96, 4, 6
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N) + 0.01
+    p = amd.Partitioner(rng.integers(0, P, size=N))
+    ref = amd.CVMatrix(lazy_fit=False)
+    ref.fit(X, Y, w)
+    (bx, by), bst = ref.training_XTX_XTY_batched(p)
+    m = amd.CVMatrix()                               # copy=True -> lazy
+    m.fit(X, Y, w)
+    assert m._pending
+    keys = list(p.folds_dict)
+    for i, k in enumerate(keys):
+        (xtx, xty), st = m.training_XTX_XTY(p.get_validation_indices(k))
+        if i == 0:
+            assert not m._pending and m._sweep is not None and m._sweep_ids is not None
+        assert_normwise(xtx, bx[i].cpu().numpy(), 1e-11, "loop XTX")
+        assert_normwise(xty, by[i].cpu().numpy(), 1e-11, "loop XTY")
+        for a, b in zip(st, bst):
+            np.testing.assert_allclose(a.cpu().numpy(), b[i].cpu().numpy(), rtol=1e-11)
+    # bits of the batched sweep path
+    m2 = amd.CVMatrix()
+    m2.fit(X, Y, w)
+    (sx, sy), sst = m2.training_XTX_XTY_batched(p)
+    assert m2._sweep is not None
+    for i, k in enumerate(keys):
+        (xtx, xty), st = m.training_XTX_XTY(p.get_validation_indices(k))
+        assert torch.equal(xtx, sx[i]) and torch.equal(xty, sy[i])
+        x_only, st_x = m.training_XTX(p.get_validation_indices(k))
+        y_only, st_y = m.training_XTY(p.get_validation_indices(k))
+        assert torch.equal(x_only, sx[i]) and torch.equal(y_only, sy[i])
+        assert st_x[2] is None and st_x[3] is None and all(s is not None for s in st_y)
+    # a copy of the indices is not recognised: ordinary route, same numbers to rounding
+    v = p.get_validation_indices(keys[2]).copy()
+    (xtx, xty), _ = m.training_XTX_XTY(v)
+    assert_normwise(xtx, sx[2].cpu().numpy(), 1e-11, "copy of the indices")
+    # an array changed in place after the sweep is not served from it
+    v2 = p.get_validation_indices(keys[1])
+    saved = v2.copy()
+    v2[0], v2[-1] = v2[-1], v2[0]
+    (xtx, _), _ = m.training_XTX_XTY(v2)
+    assert_normwise(xtx, sx[1].cpu().numpy(), 1e-11, "permuted fold")
+    v2[:] = saved
+    # folds that do not partition the rows: no sweep, the fit kernel runs
+    q = amd.Partitioner(np.arange(N) % 5)
+    m3 = amd.CVMatrix()
+    m3.fit(X, Y, w)
+    sub = q.get_validation_indices(0)[:500].copy()
+    m3.training_XTX_XTY(sub)
+    assert m3._sweep is None and not m3._pending

@@ -224,17 +224,19 @@ def test_full_size_properties_c4_c5(amd, hip_device, wl):
     batch = m.prepare_folds_from_labels(labels, P)
     (bx, by), st = m.training_XTX_XTY_batched(batch)
     assert bool((bx == bx.transpose(1, 2)).all())
-    if npdt is np.float64:
-        bound = 1e-10
-    else:
-        z = load_npz("g6_digest.npz")
-        bound = 2 * min(float(z["c5s/fold0/ref32_XTX_relfro"]), float(z["c5s/fold0/ref32_XTY_relfro"]))
     for f in (0, P - 1):
         val = torch.nonzero(labels == batch.labels[f]).reshape(-1)
         got = (bx[f], by[f], st[0][f], st[1][f])
-        errs = bench.direct_fold_check(torch, None, 1, Xd, Yd, wd, val, 0, 0, 1, flags, got, dev)
-        assert errs[0] <= bound and errs[1] <= bound, (wl, f, errs, bound)
-        assert errs[2] <= max(bound * 1e-2, 1e-10) and errs[3] <= max(bound * 1e-2, 1e-10), (wl, f, errs)
+        errs = bench.direct_fold_check(torch, None, 1, Xd, Yd, wd, val, 0, 0, 1, flags, got, dev,
+                                       yardstick=npdt is np.float32)
+        if npdt is np.float64:
+            bx_, by_, bs_ = 1e-10, 1e-10, 1e-10
+        else:
+            # at most twice the error the reference's algorithm makes in
+            # plain float32 on the same problem (bench.fp32_algorithm_error), no other slack
+            bx_, by_, bs_ = 2 * errs[4], 2 * errs[5], 1e-6
+        assert errs[0] <= bx_ and errs[1] <= by_, (wl, f, errs)
+        assert errs[2] <= bs_ and errs[3] <= bs_, (wl, f, errs)
     (cx, cy), _ = m.training_XTX_XTY_batched(batch)
     assert torch.equal(cx, bx) and torch.equal(cy, by)
 
