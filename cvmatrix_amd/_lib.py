@@ -88,9 +88,9 @@ def load():
     lib.cvm_sweep_fold_range.argtypes = [vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, u32, dbl, dbl, C.c_int,
                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, vp]
     lib.cvm_partition_workspace_bytes.restype = sz
-    lib.cvm_partition_workspace_bytes.argtypes = [i64, C.c_int]
+    lib.cvm_partition_workspace_bytes.argtypes = [i64, i64]
     lib.cvm_partition_labels.restype = C.c_int
-    lib.cvm_partition_labels.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp, vp, sz, vp]
+    lib.cvm_partition_labels.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]
     lib.cvm_pls_workspace_bytes.restype = sz
     lib.cvm_pls_workspace_bytes.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cvm_pls_fit.restype = C.c_int

@@ -214,9 +214,9 @@ int cvm_sweep_folds(const int64_t *offsets, int64_t n_folds, int K, int M, int d
                               splits, stream);
 }
 
-size_t cvm_partition_workspace_bytes(int64_t N, int n_labels) { return partition_workspace_bytes(N, n_labels); }
+size_t cvm_partition_workspace_bytes(int64_t N, int64_t n_labels) { return partition_workspace_bytes(N, n_labels); }
 
-int cvm_partition_labels(const int64_t *labels, int64_t N, int n_labels, int64_t *idx_out,
+int cvm_partition_labels(const int64_t *labels, int64_t N, int64_t n_labels, int64_t *idx_out,
                          int64_t *offsets_out, int64_t *first_out, int32_t *err_flag, void *ws,
                          size_t ws_bytes, void *stream) {
   if (!labels || !idx_out || !offsets_out || !first_out || !err_flag || !ws || N < 0)

@@ -6,12 +6,20 @@
 #pragma once
 
 constexpr int PART_THREADS = 256;
-constexpr int PART_MAXL = 4096;     // labels per call (LDS histogram); more: use the host Partitioner
+constexpr int PART_MAXL = 4096;     // histogram bins of one pass (LDS); more labels: several passes
+constexpr int PART_DIGIT_BITS = 12;
+// More than 4096 labels (leave-one-out: one label per row): the same stable counting sort applied
+// to the labels' 12-bit digits, least significant first (an LSD radix sort of (label, row) pairs:
+// every pass keeps the order of equal digits, so rows end up ascending inside a label); the
+// offsets and first appearances are then read off the sorted sequence.
 
 struct PartArgs {
   const int64_t *labels;
+  const int64_t *seq_in;            // rows in their current order (nullptr: 0, 1, 2, ...)
+  int shift, digit_mask;            // this pass sorts by (label >> shift) & digit_mask (mask 0: the label itself)
+  int64_t Lfull;                    // labels must lie in [0, Lfull)
   int64_t N, chunk;                 // rows, rows per block
-  int L, nb;                        // labels, blocks
+  int L, nb;                        // bins of this pass, blocks
   int *blockhist;                   // [nb][L]
   int64_t *blockoff;                // [nb][L]
   unsigned long long *first;        // [L] first row of each label (N: label absent)
@@ -33,10 +41,16 @@ __global__ __launch_bounds__(PART_THREADS) void part_hist_kernel(const PartArgs 
   const int64_t r0 = (int64_t)blockIdx.x * a.chunk;
   const int64_t r1 = r0 + a.chunk < a.N ? r0 + a.chunk : a.N;
   for (int64_t i = r0 + threadIdx.x; i < r1; i += PART_THREADS) {
-    const int64_t l = a.labels[i];
-    if (l < 0 || l >= a.L) { *a.err = 1; continue; }
+    const int64_t row = a.seq_in ? a.seq_in[i] : i;
+    int64_t l = a.labels[row];
+    if (l < 0 || l >= a.Lfull) {
+      *a.err = 1;
+      if (!a.digit_mask) continue;
+      l = 0;                 // (several passes: the row stays in the sequence; the result is void anyway)
+    }
+    if (a.digit_mask) l = (l >> a.shift) & a.digit_mask;
     atomicAdd(&hist[l], 1);
-    atomicMin(&a.first[l], (unsigned long long)i);
+    if (!a.digit_mask) atomicMin(&a.first[l], (unsigned long long)i);
   }
   __syncthreads();
   for (int l = threadIdx.x; l < a.L; l += PART_THREADS) a.blockhist[(size_t)blockIdx.x * a.L + l] = hist[l];
@@ -79,14 +93,20 @@ __global__ __launch_bounds__(PART_THREADS) void part_scatter_kernel(const PartAr
       if (wave == w) {
         const int64_t i = t0 + 64 * w + lane;
         long long l = -1;
-        if (i < r1) { l = a.labels[i]; if (l < 0 || l >= a.L) l = -1; }
+        int64_t row = i;
+        if (i < r1) {
+          row = a.seq_in ? a.seq_in[i] : i;
+          l = a.labels[row];
+          if (l < 0 || l >= a.Lfull) l = a.digit_mask ? 0 : -1;
+          if (l >= 0 && a.digit_mask) l = (l >> a.shift) & a.digit_mask;
+        }
         int lower = 0, total = 0;
         for (int j = 0; j < 64; ++j) {
           const long long lj = __shfl(l, j);
           if (lj == l) { ++total; if (j < lane) ++lower; }
         }
         if (l >= 0) {
-          a.idx_out[cursor[l] + lower] = i;
+          a.idx_out[cursor[l] + lower] = row;
           if (lower == total - 1) cursor[l] += total;   // the group's last lane moves the cursor on
         }
       }
@@ -95,32 +115,93 @@ __global__ __launch_bounds__(PART_THREADS) void part_scatter_kernel(const PartAr
   }
 }
 
-inline size_t partition_workspace_bytes(int64_t N, int L) {
-  (void)N;
-  const size_t nb = 256;
-  return align_up(nb * (size_t)L * sizeof(int), 256) + align_up(nb * (size_t)L * sizeof(int64_t), 256) +
-         align_up((size_t)L * 8, 256) + 256;
+// after a multi-pass sort: offsets[l] = position of the first row with label >= l, first[l] = its
+// row number (N if the label does not occur)
+__global__ void part_offsets_kernel(const int64_t *labels, const int64_t *seq, int64_t N, int64_t L,
+                                    int64_t *offsets, int64_t *first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t cur = labels[seq[i]];
+  const int64_t prev = i > 0 ? labels[seq[i - 1]] : -1;
+  if (cur < 0 || cur >= L || prev >= L) return;      // (bad labels: the error flag is already set)
+  for (int64_t l = prev + 1; l <= cur; ++l) { offsets[l] = i; first[l] = (l == cur) ? seq[i] : N; }
+  if (i == N - 1)
+    for (int64_t l = cur + 1; l <= L; ++l) { offsets[l] = N; if (l < L) first[l] = N; }
+}
+__global__ void part_empty_kernel(int64_t L, int64_t *offsets, int64_t *first) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l <= L) offsets[l] = 0;
+  if (l < L) first[l] = 0;
 }
 
-inline int partition_impl(const int64_t *labels, int64_t N, int L, int64_t *idx_out, int64_t *offsets,
+inline int part_passes(int64_t L) {
+  int p = 1;
+  while (p * PART_DIGIT_BITS < 63 && (L - 1) >> (p * PART_DIGIT_BITS)) ++p;
+  return p;
+}
+inline size_t partition_workspace_bytes(int64_t N, int64_t L) {
+  const size_t nb = 256;
+  const size_t bins = L <= PART_MAXL ? (size_t)L : (size_t)PART_MAXL;
+  size_t need = align_up(nb * bins * sizeof(int), 256) + align_up(nb * bins * sizeof(int64_t), 256) +
+                align_up(bins * 8, 256) + 256;
+  if (L > PART_MAXL) need += 2 * align_up((size_t)N * 8, 256) + align_up((bins + 1) * 8, 256);   // ping-pong sequences
+  return need;
+}
+
+inline int partition_impl(const int64_t *labels, int64_t N, int64_t L, int64_t *idx_out, int64_t *offsets,
                           int64_t *first, int32_t *err, void *ws, size_t ws_bytes, hipStream_t st) {
-  if (L < 1 || L > PART_MAXL) return fail(CVM_EINVAL, "cvm_partition_labels: 1 <= n_labels <= 4096%s");
+  if (L < 1) return fail(CVM_EINVAL, "cvm_partition_labels: n_labels >= 1%s");
   if (ws_bytes < partition_workspace_bytes(N, L)) return fail(CVM_EWORKSPACE, "cvm_partition_labels: workspace too small%s");
   PartArgs a;
+  memset(&a, 0, sizeof(a));
   int64_t nb = (N + 1023) / 1024;
   if (nb > 256) nb = 256;
   if (nb < 1) nb = 1;
-  a.labels = labels; a.N = N; a.L = L; a.nb = (int)nb;
+  const int bins = L <= PART_MAXL ? (int)L : PART_MAXL;
+  a.labels = labels; a.N = N; a.Lfull = L; a.nb = (int)nb;
   a.chunk = ((N + nb - 1) / nb + PART_THREADS - 1) / PART_THREADS * PART_THREADS;
   char *p = (char *)ws;
-  a.blockhist = (int *)p; p += align_up((size_t)256 * L * sizeof(int), 256);
-  a.blockoff = (int64_t *)p; p += align_up((size_t)256 * L * sizeof(int64_t), 256);
-  a.first = (unsigned long long *)first;
-  a.offsets = offsets; a.idx_out = idx_out; a.err = (int *)err;
-  hipLaunchKernelGGL(part_init_kernel, dim3((L + 255) / 256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(part_hist_kernel, dim3((unsigned)nb), dim3(PART_THREADS), (size_t)L * sizeof(int), st, a);
-  hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(PART_THREADS), 0, st, a);
-  hipLaunchKernelGGL(part_scatter_kernel, dim3((unsigned)nb), dim3(PART_THREADS), (size_t)L * sizeof(long long), st, a);
+  a.blockhist = (int *)p; p += align_up((size_t)256 * bins * sizeof(int), 256);
+  a.blockoff = (int64_t *)p; p += align_up((size_t)256 * bins * sizeof(int64_t), 256);
+  a.err = (int *)err;
+  if (L <= PART_MAXL) {
+    a.L = (int)L; a.seq_in = nullptr; a.shift = 0; a.digit_mask = 0;
+    a.first = (unsigned long long *)first;
+    a.offsets = offsets; a.idx_out = idx_out;
+    hipLaunchKernelGGL(part_init_kernel, dim3((a.L + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(part_hist_kernel, dim3((unsigned)nb), dim3(PART_THREADS), (size_t)a.L * sizeof(int), st, a);
+    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(PART_THREADS), 0, st, a);
+    hipLaunchKernelGGL(part_scatter_kernel, dim3((unsigned)nb), dim3(PART_THREADS), (size_t)a.L * sizeof(long long), st, a);
+    HIP_OK(hipGetLastError());
+    return CVM_OK;
+  }
+  // many labels: LSD radix passes over 12-bit digits; scratch: two row sequences, per-pass bin offsets
+  unsigned long long *scratch_first = (unsigned long long *)p; p += align_up((size_t)bins * 8, 256);
+  int64_t *seq[2];
+  seq[0] = (int64_t *)p; p += align_up((size_t)N * 8, 256);
+  seq[1] = (int64_t *)p; p += align_up((size_t)N * 8, 256);
+  int64_t *pass_offsets = (int64_t *)p;
+  const int passes = part_passes(L);
+  a.L = bins; a.digit_mask = PART_MAXL - 1;
+  a.first = scratch_first; a.offsets = pass_offsets;
+  if (N == 0) {
+    hipLaunchKernelGGL(part_empty_kernel, dim3((unsigned)((L + 256) / 256)), dim3(256), 0, st, L, offsets, first);
+    HIP_OK(hipMemsetAsync(err, 0, sizeof(int32_t), st));
+    HIP_OK(hipGetLastError());
+    return CVM_OK;
+  }
+  const int64_t *in = nullptr;
+  for (int d = 0; d < passes; ++d) {
+    a.seq_in = in; a.shift = d * PART_DIGIT_BITS;
+    a.idx_out = (d == passes - 1) ? idx_out : seq[d & 1];
+    if (d == 0) hipLaunchKernelGGL(part_init_kernel, dim3((a.L + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(part_hist_kernel, dim3((unsigned)nb), dim3(PART_THREADS), (size_t)a.L * sizeof(int), st, a);
+    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(PART_THREADS), 0, st, a);
+    hipLaunchKernelGGL(part_scatter_kernel, dim3((unsigned)nb), dim3(PART_THREADS), (size_t)a.L * sizeof(long long), st, a);
+    in = a.idx_out;
+  }
+  hipLaunchKernelGGL(part_offsets_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, labels, idx_out, N, L,
+                     offsets, first);
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }

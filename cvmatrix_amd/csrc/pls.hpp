@@ -97,10 +97,12 @@ __device__ __forceinline__ bool fold_barrier(unsigned *cnt, unsigned &target, in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release on arrival, acquire on the wait: the slices' exchanged numbers (device-coherent
+    // relaxed accesses, already acknowledged: vmcnt(0) above) are ordered before / after the count
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     long spins = 0;
     int ok = 1;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1L << 21)) { ok = 0; break; }      // seconds: the slices were not co-resident
     }
@@ -577,6 +579,21 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
   if (s == 0 && tid == 0) a.n_fit[f] = fit;
 }
 
+// After the launches of a call: if any barrier timed out (status != 0: the slices of a fold were
+// not co-resident), nothing of the call can be trusted -- every coefficient becomes NaN and every
+// n_fit -1, so that a caller who does not read the status word cannot consume half-written models.
+template <typename T>
+__global__ void pls_poison_kernel(const int *status, T *B, size_t nB, T *W, T *P, T *R, size_t nW, T *Q, size_t nQ,
+                                  int *n_fit, int64_t F) {
+  if (*status == 0) return;
+  const T nan = (T)__builtin_nan("");
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = i0; i < nB; i += step) B[i] = nan;
+  for (size_t i = i0; i < nW; i += step) { if (W) W[i] = nan; if (P) P[i] = nan; if (R) R[i] = nan; }
+  if (Q) for (size_t i = i0; i < nQ; i += step) Q[i] = nan;
+  for (size_t i = i0; i < (size_t)F; i += step) n_fit[i] = -1;
+}
+
 // ---- host ---------------------------------------------------------------------------------
 struct PlsPlan {
   int S, rows, folds_per_launch, y_in_lds, pr_in_lds, xres;
@@ -676,6 +693,16 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
   void (*kern)(const PlsArgs) = p.S > 1 ? (p.xres ? pls_kernel<T, true, true> : pls_kernel<T, false, true>)
                                         : (p.xres ? pls_kernel<T, true, false> : pls_kernel<T, false, false>);
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+  if (p.S > 1) {
+    // the slices of a fold wait for each other: a launch must fit on the device at once (the plan
+    // sizes it for one workgroup per CU; make sure the runtime agrees before relying on it)
+    int per_cu = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), PLS_THREADS, p.lds));
+    const int64_t resident = (int64_t)per_cu * cus;
+    const int64_t biggest = (F < p.folds_per_launch ? F : p.folds_per_launch) * p.S;
+    if (per_cu < 1 || biggest > resident)
+      return fail(CVM_ELAUNCH, "cvm_pls_fit: a sliced launch would not be co-resident on this device%s");
+  }
   for (int64_t f0 = 0; f0 < F; f0 += p.folds_per_launch) {
     const int64_t nf = F - f0 < p.folds_per_launch ? F - f0 : p.folds_per_launch;
     PlsArgs b = a;
@@ -694,6 +721,12 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
     b.Q = Q ? (T *)Q + (size_t)f0 * M * A : nullptr;
     b.n_fit = n_fit + f0;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nf * p.S)), dim3(PLS_THREADS), p.lds, st, b);
+    HIP_OK(hipGetLastError());
+  }
+  if (p.S > 1) {
+    hipLaunchKernelGGL((pls_poison_kernel<T>), dim3(256), dim3(256), 0, st, (const int *)status, (T *)B,
+                       (size_t)F * A * K * M, (T *)W, (T *)P, (T *)R, (size_t)F * K * A, (T *)Q, (size_t)F * M * A,
+                       (int *)n_fit, F);
     HIP_OK(hipGetLastError());
   }
   return CVM_OK;

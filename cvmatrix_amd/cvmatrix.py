@@ -648,10 +648,13 @@ class CVMatrix:
 
     def prepare_folds_from_labels(self, labels, n_labels: Optional[int] = None) -> FoldBatch:
         """Device-side ``Partitioner``: one integer fold label per row (NumPy array or tensor,
-        values in ``[0, n_labels)``, at most 4096 labels) -> a ``FoldBatch`` built by
-        ``cvm_partition_labels`` without the host ever grouping the rows.  Folds are ordered by
-        first appearance of their label, like the reference's ``folds_dict``
-        (partitioner.py:101-107); ``batch.labels`` lists the labels in that order."""
+        values in ``[0, n_labels)``) -> a ``FoldBatch`` built by ``cvm_partition_labels`` without
+        the host ever grouping the rows (any number of labels: up to 4096 one stable counting
+        sort, more -- leave-one-out has one per row -- the same sort over 12-bit digits; labels
+        that are ``arange(N) % P``, the reference benchmark's folds, or ``arange(N)`` are laid out
+        by formula without a sort).  Folds are ordered by first appearance of their label, like
+        the reference's ``folds_dict`` (partitioner.py:101-107); ``batch.labels`` lists the labels
+        in that order."""
         if self.X is None:
             raise RuntimeError("call fit() first")
         lib = _lib.load()
@@ -665,6 +668,27 @@ class CVMatrix:
             if lab.numel() != self.N:
                 raise ValueError("one fold label per row is needed")
             L = int(n_labels) if n_labels is not None else int(lab.max().item()) + 1
+            if 1 <= L <= self.N:
+                # the strided folds of the reference's benchmark (benchmarks/benchmark.py:232) and
+                # leave-one-out: row r is the (r // L)-th row of fold r % L -- no sort needed
+                r = torch.arange(self.N, dtype=torch.int64, device=dev)
+                f_of = r % L
+                if torch.equal(lab, f_of):
+                    sizes = (self.N - np.arange(L) + L - 1) // L
+                    host_offsets = np.zeros(L + 1, dtype=np.int64)
+                    np.cumsum(sizes, out=host_offsets[1:])
+                    d_off = torch.from_numpy(host_offsets).to(dev)
+                    d_idx = torch.empty(self.N, dtype=torch.int64, device=dev)
+                    d_idx[d_off[f_of] + torch.div(r, L, rounding_mode="floor")] = r
+                    if self.weights is not None:
+                        nzmask = (self.weights.reshape(-1) != 0).to(torch.int64)
+                        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                          torch.cumsum(nzmask[d_idx], 0)])
+                        nz_val = (csum[d_off[1:]] - csum[d_off[:-1]]).cpu().numpy()
+                    else:
+                        nz_val = sizes.astype(np.int64)
+                    return FoldBatch(d_idx, d_off, host_offsets, nz_val, list(range(L)), None, self.N,
+                                     w_gen=self._w_gen)
             idx = torch.empty(self.N, dtype=torch.int64, device=dev)
             offs = torch.empty(L + 1, dtype=torch.int64, device=dev)
             first = torch.empty(L, dtype=torch.int64, device=dev)
@@ -758,11 +782,12 @@ class CVMatrix:
             mats = not stats_only
             out_XTX = torch.empty((P, K, K), dtype=dt, device=dev) if (rXTX and mats) else None
             out_XTY = torch.empty((P, K, M), dtype=dt, device=dev) if (rXTY and mats) else None
-            muX = torch.empty((P, 1, K), dtype=dt, device=dev)
-            sdX = torch.empty((P, 1, K), dtype=dt, device=dev)
-            muY = torch.empty((P, 1, M), dtype=dt, device=dev) if M else None
-            sdY = torch.empty((P, 1, M), dtype=dt, device=dev) if M else None
-            out_fold = torch.empty((P, 4), dtype=torch.float64, device=dev)
+            # the four statistics: one allocation [muX | sdX | muY | sdY], each block [P, 1, *]
+            stat = torch.empty(P * (2 * K + 2 * M), dtype=dt, device=dev)
+            muX, sdX = stat[:P * K].view(P, 1, K), stat[P * K:2 * P * K].view(P, 1, K)
+            muY = stat[2 * P * K:2 * P * K + P * M].view(P, 1, M) if M else None
+            sdY = stat[2 * P * K + P * M:].view(P, 1, M) if M else None
+            out_fold = None       # (per-fold [sw_T, nz_T, sw_V, nz_V]: diagnostics, not requested)
             sweep = getattr(self, "_sweep", None)
             if sweep is not None and sweep[0] is batch:
                 # the partials of exactly these folds are still in the sweep workspace
@@ -772,7 +797,7 @@ class CVMatrix:
                     float(self.resolution), 1 if self.weights is not None else 0,
                     self._G.data_ptr(), _lib.ptr(self._H), self._gs.data_ptr(),
                     _lib.ptr(out_XTX), _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(),
-                    _lib.ptr(muY), _lib.ptr(sdY), out_fold.data_ptr(),
+                    _lib.ptr(muY), _lib.ptr(sdY), _lib.ptr(out_fold),
                     self._sweep_ws.data_ptr(), self._sweep_ws.numel(), sweep[1], self._stream(),
                 )
                 _lib.check(rc, "cvm_sweep_fold_range")
@@ -794,7 +819,7 @@ class CVMatrix:
                 float(self.ddof), float(self.resolution), self._G.data_ptr(),
                 _lib.ptr(self._H), self._gs.data_ptr(), _lib.ptr(out_XTX),
                 _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(), _lib.ptr(muY),
-                _lib.ptr(sdY), out_fold.data_ptr(), ws.data_ptr(), ws.numel(), self._stream(),
+                _lib.ptr(sdY), _lib.ptr(out_fold), ws.data_ptr(), ws.numel(), self._stream(),
             )
             _lib.check(rc, "cvm_fold_update")
         return out_XTX, out_XTY, (muX, sdX, muY, sdY), out_fold

@@ -47,7 +47,9 @@ def pls_fit_batched(XTX: torch.Tensor, XTY: torch.Tensor, A: int, *, return_fact
     """Fit A-component PLS models on ``XTX`` (F,K,K) / ``XTY`` (F,K,M) device tensors (the
     outputs of ``training_XTX_XTY_batched``; a single (K,K)/(K,M) pair is taken as F = 1).
 
-    ``check=True`` synchronises once to turn the kernel's status word into an exception."""
+    ``check=True`` synchronises once to turn the kernel's status word into an exception;
+    with ``check=False`` a timed-out barrier (slices of a fold not co-resident) still cannot go
+    unnoticed: the library then overwrites every coefficient with NaN and every ``n_fit`` with -1."""
     if not (isinstance(XTX, torch.Tensor) and XTX.is_cuda and isinstance(XTY, torch.Tensor) and XTY.is_cuda):
         raise TypeError("pls_fit_batched takes device tensors (the batched training matrices).")
     if XTX.dim() == 2:

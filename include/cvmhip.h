@@ -152,15 +152,17 @@ int cvm_sweep_fold_range(const int64_t *offsets, int64_t n_total, int64_t fold0,
                          int64_t splits, void *stream);
 
 /* Device-side Partitioner (replaces cvmatrix/partitioner.py:89-107 for integer labels):
- *   labels      int64[N], one fold label per row, each in [0, n_labels), n_labels <= 4096
+ *   labels      int64[N], one fold label per row, each in [0, n_labels) (up to 4096 labels: one
+ *               stable counting sort; more, e.g. leave-one-out with a label per row: the same
+ *               sort over 12-bit digits of the label, least significant first)
  *   idx_out     int64[N]           row numbers grouped by label, ascending inside a group
  *   offsets_out int64[n_labels+1]  label l owns idx_out[offsets_out[l] .. offsets_out[l+1])
  *   first_out   int64[n_labels]    first row of each label (N if the label does not occur): the
  *                                  reference orders its folds by first appearance
  *   err_flag    int32[1]           set to 1 if some label is outside [0, n_labels), else 0
  * The output is exactly the idx / offsets pair cvm_fold_update takes. */
-size_t cvm_partition_workspace_bytes(int64_t N, int n_labels);
-int cvm_partition_labels(const int64_t *labels, int64_t N, int n_labels, int64_t *idx_out,
+size_t cvm_partition_workspace_bytes(int64_t N, int64_t n_labels);
+int cvm_partition_labels(const int64_t *labels, int64_t N, int64_t n_labels, int64_t *idx_out,
                          int64_t *offsets_out, int64_t *first_out, int32_t *err_flag, void *ws,
                          size_t ws_bytes, void *stream);
 

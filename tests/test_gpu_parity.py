@@ -920,7 +920,27 @@ def test_c_abi_from_plain_c(amd, tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("N,L", [(50000, 37), (4096, 4096), (1000, 1), (70001, 300)])
+@pytest.mark.parametrize("N,P", [(100000, 10), (100003, 64), (5000, 5000), (777, 1)])
+def test_device_partitioner_strided_and_leave_one_out_by_formula(amd, N, P):
+    """Labels arange(N) % P (the reference benchmark's folds, benchmarks/benchmark.py:232) and
+    arange(N) (leave-one-out): laid out by formula, equal to the host Partitioner."""
+    import torch
+
+    rng = np.random.default_rng(N)
+    X, w = rng.random((N, 8)), rng.random(N)
+    w[::7] = 0
+    m = amd.CVMatrix()
+    m.fit(X, None, w)
+    labels = np.arange(N) % P
+    hb = m.prepare_folds(amd.Partitioner(labels))
+    db = m.prepare_folds_from_labels(torch.from_numpy(labels).to(m.device))
+    assert db.labels == list(range(P)) and np.array_equal(db.host_offsets, hb.host_offsets)
+    assert bool((db.idx == hb.idx).all()) and bool((db.offsets == hb.offsets).all())
+    assert np.array_equal(db.nz_val, hb.nz_val)
+
+
+@pytest.mark.parametrize("N,L", [(50000, 37), (4096, 4096), (1000, 1), (70001, 300), (60000, 4097),
+                                 (100000, 100000), (30000, 20000000)])
 def test_device_partitioner_matches_host_partitioner(amd, N, L):
     """cvm_partition_labels (CVMatrix.prepare_folds_from_labels): the same folds, in the same
     first-seen order with ascending indices, as the host Partitioner builds from the labels
@@ -928,7 +948,7 @@ def test_device_partitioner_matches_host_partitioner(amd, N, L):
     import torch
 
     rng = np.random.default_rng(N + L)
-    labels = rng.integers(0, L, size=N) if L < N else rng.permutation(N)
+    labels = rng.permutation(N) if L == N else rng.integers(0, L, size=N)
     K, M = 24, 2
     X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
     w[rng.choice(N, N // 10, replace=False)] = 0
