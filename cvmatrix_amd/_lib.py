@@ -12,7 +12,9 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime that libcvmhip.so binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvmhip.so")
+# CVM_LIB_PATH: load another build of the library (experimental builds under tools/; implies
+# CVM_SKIP_HASH_CHECK)
+LIB_PATH = os.environ.get("CVM_LIB_PATH") or os.path.join(_HERE, "libcvmhip.so")
 
 CVM_OK, CVM_EINVAL, CVM_EWORKSPACE, CVM_ELAUNCH = 0, 1, 2, 3
 CVM_F32, CVM_F64 = 0, 1
@@ -47,7 +49,8 @@ def load():
     # compiler is there, refused otherwise (CVM_SKIP_HASH_CHECK=1: use it as it is)
     from . import build as _build
 
-    if os.environ.get("CVM_SKIP_HASH_CHECK", "0") == "0" and os.path.isdir(os.path.join(_HERE, "csrc")):
+    if (os.environ.get("CVM_SKIP_HASH_CHECK", "0") == "0" and not os.environ.get("CVM_LIB_PATH")
+            and os.path.isdir(os.path.join(_HERE, "csrc"))):
         want, have = _build.source_hash(), _build._embedded_hash_without_loading(LIB_PATH)
         if have != want:
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

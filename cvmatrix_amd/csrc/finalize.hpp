@@ -6,6 +6,21 @@
 // ----------------------------------------------------------------------------------
 // finalize kernels
 // ----------------------------------------------------------------------------------
+// Output matrices are written once and never read again by the library: their 16-byte stores are
+// nontemporal (-DCVM_NT_STORES=0 builds the plain-store variant).  Measured (tools/bench_small.py,
+// same box): leave-one-out K=500 1.71 -> 2.06 M folds/s, K=512 n=8 1.25 -> 1.53 M, K=4096 float32
+// n=16 4.55 -> 5.16 TB/s algorithmic, 3000 folds of 33 rows through the fused epilogue +8 %.
+#ifndef CVM_NT_STORES
+#define CVM_NT_STORES 1
+#endif
+template <typename V> __device__ __forceinline__ void out_store(V *p, V v) {
+#if CVM_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 struct FinArgs {
   Geom g;
   int splits;           // slot stride of the partial workspace: unit (seg, sp) = seg * splits + sp
@@ -33,6 +48,17 @@ __device__ __forceinline__ long sum_unit(int q, int nsp, int stride) {
   const int sg = q / nsp;
   return (long)sg * stride + (q - sg * nsp);
 }
+// the same slots visited in order, one step at a time (no division in the summing loops)
+struct UnitCursor {
+  int sp, nsp;
+  long base, stride;     // current slot = base + sp
+  __device__ __forceinline__ UnitCursor(int nsp_, int stride_) : sp(0), nsp(nsp_), base(0), stride(stride_) {}
+  __device__ __forceinline__ long next() {
+    const long u = base + sp;
+    if (++sp == nsp) { sp = 0; base += stride; }
+    return u;
+  }
+};
 
 // column chunks (grid.y) of fold_stats_kernel: enough workgroups to fill the chip when there are
 // few folds and many columns, one when there are many folds
@@ -59,14 +85,15 @@ __device__ __forceinline__ void fit_stats_columns(const FinArgs &a, double *gsta
     double s = 0;
     int p = 0;
     const int np = a.n_sum * a.s_diag;     // (the column sums come from the diagonal items)
+    UnitCursor cur(a.s_diag, a.splits);
     for (; p + 16 <= np; p += 16) {
       double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = unit_stats<T>((char *)a.ws, g, sum_unit(p + u, a.s_diag, a.splits))[src];
+      for (int u = 0; u < 16; ++u) v[u] = unit_stats<T>((char *)a.ws, g, cur.next())[src];
 #pragma unroll
       for (int u = 0; u < 16; ++u) s += v[u];
     }
-    for (; p < np; ++p) s += unit_stats<T>((char *)a.ws, g, sum_unit(p, a.s_diag, a.splits))[src];
+    for (; p < np; ++p) s += unit_stats<T>((char *)a.ws, g, cur.next())[src];
     if (c < total - 1) gstats[c] = s;
     else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
   }
@@ -154,9 +181,11 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
 constexpr int ST = 64;                 // tile edge of the finishing code
 // `gpre`: the tile's 16-byte pieces of G already in registers, piece j = q-th with q = tid +
 // j * nthreads (finish_tile_preload below) -- used where `full`; nullptr: load them here.
+// `st`: the fold's statistics of this tile in LDS (stage_tile_stats below): [0,64) means of the
+// tile's rows, [64,128) their stds, [128,192) means of its columns, [192,256) their stds.
 template <typename T, bool FOLD, typename TS = double>
 __device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, int a0, int b0, int K,
-                                                  const T *Gt, T *out, const double *fs, double swt,
+                                                  const T *Gt, T *out, const double *st, double swt,
                                                   bool cX, bool sX, int tid, int nthreads,
                                                   const T (*gpre)[16 / sizeof(T)] = nullptr) {
   constexpr int VW = 16 / sizeof(T);            // elements per 16-byte access
@@ -188,7 +217,7 @@ __device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, i
             for (int e = 0; e < VW; ++e) gvv[e] = (gc + e < K) ? Gt[(size_t)gr * K + gc + e] : (T)0;
           }
         }
-        const double mur = (FOLD && cX) ? fs[gr] : 0.0, sdr = (FOLD && sX) ? fs[K + gr] : 1.0;
+        const double mur = (FOLD && cX) ? st[lr] : 0.0, sdr = (FOLD && sX) ? st[ST + lr] : 1.0;
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
           const int cc = lc + e, gce = gc + e;
@@ -197,8 +226,8 @@ __device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, i
             const double upd = (diag && lr > cc) ? Ts[cc][lr] : Ts[lr][cc];
             if (FOLD) {
               v = (double)gvv[e] - upd;
-              if (cX) v -= swt * (mur * fs[gce]);
-              if (sX) v = v / (sdr * fs[K + gce]);
+              if (cX) v -= swt * (mur * st[2 * ST + cc]);
+              if (sX) v = v / (sdr * st[3 * ST + cc]);
             } else {
               v = upd;
             }
@@ -214,7 +243,7 @@ __device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, i
         vst_t vv;
 #pragma unroll
         for (int e = 0; e < VW; ++e) vv[e] = vals[e];
-        *reinterpret_cast<vst_t *>(dst) = vv;
+        out_store(reinterpret_cast<vst_t *>(dst), vv);
       } else {
 #pragma unroll
         for (int e = 0; e < VW; ++e) if (gc + e < K) dst[e] = vals[e];
@@ -227,6 +256,17 @@ __device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, i
       }
     }
     __syncthreads();
+  }
+}
+
+// The statistics a tile's finish needs, from the fold's vector `fs` ([muX(K) sdX(K) ...]) into LDS:
+// one global load per thread instead of two per finished element.  (Callers put a barrier between
+// this and finish_store_tile.)
+__device__ __forceinline__ void stage_tile_stats(double *st, const double *fs, int a0, int b0, int K, int tid) {
+  if (tid < 4 * ST) {
+    const int part = tid / ST, l = tid - part * ST;
+    const int col = ((part < 2) ? a0 : b0) + l;
+    st[tid] = (col < K) ? fs[((part & 1) ? K : 0) + col] : ((part & 1) ? 1.0 : 0.0);
   }
 }
 
@@ -286,7 +326,7 @@ __device__ __forceinline__ void fused_finish_direct(double (*Ts)[TP], const doub
       double v0 = gv[j][0] - u0, v1 = gv[j][1] - u1;
       if (cX) { v0 -= swt * (mur * muc0); v1 -= swt * (mur * muc1); }
       if (sX) { v0 = v0 / (sdr * sdc0); v1 = v1 / (sdr * sdc1); }
-      *reinterpret_cast<v2 *>(out + (size_t)gr * K + gc) = (v2){v0, v1};
+      out_store(reinterpret_cast<v2 *>(out + (size_t)gr * K + gc), (v2){v0, v1});
       if (!diagb) { Ts[lr][lc] = v0; Ts[lr][lc + 1] = v1; }   // parked for the mirrored store
     }
   }
@@ -303,7 +343,7 @@ __device__ __forceinline__ void fused_finish_mirror(double (*Ts)[TP], int a0, in
   for (int it = it_lo; it < it_hi; ++it) {
     const int lr = 2 * it + half, gr = b0 + lr;
     if (gr >= K) continue;
-    *reinterpret_cast<v2 *>(out + (size_t)gr * K + gc2) = (v2){Ts[lc][lr], Ts[lc + 1][lr]};
+    out_store(reinterpret_cast<v2 *>(out + (size_t)gr * K + gc2), (v2){Ts[lc][lr], Ts[lc + 1][lr]});
   }
 }
 template <int TP>
@@ -362,11 +402,13 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     const int a0 = ti * TILE + si * ST, b0 = tj * TILE + sj * ST;
     if (a0 >= K || b0 >= K) return;
     __shared__ __attribute__((aligned(16))) double sm[ST * (ST + 1)];
+    __shared__ double st_lds[4 * ST];
     double (*Ts)[ST + 1] = reinterpret_cast<double (*)[ST + 1]>(sm);
     constexpr int VW = 16 / sizeof(T);
     constexpr int LPR = ST / VW;
     typedef T vld_t __attribute__((ext_vector_type(VW)));
     const int tid = threadIdx.x;
+    if (FOLD) stage_tile_stats(st_lds, fs, a0, b0, K, tid);   // (visible after the barrier below)
     // every thread owns NQ 16-byte pieces of the sub-tile; the splits are summed in order, the
     // pieces of one split loaded together (NQ independent loads in flight: a fit with 25 splits
     // is otherwise one long chain of dependent latencies on 44 workgroups)
@@ -425,7 +467,7 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     }
     __syncthreads();
     T *out = (T *)a.out_XTX + (FOLD ? fo * (size_t)K * K : 0);
-    finish_store_tile<T, FOLD>(Ts, ti == tj && si == sj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX,
+    finish_store_tile<T, FOLD>(Ts, ti == tj && si == sj, a0, b0, K, (const T *)a.G, out, st_lds, swt, cX, sX,
                                tid, NTHR);
   } else {
     if (!a.out_XTY || M == 0) return;
@@ -461,8 +503,10 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
 // Rows are stored as they are summed; the mirrored block goes through a [rows][65] LDS transpose.
 // On a diagonal sub-tile only the upper triangle is stored, twice (as is and mirrored), so the
 // result is exactly symmetric.  Needs 16-byte aligned rows (K * sizeof(T) % 16 == 0).
-constexpr int FIT_RC = 4;
-constexpr int FIT_RH = ST / FIT_RC;
+// (8-row chunks for float64, 16-row chunks for float32: one 16-byte piece per thread, sixteen
+//  partials requested before the first is added -- the sweep sums 40-70 partials per element and a
+//  workgroup is bound by the round trips, not by the bytes)
+template <typename T> constexpr int fit_rc() { return sizeof(T) == 8 ? 8 : 4; }
 constexpr int FIT_THREADS = 256;
 constexpr int FIT_PCH = 4;             // row chunks of a 128-row XTY panel
 constexpr int FIT_STAT_WGS = 8;        // workgroups that sum the column statistics (a.gstats: output)
@@ -471,6 +515,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
   const Geom &g = a.g;
   const int K = g.K, M = g.M;
   const int x = blockIdx.x, tid = threadIdx.x;
+  constexpr int FIT_RC = fit_rc<T>(), FIT_RH = ST / FIT_RC;
   const int n_sub = g.nTiles * APPLY_SUB * FIT_RC;
   constexpr int VW = 16 / sizeof(T);
   typedef T vld_t __attribute__((ext_vector_type(VW)));
@@ -488,7 +533,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
     const bool diag = (ti == tj && si == sj);
     __shared__ double Ts[FIT_RH][ST + 1];
     constexpr int LPR = ST / VW;
-    constexpr int NQ = FIT_RH * LPR / FIT_THREADS;   // 2 (float64) or 1 (float32) pieces per thread
+    constexpr int NQ = FIT_RH * LPR / FIT_THREADS;   // one 16-byte piece per thread
     static_assert(NQ >= 1, "chunk smaller than the workgroup");
     double v[NQ][VW];
     const char *pp[NQ];
@@ -501,15 +546,16 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
 #pragma unroll
       for (int e = 0; e < VW; ++e) v[j][e] = 0;
     }
-    constexpr int UP = 8;                            // splits requested before the first is added
+    constexpr int UP = 16;                           // splits requested before the first is added
     const int nsp = (ti == tj) ? a.s_diag : a.s_off;
     const int np = a.n_sum * nsp;                    // segment-major, split order within a segment
+    UnitCursor cur(nsp, a.splits);
     int p = 0;
     for (; p + UP <= np; p += UP) {
       vld_t qv[UP][NQ];
 #pragma unroll
       for (int u = 0; u < UP; ++u) {
-        const size_t so = (size_t)sum_unit(p + u, nsp, a.splits) * g.unit_bytes;
+        const size_t so = (size_t)cur.next() * g.unit_bytes;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + so);
       }
@@ -521,7 +567,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
           for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[u][j][e];
     }
     for (; p < np; ++p) {
-      const size_t so = (size_t)sum_unit(p, nsp, a.splits) * g.unit_bytes;
+      const size_t so = (size_t)cur.next() * g.unit_bytes;
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
         const vld_t qv = *reinterpret_cast<const vld_t *>(pp[j] + so);
@@ -589,15 +635,15 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
       const char *pp = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
       int p = 0;
       const int np = a.n_sum * a.s_diag;
-      for (; p + 8 <= np; p += 8) {
-        T t8[8];
+      UnitCursor cur(a.s_diag, a.splits);
+      for (; p + 16 <= np; p += 16) {
+        T t16[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          t8[u] = *reinterpret_cast<const T *>(pp + (size_t)sum_unit(p + u, a.s_diag, a.splits) * g.unit_bytes);
+        for (int u = 0; u < 16; ++u) t16[u] = *reinterpret_cast<const T *>(pp + (size_t)cur.next() * g.unit_bytes);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += (double)t8[u];
+        for (int u = 0; u < 16; ++u) s += (double)t16[u];
       }
-      for (; p < np; ++p) s += (double)*reinterpret_cast<const T *>(pp + (size_t)sum_unit(p, a.s_diag, a.splits) * g.unit_bytes);
+      for (; p < np; ++p) s += (double)*reinterpret_cast<const T *>(pp + (size_t)cur.next() * g.unit_bytes);
       out[(size_t)ga * M + m] = (T)s;
     }
   }

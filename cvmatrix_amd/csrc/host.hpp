@@ -332,7 +332,7 @@ template <typename T> void launch_fit_apply(FinArgs f, const Geom &g, double *gs
   const bool aligned = ((size_t)g.K * sizeof(T)) % 16 == 0 && ((uintptr_t)f.out_XTX % 16 == 0);
   if (aligned) {
     f.gstats = gstats;
-    hipLaunchKernelGGL((fit_apply_kernel<T>), dim3(g.nTiles * APPLY_SUB * FIT_RC + g.P * FIT_PCH + FIT_STAT_WGS),
+    hipLaunchKernelGGL((fit_apply_kernel<T>), dim3(g.nTiles * APPLY_SUB * fit_rc<T>() + g.P * FIT_PCH + FIT_STAT_WGS),
                        dim3(FIT_THREADS), 0, st, f);
   } else {
     hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);

@@ -135,6 +135,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm);
   __shared__ int64_t rows[SMALL_ROWS];
   __shared__ double wl[SMALL_ROWS];
+  __shared__ double st_lds[4 * ST];              // this fold's means / stds of the tile's rows and columns
   const bool xtx_part = x < a.nT64;
   if (xtx_part ? !a.out_XTX : (!a.out_XTY || M == 0)) return;
   // a workgroup takes its tile for `fpb` consecutive folds: the tile of G (the same for every
@@ -162,6 +163,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
       rows[tid] = r;
       wl[tid] = WEIGHTED ? (double)W[r] : 1.0;
     }
+    if (xtx_part) stage_tile_stats(st_lds, fs, a0, b0, K, tid);
     __syncthreads();
     if (xtx_part) {
       T *out = (T *)a.out_XTX + fo * (size_t)K * K;
@@ -194,7 +196,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
 #pragma unroll
         for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
       __syncthreads();
-      finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, fs, swt, cX, sX, tid, 256, gpre);
+      finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, st_lds, swt, cX, sX, tid, 256, gpre);
     } else {
       const T *Ht = (const T *)a.H;
       T *out = (T *)a.out_XTY + fo * (size_t)K * M;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
           if (sX) v = v / (sdr * cur.sdc[e]);
           vv[e] = (T)v;
         }
-        *reinterpret_cast<vec_t *>(out + (size_t)(a0 + i) * K + gc) = vv;
+        out_store(reinterpret_cast<vec_t *>(out + (size_t)(a0 + i) * K + gc), vv);
       }
     }
     // the panel's rows of XTY (first column chunk only)
