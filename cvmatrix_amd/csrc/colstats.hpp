@@ -74,16 +74,25 @@ __global__ __launch_bounds__(COL_THREADS) void colstats_kernel(const ColArgs a) 
     };
     int64_t r = r0;
     if (live) {
-      for (; r + COL_UNROLL <= r1; r += COL_UNROLL) {
-        int64_t rows[COL_UNROLL];
-        T wr[COL_UNROLL];
-        vec_t x[COL_UNROLL];
+      // the row numbers of the NEXT group are requested before this group's rows: the row loads
+      // then never wait for an index load (two dependent latencies per group otherwise)
+      int64_t rows[COL_UNROLL], nrows[COL_UNROLL];
+      if (r + COL_UNROLL <= r1) {
 #pragma unroll
         for (int j = 0; j < COL_UNROLL; ++j) rows[j] = idx[r + j];
+      }
+      for (; r + COL_UNROLL <= r1; r += COL_UNROLL) {
+        T wr[COL_UNROLL];
+        vec_t x[COL_UNROLL];
+        const bool more = r + 2 * COL_UNROLL <= r1;
+#pragma unroll
+        for (int j = 0; j < COL_UNROLL; ++j) nrows[j] = more ? idx[r + COL_UNROLL + j] : 0;
 #pragma unroll
         for (int j = 0; j < COL_UNROLL; ++j) { x[j] = load(rows[j]); wr[j] = WEIGHTED ? wp[rows[j]] : (T)1; }
 #pragma unroll
         for (int j = 0; j < COL_UNROLL; ++j) acc1(x[j], wr[j]);
+#pragma unroll
+        for (int j = 0; j < COL_UNROLL; ++j) rows[j] = nrows[j];
       }
       for (; r < r1; ++r) {
         const int64_t row = idx[r];
