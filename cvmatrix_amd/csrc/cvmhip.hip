@@ -24,6 +24,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <queue>
 #include <tuple>
 #include <type_traits>
 #include <vector>

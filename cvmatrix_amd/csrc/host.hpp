@@ -56,9 +56,12 @@ bool fast_shape(int K, int M, int esize) {
 // The launch is a list of work items (geometry.hpp: all off-diagonal-tile items, then the
 // diagonal-class items) that TARGET_WG persistent workgroups (one 8-wave workgroup per CU) take in
 // order, each as soon as it is free (wgram4_kernel's work queues).  An item costs its 16-row
-// stages times the per-stage cost of its kind plus a fixed prologue/epilogue (~3 stages: pipeline
-// fill, partial store, fetching the next item; fitted to measured launch times of eleven split
-// pairs at C3, as is the diagonal tiles' relative cost 0.66-0.69).  Per-stage costs, in units of an off-diagonal tile's stage (16 MFMAs per wave and
+// stages times the per-stage cost of its kind plus a fixed prologue/epilogue of about one stage.
+// The constants are fitted to measured launch times of 23 split pairs at the C3 shape (11 of the
+// 10-fold sweep, 12 of the fit stage; tools/exp_splits.sh, tools/exp_fit_splits.py): the simulation
+// below reproduces them to 1.9 % rms with 2.05 us per off-diagonal stage and a diagonal tile costing
+// 0.78 of it -- more than its 11/16 share of the MFMAs: it reads almost twice the LDS fragments per
+// MFMA, and those reads are what the loop pays for beyond the matrix instructions.  Per-stage costs, in units of an off-diagonal tile's stage (16 MFMAs per wave and
 // k-step): a diagonal tile in the LDS-DMA kernel issues 9 + 2*NBY (the upper triangle of its 8x8
 // grid of MFMA tiles shared out evenly + XTY), a further-Y-chunk item keeps one wave busy with 16;
 // in the general kernel every wave of every item runs the same loop.
@@ -77,8 +80,12 @@ struct SplitKey {
 };
 struct SplitChoice { int s_off, s_diag; };
 
+// `lists` = 8: the kernel's own hand-out (wgram4_kernel): 8 lists (one per XCD: its share of the
+// class-0 items, then of the class-1 items), target/8 workgroups per list, each takes the next
+// item of its list when it is free and helps the following lists once its own is empty.
+// `lists` = 1: one XCD's list and workgroups alone (an eighth of the work: the coarse pass).
 double simulate_launch(int64_t n_seg, int64_t max_rows, const Geom &g, int s_off, int s_diag, double c_diag,
-                       int target) {
+                       int target, int lists) {
   const int nOff = g.diag_only ? 0 : g.nTiles - g.P;
   const int nFirst = g.diag_only ? 0 : g.P;                 // diagonal tiles with the first Y chunk
   const int nY = g.diag_only ? g.P * g.Yc : g.P * (g.Yc - 1); // XTY-only items (one busy wave, 16 MFMAs)
@@ -86,37 +93,59 @@ double simulate_launch(int64_t n_seg, int64_t max_rows, const Geom &g, int s_off
     int64_t per = (max_rows + s - 1) / s;
     return (double)((per + STAGE_ROWS - 1) / STAGE_ROWS);
   };
-  const double fixed = 3.0;
+  const double fixed = 1.0;
   const double c_off = stages_of(s_off) + fixed;
   const double c_first = stages_of(s_diag) * c_diag + fixed, c_y = stages_of(s_diag) + fixed;
-  // in-order hand-out to `target` CUs: a min-heap of the CUs' free times
-  std::vector<double> heap((size_t)target, 0.0);
-  auto run = [&](int64_t count, double cost) {
-    for (int64_t i = 0; i < count; ++i) {
-      std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
-      heap.back() += cost;
-      std::push_heap(heap.begin(), heap.end(), std::greater<double>());
+  const int64_t n0 = n_seg * s_off * nOff, per1 = nFirst + nY, n1 = n_seg * s_diag * per1;
+  const int64_t ipx0 = (n0 + 7) / 8, ipx1 = (n1 + 7) / 8;
+  int64_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto next_cost = [&](int x, double &cost) -> bool {
+    if (pos[x] < ipx0 && (int64_t)x * ipx0 + pos[x] >= n0) pos[x] = ipx0;   // (a shorter last list)
+    const int64_t q = pos[x];
+    if (q < ipx0) {
+      cost = c_off;
+    } else {
+      const int64_t item = (int64_t)x * ipx1 + (q - ipx0);
+      if (q - ipx0 >= ipx1 || item >= n1) return false;
+      cost = (item % per1) < nFirst ? c_first : c_y;
     }
+    ++pos[x];
+    return true;
   };
-  const int64_t u_off = n_seg * s_off, u_diag = n_seg * s_diag;
-  // (the items of one unit are adjacent in the list; with equal costs per class the order within
-  //  a class does not matter to the estimate)
-  run(u_off * nOff, c_off);
-  // class 1: per unit nFirst items of c_first and nY of c_y, interleaved unit by unit
-  if (nY == 0) run(u_diag * nFirst, c_first);
-  else if (nFirst == 0) run(u_diag * nY, c_y);
-  else for (int64_t u = 0; u < u_diag; ++u) { run(nFirst, c_first); run(nY, c_y); }
-  double t = 0;
-  for (double v : heap) t = v > t ? v : t;
-  return t;
+  const int workers = lists == 8 ? target : (target + 7) / 8;
+  // a small binary heap of the workgroups' free times (workgroup number in the low bits)
+  std::vector<std::pair<double, int>> heap;
+  heap.reserve((size_t)workers);
+  for (int i = 0; i < workers; ++i) heap.emplace_back(0.0, i);
+  auto cmp = [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a > b; };
+  double t_end = 0;
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), cmp);
+    std::pair<double, int> e = heap.back();
+    const int home = lists == 8 ? (e.second & 7) : 0;
+    double cost = 0;
+    bool got = false;
+    for (int d = 0; d < lists && !got; ++d) got = next_cost((home + d) & 7, cost);
+    if (!got) { if (e.first > t_end) t_end = e.first; heap.pop_back(); continue; }
+    heap.back().first = e.first + cost;
+    std::push_heap(heap.begin(), heap.end(), cmp);
+  }
+  return t_end;
 }
 
 SplitChoice choose_splits2(int64_t n_seg, int64_t max_rows, const Geom &g, int esize, int target) {
   if (n_seg < 1) n_seg = 1;
+  // plan for a rounded-up row count (1/16 steps of the leading power of two): ragged folds asked
+  // for one call at a time would otherwise each pay for a plan of their own
+  {
+    int64_t step = 1;
+    while (step * 32 <= max_rows) step *= 2;
+    max_rows = (max_rows + step - 1) / step * step;
+  }
   int64_t cap = max_rows / 64;                       // >= 64 rows per split
   const int64_t mem_cap = (int64_t)(((size_t)3 << 30) / ((size_t)n_seg * g.unit_bytes));
   if (cap > mem_cap) cap = mem_cap;
-  if (cap > 64) cap = 64;
+  if (cap > 128) cap = 128;
   if (cap < 1) cap = 1;
   // CVM_FORCE_SPLITS="s_off,s_diag": experiments (tools/) pin the plan; clamped to the caps
   static const char *force = getenv("CVM_FORCE_SPLITS");
@@ -134,24 +163,34 @@ SplitChoice choose_splits2(int64_t n_seg, int64_t max_rows, const Geom &g, int e
     if (it != cache.end()) return it->second;
   }
   const bool fast = fast_shape(g.K, g.M, esize);
-  const double c_diag = fast ? (9.0 + 2.0 * (g.M > 16 ? 2 : 1)) / 16.0 : 1.0;
+  // (9 + 2 NBY MFMAs of 16 per k-step, times the measured 0.78 / 0.6875 for their LDS reads)
+  double c_diag = fast ? (9.0 + 2.0 * (g.M > 16 ? 2 : 1)) / 16.0 * (0.78 / 0.6875) : 1.0;
+  if (c_diag > 1.0) c_diag = 1.0;
   const int64_t items1 = n_seg * (int64_t)g.nT;
-  SplitChoice best{1, 1};
-  double best_score = 1e300;
+  const int nOff = g.diag_only ? 0 : g.nTiles - g.P;
+  // what extra splits cost after the launch: their partial tiles are read back by the finalize
+  // kernels (about 1.5 times on average: the sweep reads them twice) at ~3.5 TB/s; in stages of
+  // 2.05 us, shared by all CUs
+  const double tile_bytes = (double)TILE * TILE * esize;
+  auto partial_cost = [&](int so, int sd) {
+    const double bytes = (double)n_seg * ((double)so * nOff * tile_bytes +
+                                          (double)sd * ((double)g.P * tile_bytes + (double)g.h_elems * esize));
+    return 1.5 * bytes / 3.5e12 / 2.05e-6;
+  };
+  struct Cand { double score; int so, sd; };
+  std::vector<Cand> cands;
   auto consider = [&](int so, int sd) {
     if (so < 1 || sd < 1 || so > cap || sd > cap) return;
-    // fewest splits on near-ties: less partial traffic, and one split per fold lets the float64
-    // kernel finish folds in its epilogue
-    const double score = simulate_launch(n_seg, max_rows, g, so, sd, c_diag, target) + 0.5 * (so > sd ? so : sd);
-    if (score < best_score - 1e-9) { best_score = score; best = SplitChoice{so, sd}; }
+    const double t = simulate_launch(n_seg, max_rows, g, so, sd, c_diag, target, 1);
+    cands.push_back(Cand{t + partial_cost(so, sd), so, sd});
   };
   if (items1 >= 8 * (int64_t)target || g.diag_only || g.nTiles == g.P) {
     // many rounds of workgroups (or a single class): the tail is a small part of the launch
     for (int sx = 1; sx <= cap && sx <= 8; ++sx) consider(sx, sx);
   } else {
-    static const double ratios[] = {0.5, 0.6, 0.6875, 0.75, 0.875, 1.0, 1.25, 1.4, 1.5, 1.75, 2.0};
+    static const double ratios[] = {0.6, 0.7, 0.75, 0.875, 1.0, 1.25, 1.5, 1.75, 2.0};
     for (int so = 1; so <= cap; ++so) {
-      if ((int64_t)so * items1 > 16 * (int64_t)target && so > 1) break;   // far more rounds than needed
+      if ((int64_t)so * n_seg * nOff > 16 * (int64_t)target && so > 1) break;   // more rounds than pay
       int last = 0;
       for (double r : ratios) {
         int sd = (int)(so * r + 0.5);
@@ -161,6 +200,18 @@ SplitChoice choose_splits2(int64_t n_seg, int64_t max_rows, const Geom &g, int e
         consider(so, sd);
       }
     }
+  }
+  // the coarse pass looked at one XCD alone; the best few get the whole machine, with stealing
+  std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) {
+    return a.score != b.score ? a.score < b.score : (a.so + a.sd) < (b.so + b.sd);
+  });
+  SplitChoice best{1, 1};
+  double best_score = 1e300;
+  for (size_t i = 0; i < cands.size() && i < 6; ++i) {
+    const Cand &c = cands[i];
+    const double score = simulate_launch(n_seg, max_rows, g, c.so, c.sd, c_diag, target, 8) + partial_cost(c.so, c.sd);
+    // fewest splits on near-ties: one split per fold lets the float64 kernel finish folds in its epilogue
+    if (score < best_score * (1.0 - 1e-3)) { best_score = score; best = SplitChoice{c.so, c.sd}; }
   }
   std::lock_guard<std::mutex> lk(mu);
   if (cache.size() > 4096) cache.clear();
