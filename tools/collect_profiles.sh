@@ -39,6 +39,6 @@ cd $ROOT
 python3 bench.py > $O/plain.out 2>&1; grep "^{" $O/plain.out | tail -1 > $D/bench_bench_plain.json
 python3 tools/bench_foldsizes.py > $D/fold_size_sweep.txt 2>/dev/null
 python3 tools/power_probe.py C3 C3fit C3fold C3two C4 C4fit C5 2>/dev/null > $D/power_probe.txt
-for p in "500:250" "240:280,280:120" "240:280,240:135" "480:145,560:65"; do ./tools/dispatch_probe "$p" | head -1; python3 tools/dispatch_analyze.py <(./tools/dispatch_probe "$p") | sed -n 2,6p; done > $D/dispatch_probe.txt 2>&1
+for p in "500:250" "240:280,280:120" "240:280,240:135" "480:145,560:65"; do ./tools/dispatch_probe "$p" > /tmp/dp.txt; python3 tools/dispatch_analyze.py /tmp/dp.txt | sed -n 1,7p | cut -c1-400; echo; done > $D/dispatch_probe.txt 2>&1
 tail -3 $O/stats.log
 ls -la $D

@@ -8,6 +8,11 @@
 //   4  as 0 but 8 MFMAs + branch per iteration (the shape of tools/mfma_peak.hip)
 //   5  as 3, but the LDS reads and the multiplies spread between the MFMAs
 //      (sched_group_barrier pipeline) instead of issued in two clumps
+//   6  as 3, but the fragments come by ds_read_b128: a lane takes columns 2j, 2j+1 of a 32-column
+//      group, i.e. the operands of two MFMA tiles (even / odd columns) in one instruction:
+//      4 + 1 LDS instructions per k-step instead of 9 (the same bytes)
+//   7  the diagonal tile's wave 0: 11 MFMAs per k-step fed by 8 + 1 + 1 b64 reads
+//   8  as 7 with b128 reads (4 + 1 + 1)
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/mfma_mix.hip -o tools/mfma_mix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -36,7 +41,97 @@ template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in
   };
   read_frags(smem, 0, 0);
   read_frags(smem, 1, 1);
-  if (V == 4) {
+  if (V == 6) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int a2 = 64 * (wave >> 1) + 2 * lc, b2 = PANEL + 64 * (wave & 1) + 2 * lc;
+    d2 ap[2][2], bp[2][2];
+    auto read2 = [&](const double* buf, int ks, int slot) {
+      const int r = 4 * ks + lk;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) ap[slot][g] = *reinterpret_cast<const d2*>(&buf[a2 + r * PITCH + 32 * g]);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) bp[slot][g] = *reinterpret_cast<const d2*>(&buf[b2 + r * PITCH + 32 * g]);
+      wv[slot] = buf[2 * PANEL + r];
+    };
+    read2(smem, 0, 0);
+#pragma unroll 1
+    for (int s = 0; s < stages; ++s) {
+      const double* buf = smem + (s & 3) * BUF;
+      const double* nbuf = smem + ((s + 1) & 3) * BUF;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        if (ks < 3) read2(buf, ks + 1, c ^ 1); else read2(nbuf, 0, c ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[c][m >> 1][m & 1], bp[c][n >> 1][n & 1], acc[m * 4 + n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { ap[c ^ 1][g][0] *= wv[c ^ 1]; ap[c ^ 1][g][1] *= wv[c ^ 1]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 2; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[c][m >> 1][m & 1], bp[c][n >> 1][n & 1], acc[m * 4 + n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else if (V == 7 || V == 8) {
+    // diagonal tile, wave W = 0: B fragments of column tiles 0..7, rows 0 and 7, one Y fragment
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double bfd[2][8], yf[2], aw[2][2];
+    auto readd = [&](const double* buf, int ks, int slot) {
+      const int r = 4 * ks + lk;
+      if (V == 7) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bfd[slot][j] = buf[r * PITCH + 16 * j + lc];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const d2 t = *reinterpret_cast<const d2*>(&buf[r * PITCH + 32 * g + 2 * lc]);
+          bfd[slot][2 * g] = t[0]; bfd[slot][2 * g + 1] = t[1];
+        }
+      }
+      yf[slot] = buf[PANEL + r * 48 + lc];
+      wv[slot] = buf[2 * PANEL + r];
+    };
+    double st_s[2] = {0, 0}, st_q[2] = {0, 0};
+    auto prep = [&](int c) {
+      const double x0 = bfd[c][0], x1 = bfd[c][7];
+      const double p0 = x0 * wv[c], p1 = x1 * wv[c];
+      st_s[0] += p0; st_q[0] += p0 * x0; st_s[1] += p1; st_q[1] += p1 * x1;
+      aw[c][0] = p0; aw[c][1] = p1;
+    };
+    readd(smem, 0, 0);
+    prep(0);
+#pragma unroll 1
+    for (int s = 0; s < stages; ++s) {
+      const double* buf = smem + (s & 3) * BUF;
+      const double* nbuf = smem + ((s + 1) & 3) * BUF;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        if (ks < 3) readd(buf, ks + 1, c ^ 1); else readd(nbuf, 0, c ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[c][0], bfd[c][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        prep(c ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[8] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[c][1], bfd[c][7], acc[8], 0, 0, 0);
+        acc[9] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[c][0], yf[c], acc[9], 0, 0, 0);
+        acc[10] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[c][1], yf[c], acc[10], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+    acc[11][0] = st_s[0] + st_q[0] + st_s[1] + st_q[1];
+  } else if (V == 4) {
     for (int s = 0; s < stages * 8; ++s) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -183,7 +278,7 @@ template <int V> void run8(const double* din, double* dout, const char* what) {
   printf("%-58s %.3f ms  %.2f TFLOP/s  %.1f ns/stage\n", what, ms, mf * 2048.0 / ms / 1e9, ms * 1e6 / stages);
 }
 
-template <int V> void run(const double* din, double* dout, const char* what) {
+template <int V> void run(const double* din, double* dout, const char* what, double mfma_per_stage = 64.0) {
   const int stages = 4000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipFuncSetAttribute((const void*)kern<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BUF * 8);
@@ -194,7 +289,7 @@ template <int V> void run(const double* din, double* dout, const char* what) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
-  const double mf = 256.0 * 4 * stages * 64.0;
+  const double mf = 256.0 * 4 * stages * mfma_per_stage;
   printf("%-58s %.3f ms  %.2f TFLOP/s  %.1f ns/stage\n", what, ms, mf * 2048.0 / ms / 1e9, ms * 1e6 / stages);
 }
 
@@ -210,6 +305,9 @@ int main() {
   run<2>(din, dout, "+ 4 weighting multiplies per k-step");
   run<3>(din, dout, "+ one barrier per stage (4 waves)");
   run<5>(din, dout, "same, reads and multiplies spread between the MFMAs");
+  run<6>(din, dout, "as the barrier line, fragments by ds_read_b128");
+  run<7>(din, dout, "diagonal tile wave 0: 11 MFMAs, 10 b64 reads per k-step", 44.0);
+  run<8>(din, dout, "diagonal tile wave 0: 11 MFMAs, 6 reads (b128)", 44.0);
   run8<0>(din, dout, "8 waves x 64x32 (2 per SIMD): reads + weighting + barrier");
   run8<1>(din, dout, "8 waves x 64x32 (2 per SIMD): reads + weighting, no barrier");
   return 0;
