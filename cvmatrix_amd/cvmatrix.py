@@ -190,6 +190,9 @@ class CVMatrix:
         self._w_checked_src = None
         self._w_gen = 0          # bumped whenever the validated weights change
         self._np_cache = {}
+        self._small_ws_key = None
+        self._small_ws_bytes = 0
+        self._one_off = None
 
     # ------------------------------------------------------------------ full-data matrices
     # ``fit`` may leave them pending (``lazy_fit``): they are computed on first use -- by the
@@ -319,7 +322,11 @@ class CVMatrix:
         return self._ws
 
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """The caller's current HIP stream on this device, as the integer the C ABI takes."""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:                       # (private helper of torch; fall back to the API)
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     # ------------------------------------------------------------------ fit stage
     def fit(self, X, Y=None, weights=None, folds=None) -> None:
@@ -474,6 +481,10 @@ class CVMatrix:
     def _resolve_totals(self) -> None:
         """Hook: make ``_n_total`` / ``_nz_total`` current (multi-GPU subclasses fetch the
         all-reduced counts here)."""
+
+    def _totals_in_flight(self) -> bool:
+        """Hook: True while those counts are still being fetched from the device."""
+        return False
 
     def _gslice(self, lo: int, hi: int, cond: bool):
         if not cond or self._gstats is None:
@@ -844,8 +855,16 @@ class CVMatrix:
         r_muY = rXTY and (cX or cY)
         r_sdX = sX
         r_sdY = rXTY and sY
-        self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
+        # the data-dependent raises come before anything is launched -- unless the counts they
+        # need are still on their way from the other GPUs (multi-GPU, _totals_in_flight): then the
+        # kernels are queued first (they never fault on such data) and the check, which has to
+        # wait for the exchange anyway, follows; the results are only handed out after it
+        late = self._totals_in_flight()
+        if not late:
+            self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
         xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY, sweep_fold=sweep_fold)
+        if late:
+            self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
         o = self._out
         stats = (o(muX) if r_muX else None, o(sdX) if r_sdX else None,
                  o(muY) if r_muY else None, o(sdY) if r_sdY else None)
@@ -910,11 +929,93 @@ class CVMatrix:
         if self.X is not None and return_XTY and self.Y is None:
             raise ValueError(MSG_NO_Y)
         if self.X is not None:
-            i = self._sweep_fold_of(val_indices)
+            v = val_indices
+            if (type(v) is np.ndarray and v.ndim == 1 and 0 < v.size <= 32 and v.dtype == np.int64
+                    and v.flags.c_contiguous):
+                return self._one_small_fold(v, return_XTX, return_XTY)
+            i = self._sweep_fold_of(v)
             if i is not None:
                 return self._finish_sweep_fold(i, return_XTX, return_XTY)
         return self._first(
             self._training_matrices_batched(return_XTX, return_XTY, [val_indices]))
+
+    def _one_small_fold(self, v: np.ndarray, rXTX: bool, rXTY: bool):
+        """One fold of at most 32 rows given as an int64 index array -- the call of the reference's
+        leave-one-out loop (one ``training_XTX_XTY(validation_indices)`` per sample,
+        benchmarks/benchmark.py:153-158): same checks, same library call (``cvm_fold_update`` with
+        the indices inside the kernel arguments, CVM_IDX_HOST) and same bits as the general route,
+        without building a ``FoldBatch``, without a fold axis, with three allocations."""
+        lib = _lib.load()
+        self._ensure_fit()
+        N, K, M = self.N, self.K, self.M or 0
+        n = v.size
+        if n == 1:
+            lo = hi = int(v[0])
+        else:
+            lo, hi = int(v.min()), int(v.max())
+        if lo < -N or hi >= N:
+            raise IndexError(f"validation index out of bounds for {N} samples")
+        if lo < 0:
+            v = np.where(v < 0, v + N, v)
+        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
+        r_muX = cX or (rXTY and cY)                 # cvmatrix.py:828-831
+        r_muY = rXTY and (cX or cY)
+        r_sdX = sX
+        r_sdY = rXTY and sY
+        if r_muX or r_muY or r_sdX or r_sdY:        # the reference's raises, in its order (_validate)
+            self._resolve_totals()
+            if self.weights is not None:
+                wh = self._w_host
+                nz_val = int(np.count_nonzero(wh[v])) if n > 1 else int(wh[v[0]] != 0)
+                nz_train = self._nz_total - nz_val
+                if nz_train == 0:
+                    raise ValueError(MSG_NZ_ZERO)
+            else:
+                nz_train = self._n_total - n
+            if (r_sdX or r_sdY) and nz_train <= self.ddof:
+                raise ValueError(MSG_NZ_DDOF)
+        flags = ((_lib.RET_XTX if rXTX else 0) | (_lib.RET_XTY if rXTY else 0)
+                 | (_lib.CENTER_X if cX else 0) | (_lib.CENTER_Y if cY else 0)
+                 | (_lib.SCALE_X if sX else 0) | (_lib.SCALE_Y if sY else 0) | _lib.IDX_HOST)
+        dev, dt = self.device, self._tdt
+        if torch.cuda.current_device() != dev.index:
+            torch.cuda.set_device(dev)
+        xtx = torch.empty((K, K), dtype=dt, device=dev) if rXTX else None
+        xty = torch.empty((K, M), dtype=dt, device=dev) if rXTY else None
+        stat = torch.empty(2 * K + 2 * M, dtype=dt, device=dev)
+        base, es = stat.data_ptr(), stat.element_size()
+        key = (K, M, self._cdt)
+        if self._small_ws_key != key:
+            self._small_ws_bytes = int(lib.cvm_fold_workspace_bytes(1, 32, 32, K, M, self._cdt, 0x3F))
+            self._small_ws_key = key
+            self._one_off = np.zeros(2, dtype=np.int64)
+        ws = self._ws
+        if ws is None or ws.numel() < self._small_ws_bytes or ws.device != dev:
+            ws = self._workspace(self._small_ws_bytes)
+        off = self._one_off
+        off[1] = n
+        rc = lib.cvm_fold_update(
+            self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), v.ctypes.data, off.ctypes.data,
+            off.ctypes.data, 1, N, K, M, self._cdt, flags, float(self.ddof), float(self.resolution),
+            self._G.data_ptr(), _lib.ptr(self._H), self._gs.data_ptr(), _lib.ptr(xtx), _lib.ptr(xty),
+            base, base + K * es, (base + 2 * K * es) if M else 0, (base + (2 * K + M) * es) if M else 0,
+            0, ws.data_ptr(), ws.numel(), self._stream(),
+        )
+        _lib.check(rc, "cvm_fold_update")
+        if self.output == "numpy":
+            o = self._out
+            stats = (o(stat[:K].view(1, K)) if r_muX else None, o(stat[K:2 * K].view(1, K)) if r_sdX else None,
+                     o(stat[2 * K:2 * K + M].view(1, M)) if r_muY else None,
+                     o(stat[2 * K + M:].view(1, M)) if r_sdY else None)
+            if rXTX and rXTY:
+                return (o(xtx), o(xty)), stats
+            return (o(xtx) if rXTX else o(xty)), stats
+        stats = (stat[:K].view(1, K) if r_muX else None, stat[K:2 * K].view(1, K) if r_sdX else None,
+                 stat[2 * K:2 * K + M].view(1, M) if r_muY else None,
+                 stat[2 * K + M:].view(1, M) if r_sdY else None)
+        if rXTX and rXTY:
+            return (xtx, xty), stats
+        return (xtx if rXTX else xty), stats
 
     def _finish_sweep_fold(self, i: int, rXTX: bool, rXTY: bool):
         """One fold of the sweep, finished on its own (cvm_sweep_fold_range): the short path of
