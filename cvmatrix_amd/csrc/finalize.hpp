@@ -21,6 +21,15 @@ template <typename V> __device__ __forceinline__ void out_store(V *p, V v) {
 #endif
 }
 
+// Scaling by the training-set standard deviations (cvmatrix.py:1007-1010: XTX / (sd_a sd_b), XTY /
+// (sd_a sd_y)): the per-fold statistics vector `fstats` holds the RECIPROCAL stds, one division per
+// column and fold (fold_stats_kernel / small_stats_kernel), and every finish computes
+// v * (isd_a * isd_b).  A float64 division per output element costs a dozen instructions at the
+// float64 vector rate, and with K x K outputs per fold of a few rows that arithmetic -- not the
+// memory system -- bounded the small-fold kernels (K = 4096, 16-row folds: 3.4 TB/s of stores with
+// the division, 4.0 without any scaling).  Against the reference's v / (sd_a * sd_b) the result
+// differs by at most ~2 ulp (three roundings instead of two); the 1e-10 parity bar is six orders
+// above that, symmetry stays exact (the same two factors commute).
 struct FinArgs {
   Geom g;
   int splits;           // slot stride of the partial workspace: unit (seg, sp) = seg * splits + sp
@@ -161,7 +170,7 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
       if (sd <= a.resolution) sd = 1.0;  // 1128
     }
     fs[isX ? cc : 2 * K + cc] = mu;
-    fs[isX ? K + cc : 2 * K + M + cc] = sd;
+    fs[isX ? K + cc : 2 * K + M + cc] = 1.0 / sd;     // the finish MULTIPLIES by reciprocal stds (below)
     T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
     const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
     if (omu) omu[o] = (T)mu;
@@ -227,7 +236,7 @@ __device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, i
             if (FOLD) {
               v = (double)gvv[e] - upd;
               if (cX) v -= swt * (mur * st[2 * ST + cc]);
-              if (sX) v = v / (sdr * st[3 * ST + cc]);
+              if (sX) v = v * (sdr * st[3 * ST + cc]);
             } else {
               v = upd;
             }
@@ -325,7 +334,7 @@ __device__ __forceinline__ void fused_finish_direct(double (*Ts)[TP], const doub
       const double u1 = (diagb && lr > lc + 1) ? Ts[lc + 1][lr] : Ts[lr][lc + 1];
       double v0 = gv[j][0] - u0, v1 = gv[j][1] - u1;
       if (cX) { v0 -= swt * (mur * muc0); v1 -= swt * (mur * muc1); }
-      if (sX) { v0 = v0 / (sdr * sdc0); v1 = v1 / (sdr * sdc1); }
+      if (sX) { v0 = v0 * (sdr * sdc0); v1 = v1 * (sdr * sdc1); }
       out_store(reinterpret_cast<v2 *>(out + (size_t)gr * K + gc), (v2){v0, v1});
       if (!diagb) { Ts[lr][lc] = v0; Ts[lr][lc + 1] = v1; }   // parked for the mirrored store
     }
@@ -488,9 +497,9 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
       if (FOLD) {
         v = (double)Ht[(size_t)ga * M + m] - v;
         if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
-        if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + m]);
-        else if (sX) v = v / fs[K + ga];
-        else if (sY) v = v / fs[2 * K + M + m];
+        if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + m]);
+        else if (sX) v = v * fs[K + ga];
+        else if (sY) v = v * fs[2 * K + M + m];
       }
       out[(size_t)ga * M + m] = (T)v;
     }

@@ -99,7 +99,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
       if (sd <= a.resolution) sd = 1.0;  // 1128
     }
     fs[isX ? cc : 2 * K + cc] = mu;
-    fs[isX ? K + cc : 2 * K + M + cc] = sd;
+    fs[isX ? K + cc : 2 * K + M + cc] = 1.0 / sd;     // reciprocal: the finish multiplies (finalize.hpp)
     T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
     const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
     if (omu) omu[o] = (T)mu;
@@ -221,9 +221,9 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
           for (int r = 0; r < n; ++r) acc += As[r][la] * Bs[r][lm];
           double v = (double)Ht[(size_t)ga * M + gm] - (double)acc;
           if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + gm]);
-          if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + gm]);
-          else if (sX) v = v / fs[K + ga];
-          else if (sY) v = v / fs[2 * K + M + gm];
+          if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + gm]);
+          else if (sX) v = v * fs[K + ga];
+          else if (sY) v = v * fs[2 * K + M + gm];
           out[(size_t)ga * M + gm] = (T)v;
         }
       }
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
         for (int e = 0; e < VW; ++e) {
           double v = (double)gpre[p][e] - (double)acc[p][e];
           if (cX) v -= swt * (mur * cur.muc[e]);
-          if (sX) v = v / (sdr * cur.sdc[e]);
+          if (sX) v = v * (sdr * cur.sdc[e]);
           vv[e] = (T)v;
         }
         out_store(reinterpret_cast<vec_t *>(out + (size_t)(a0 + i) * K + gc), vv);
@@ -402,9 +402,9 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
         }
         double v = (double)Ht[(size_t)ga * M + m] - (double)s;
         if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
-        if (sX && sY) v = v / (fs[K + ga] * fs[2 * K + M + m]);
-        else if (sX) v = v / fs[K + ga];
-        else if (sY) v = v / fs[2 * K + M + m];
+        if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + m]);
+        else if (sX) v = v * fs[K + ga];
+        else if (sY) v = v * fs[2 * K + M + m];
         out[(size_t)ga * M + m] = (T)v;
       }
     }

@@ -508,9 +508,9 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
               if (row < K && col < M) {
                 double v = Ht[(size_t)row * M + col] - acc[m * 2 + n][r];
                 if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
-                if (sX && sY) v = v / (fs[K + row] * fs[2 * K + M + col]);
-                else if (sX) v = v / fs[K + row];
-                else if (sY) v = v / fs[2 * K + M + col];
+                if (sX && sY) v = v * (fs[K + row] * fs[2 * K + M + col]);
+                else if (sX) v = v * fs[K + row];
+                else if (sY) v = v * fs[2 * K + M + col];
                 out[(size_t)row * M + col] = v;
               }
             }
@@ -765,9 +765,9 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
             if (row < K && col < M) {
               double v = Ht[(size_t)row * M + col] - acch[i * NBY + n][r];
               if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
-              if (sX && sY) v = v / (fs[K + row] * fs[2 * K + M + col]);
-              else if (sX) v = v / fs[K + row];
-              else if (sY) v = v / fs[2 * K + M + col];
+              if (sX && sY) v = v * (fs[K + row] * fs[2 * K + M + col]);
+              else if (sX) v = v * fs[K + row];
+              else if (sY) v = v * fs[2 * K + M + col];
               out[(size_t)row * M + col] = v;
             }
           }
