@@ -199,6 +199,52 @@ def fp32_algorithm_error(torch, Xd, Yd, wd, val, ddof, flags, dev):
     return Gt.to(f64), Ht.to(f64)
 
 
+def measure_hbm_traffic(workload, path):
+    """HBM bytes per launch of the dominant Gram kernel, measured NOW: two child runs of this
+    script's headline loop under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
+    passes, as MI355X_MICROARCH.md's HBM section prescribes; counter KB -> bytes x1024, FETCH_SIZE
+    doubled on gfx950).  Returns (bytes, fetch, write, launches) or None if the profiler is not
+    usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None
+    out = {}
+    base = tempfile.mkdtemp(prefix="cvm_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--headline-only", "--steps", "5", "--warmup", "2",
+                   "--workload", workload, "--path", path, "--no-live-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=600)
+            if r.returncode != 0:
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        k = row["Kernel_Name"]
+                        # the gathered Gram launch: wgram4_kernel<T, WEIGHTED, GATHER = true, FUSED = false>
+                        if "wgram4_kernel" in k and row["Counter_Name"] == ctr and ", true, false>" in k:
+                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None
+            out[ctr] = (sum(per.values()) / len(per), len(per))
+        fetch = out["FETCH_SIZE"][0] * 1024.0 * 2.0
+        write = out["WRITE_SIZE"][0] * 1024.0
+        return fetch + write, fetch, write, out["FETCH_SIZE"][1]
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +265,9 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="override the global N (debug / tests)")
     ap.add_argument("--device-data", action="store_true",
                     help="generate the inputs on the device (default for C4)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-measure roofline.traffic with rocprofv3 child runs (two short passes, "
+                         "~1 min); the figure of profiles/hbm_traffic.json is reported instead")
     args = ap.parse_args()
 
     import torch
@@ -493,19 +542,29 @@ def main():
             lib.cvm_plan_fold(n_mine, int(n_val.max()), K, M, _lib.CVM_F64 if es == 8 else _lib.CVM_F32,
                               fl, C.c_size_t(1 << 40), info)
             executed = float(info[5]) * 2048.0 * float(np.ceil(n_val / 4.0).sum())
-        traffic = None
+        traffic = traffic_src = None
+        if world == 1 and not args.rows and not ho and not args.no_live_traffic:
+            live = measure_hbm_traffic(args.workload, args.path)
+            if live is not None:
+                traffic = round(live[0])
+                traffic_src = (f"measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over "
+                               f"`bench.py --headline-only --steps 5 --warmup 2` ({live[3]} launches of the gathered "
+                               f"wgram4_kernel; fetch {live[1] / 1e6:.0f} MB with the gfx950 x2 correction, write "
+                               f"{live[2] / 1e6:.0f} MB)")
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world == 1 and not args.rows:
+        if traffic is None and os.path.exists(tpath) and world == 1 and not args.rows:
             with open(tpath) as f:
                 traffic = json.load(f).get(args.workload, {}).get("fold_gram_bytes_per_launch")
+            if traffic:
+                traffic_src = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "`bench.py --headline-only` (not re-measured in this run)")
         n_rows_local = int(Xd.shape[0])
         roofline = {
             "kernel": "wgram4_kernel<T,WEIGHTED,GATHER,FUSED> (gather + weighted Gram of this rank's folds, "
                       "1 launch/step; in the sweep path the same launch also yields the full-data matrices)",
             "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_source": ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                               "`bench.py --headline-only` (not re-measured in this run)") if traffic else None,
+            "traffic_source": traffic_src,
             "flops_per_launch": f_tri, "flops_convention": "n*K*(K+1) + 2*n*K*M per fold (symmetric)",
             "achieved_dense_convention": round(f_dense / (gram_ms * 1e-3) / 1e12, 3) if gram_ms > 0 else None,
             "mfma_executed_tflops": round(executed / (gram_ms * 1e-3) / 1e12, 3) if gram_ms > 0 else None,
