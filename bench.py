@@ -222,7 +222,7 @@ def measure_hbm_traffic(workload, path):
                    sys.executable, os.path.join(ROOT, "bench.py"), "--headline-only", "--steps", "5", "--warmup", "2",
                    "--workload", workload, "--path", path, "--no-live-traffic"]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
-                               timeout=600)
+                               timeout=240)
             if r.returncode != 0:
                 return None
             per = {}

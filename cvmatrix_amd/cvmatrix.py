@@ -436,9 +436,7 @@ class CVMatrix:
         self._sweep_ids = None
         if src is not None and len(src._fold_arrays) == P:
             arrs = src._fold_arrays
-            self._sweep_ids = ({id(a): i for i, a in enumerate(arrs)},
-                               [(a.size, int(a[0]) if a.size else -1, int(a[-1]) if a.size else -1) for a in arrs],
-                               arrs)
+            self._sweep_ids = ({id(a): i for i, a in enumerate(arrs)}, [self._fingerprint(a) for a in arrs], arrs)
 
     @staticmethod
     def _weights_key(w):
@@ -917,10 +915,18 @@ class CVMatrix:
         i = ids[0].get(id(v))
         if i is None or ids[2][i] is not v:
             return None
-        size, first, last = ids[1][i]
-        if v.size != size or (size and (int(v[0]) != first or int(v[-1]) != last)):
+        if self._fingerprint(v) != ids[1][i]:
             return None                             # the array was changed since the sweep: recompute
         return i
+
+    @staticmethod
+    def _fingerprint(a: np.ndarray):
+        """Cheap witness that an index array still holds what it held when a sweep read it: size,
+        both ends and the sum of ~60 evenly spaced elements."""
+        n = a.size
+        if n == 0:
+            return (0, -1, -1, 0)
+        return (n, int(a[0]), int(a[-1]), int(a[::max(1, n // 61)].sum()))
 
     def _training_matrices(self, return_XTX: bool, return_XTY: bool, val_indices):
         """cvmatrix.py:754-896 for one fold."""

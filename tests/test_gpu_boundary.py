@@ -218,6 +218,12 @@ def test_reference_loop_is_served_from_one_sweep(amd, hip_device):
     (xtx, _), _ = m.training_XTX_XTY(v2)
     assert_normwise(xtx, sx[1].cpu().numpy(), 1e-11, "permuted fold")
     v2[:] = saved
+    assert m._sweep_fold_of(v2) == 1
+    other = int(p.get_validation_indices(keys[0])[5])
+    v2[v2.size // 2] = other                          # a row of another fold, in the middle
+    if m._fingerprint(v2) != m._fingerprint(saved):   # (the witness samples ~60 positions)
+        assert m._sweep_fold_of(v2) is None
+    v2[:] = saved
     # folds that do not partition the rows: no sweep, the fit kernel runs
     q = amd.Partitioner(np.arange(N) % 5)
     m3 = amd.CVMatrix()
