@@ -111,6 +111,13 @@ template <typename T> __global__ void fit_stats_kernel(const FinArgs a, double *
   fit_stats_columns<T>(a, gstats, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+// value of `v` in lane `j` (wave-uniform j) as a double
+__device__ __forceinline__ double lane_value(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
 // fold: training-set mean / std of every column; reference operation order
 // (cvmatrix.py:612-620, 709-745, 1043, 1079, 1119-1128)
 template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
@@ -121,10 +128,14 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
   const long u0 = (long)f * a.splits;
   double swv = 0, nzv = 0;
   if (weighted) {
-    for (int p = 0; p < a.s_diag; ++p) {
-      const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
-      swv += st[2 * g.Kp + 2 * g.Mp + 0];
-      nzv += st[2 * g.Kp + 2 * g.Mp + 1];
+    // lane l fetches partial p0 + l, the sums then run over the lanes in split order (one load
+    // round per 64 partials instead of a chain of dependent scalar loads)
+    const int lane = threadIdx.x & 63;
+    for (int p0 = 0; p0 < a.s_diag; p0 += 64) {
+      const int cnt = a.s_diag - p0 < 64 ? a.s_diag - p0 : 64;
+      const double *st = unit_stats<T>((char *)a.ws, g, u0 + p0 + (lane < cnt ? lane : 0));
+      const double sl = st[2 * g.Kp + 2 * g.Mp + 0], nl = st[2 * g.Kp + 2 * g.Mp + 1];
+      for (int j = 0; j < cnt; ++j) { swv += lane_value(sl, j); nzv += lane_value(nl, j); }
     }
   } else {
     swv = nzv = (double)(a.offs[a.seg0 + f + 1] - a.offs[a.seg0 + f]);
@@ -151,9 +162,22 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
     if (isX ? !(want_muX) : !(want_muY)) continue;
     const int s_src = isX ? cc : 2 * g.Kp + cc;
     const int q_src = isX ? g.Kp + cc : 2 * g.Kp + g.Mp + cc;
+    // in split order; sixteen partials (32 loads) in flight, the adds stay one chain
     double sv = 0, qv = 0;
+    int p = 0;
+    for (; p + 16 <= a.s_diag; p += 16) {
+      double s16[16], q16[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double *st = unit_stats<T>((char *)a.ws, g, u0 + p + j);
+        s16[j] = st[s_src]; q16[j] = st[q_src];
+      }
+      __builtin_amdgcn_sched_barrier(0);     // (all 32 loads issued before the first add waits)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { sv += s16[j]; qv += q16[j]; }
+    }
 #pragma unroll 4
-    for (int p = 0; p < a.s_diag; ++p) {
+    for (; p < a.s_diag; ++p) {
       const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
       sv += st[s_src]; qv += st[q_src];
     }

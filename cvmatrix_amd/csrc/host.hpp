@@ -292,6 +292,12 @@ int device_cu_count(int dev) {
   return c;
 }
 
+int current_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return device_cu_count(dev);
+}
+
 template <typename T>
 int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st,
                  int kind, unsigned *queue, bool fused = false) {
@@ -506,25 +512,20 @@ int fold_statistics_impl(const void *X, const void *Y, const void *w, const int6
   g.tile_elems = 0; g.h_elems = 0;
   g.unit_bytes = align_up(g.stat_len * 8, 256);
   const size_t fst = align_up(fstat_len(K, M) * 8, 256);
-  // rows per unit: short enough for >1000 workgroups in flight at the benchmark shapes, long
-  // enough that the units' statistics vectors stay a few per cent of the bytes streamed
-  int64_t splits = (max_rows + CVM_COL_ROWS - 1) / CVM_COL_ROWS;
-  if (splits < 1) splits = 1;
-  if (splits > 1024) splits = 1024;
+  int64_t splits = colstats_splits(max_rows, n_folds, K, sizeof(T), current_cu_count());
   while (splits > 1 && (size_t)splits * g.unit_bytes + fst > ws_bytes) splits /= 2;
   const size_t per_fold = (size_t)splits * g.unit_bytes + fst;
   if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
   int64_t per_batch = (int64_t)(ws_bytes / per_fold);
   if (per_batch > 32768) per_batch = 32768;
   const bool aligned = rows_aligned(X, K, sizeof(T));
-  constexpr int VEC = 16 / (int)sizeof(T);
-  const int nxb = (K + COL_THREADS * VEC - 1) / (COL_THREADS * VEC);
   for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
     const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
     ColArgs c;
-    c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0; c.splits = (int)splits;
+    c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0;
     c.g = g; c.ws = (char *)ws;
-    const dim3 grid((unsigned)(nxb + 1), (unsigned)(nb * splits));
+    colstats_shape<T>(c, K, M, nb, (int)splits);
+    const dim3 grid = colstats_grid(c, nb);
     if (w) {
       if (aligned) hipLaunchKernelGGL((colstats_kernel<T, true, true>), grid, dim3(COL_THREADS), 0, st, c);
       else hipLaunchKernelGGL((colstats_kernel<T, true, false>), grid, dim3(COL_THREADS), 0, st, c);
@@ -586,21 +587,19 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       gs.tile_elems = 0; gs.h_elems = 0;
       gs.unit_bytes = align_up(gs.stat_len * 8, 256);
       const size_t fst = align_up(fstat_len(K, M) * 8, 256);
-      int64_t csplits = (max_rows + CVM_COL_ROWS - 1) / CVM_COL_ROWS;
-      if (csplits < 1) csplits = 1;
+      int64_t csplits = colstats_splits(max_rows, n_folds, K, sizeof(T), current_cu_count());
       while (csplits > 1 && (size_t)csplits * gs.unit_bytes + fst > ws_bytes) csplits /= 2;
       const size_t per_fold = (size_t)csplits * gs.unit_bytes + fst;
       if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
       int64_t per_batch = (int64_t)(ws_bytes / per_fold);
       if (per_batch > 16384) per_batch = 16384;
-      constexpr int VEC = 16 / (int)sizeof(T);
-      const int nxb = (K + COL_THREADS * VEC - 1) / (COL_THREADS * VEC);
       for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
         ColArgs c;
-        c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0; c.splits = (int)csplits;
+        c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0;
         c.g = gs; c.ws = (char *)ws;
-        const dim3 cgrid((unsigned)(nxb + 1), (unsigned)(nb * csplits));
+        colstats_shape<T>(c, K, M, nb, (int)csplits);
+        const dim3 cgrid = colstats_grid(c, nb);
         if (w) hipLaunchKernelGGL((colstats_kernel<T, true, true>), cgrid, dim3(COL_THREADS), 0, st, c);
         else hipLaunchKernelGGL((colstats_kernel<T, false, true>), cgrid, dim3(COL_THREADS), 0, st, c);
         FinArgs f;

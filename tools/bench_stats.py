@@ -4,13 +4,14 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cvmatrix_amd._lib as L
-if len(sys.argv) > 1:
-    L.LIB_PATH = sys.argv[1]
+SHAPES = ((100000, 512, 16, 10, torch.float64), (200000, 4096, 1, 20, torch.float32),
+          (100000, 512, 16, 1000, torch.float64))
+if len(sys.argv) > 1:            # indices of the shapes to run, e.g. "0,1"
+    SHAPES = tuple(SHAPES[int(i)] for i in sys.argv[1].split(","))
 from cvmatrix_amd import CVMatrix, Partitioner
 
 dev = torch.device("cuda:0")
-for (N, K, M, P, dt) in ((100000, 512, 16, 10, torch.float64), (200000, 4096, 1, 20, torch.float32),
-                         (100000, 512, 16, 1000, torch.float64)):
+for (N, K, M, P, dt) in SHAPES:
     g = torch.Generator(device=dev); g.manual_seed(0)
     X = torch.rand((N, K), dtype=dt, device=dev, generator=g)
     Y = torch.rand((N, M), dtype=dt, device=dev, generator=g)
