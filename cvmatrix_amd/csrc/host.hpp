@@ -283,6 +283,8 @@ WsCarve carve_queue(void *ws, size_t ws_bytes) {
 }
 constexpr size_t QUEUE_RESERVE = QUEUE_BYTES + 256;   // what the workspace-size functions add for it
 
+__global__ void queue_zero_kernel(unsigned *q) { q[threadIdx.x] = 0u; }
+
 int device_cu_count(int dev) {
   static std::atomic<int> cus[64];
   int c = cus[dev & 63].load(std::memory_order_relaxed);
@@ -341,7 +343,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
   if (fast) {
     if (!queue) return fail(CVM_EWORKSPACE, "launch_wgram: no room for the work-queue heads in the workspace%s");
-    HIP_OK(hipMemsetAsync(queue, 0, QUEUE_BYTES, st));
+    // (a one-workgroup kernel: the runtime's fill kernel takes 5.6 us for these 1 KiB)
+    hipLaunchKernelGGL(queue_zero_kernel, dim3(1), dim3(QUEUE_BYTES / 4), 0, st, queue);
     // persistent workgroups: one per CU (fewer when the lists are shorter than that)
     long wgs = 8 * (a.ipx0 + a.ipx1);
     const long cus = device_cu_count(dev);
@@ -461,11 +464,14 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     const dim3 gs((unsigned)nb), ga((unsigned)(a.nT64 + a.P64), (unsigned)((nb + fpb - 1) / fpb));
     // one- and two-row folds (leave-one-out) of a matrix whose rows are not whole 128-byte lines and
     // fit one column chunk: whole rows of the full output, nothing transposed (small_rows_kernel;
-    // measured +23 % at the reference's published leave-one-out shape K = 500, slower elsewhere)
+    // measured +23 % at the reference's published leave-one-out shape K = 500 in float64 and +25 %
+    // in float32; it reads G for both triangles, so only while G stays in an XCD's L2 -- 2 MB:
+    // float32 K = 900 -8 %, K = 1000 -18 %)
     const int vw = 16 / (int)sizeof(T);
     const int lpr = K <= 64 * vw ? 64 : (K <= 128 * vw ? 128 : 256);     // pieces per row of a workgroup
     const int tc = lpr * vw;
-    const bool direct = !no_direct && sizeof(T) == 8 && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
+    const bool direct = !no_direct && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
+                        (size_t)K * K * sizeof(T) <= ((size_t)2 << 20) + (64 << 10) &&
                         ((size_t)K * sizeof(T)) % 16 == 0 && ((size_t)K * sizeof(T)) % 128 != 0 &&
                         ((uintptr_t)G % 16 == 0) && ((uintptr_t)X % 16 == 0) &&
                         (!a.out_XTX || (uintptr_t)a.out_XTX % 16 == 0);

@@ -77,28 +77,48 @@ def test_g3_leave_one_out_sweep(amd, chunk):
         pc.run_g3loo_case(name, make_factory(amd), TOL, batched=True)
 
 
-@pytest.mark.parametrize("K,weighted", [(70, True), (70, False), (500, True)])
-def test_leave_one_out_flag_sweep_rows_kernel(amd, K, weighted):
+def assert_fp32_like_reference(got, ref64, ref32, what, floor=2e-6):
+    """BASELINE.md section 4 for float32: the error against the float64 reference is at most
+    twice the error of the reference's own float32 arithmetic (`ref32`: the oracle run in
+    float32 on the same float32 inputs), plus a floor of a few float32 roundings of the scale."""
+    got = to_np(got).astype(np.float64)
+    ref64 = np.asarray(ref64, dtype=np.float64)
+    ref32 = np.asarray(ref32, dtype=np.float64)
+    scale = max(np.abs(ref64).max(), np.finfo(np.float64).tiny)
+    err = np.abs(got - ref64).max() / scale
+    yard = np.abs(ref32 - ref64).max() / scale
+    assert err <= 2 * yard + floor, f"{what}: error {err:.3e} > 2 x reference float32 error {yard:.3e} + {floor}"
+
+
+@pytest.mark.parametrize("K,weighted,dtype", [(70, True, np.float64), (70, False, np.float64), (500, True, np.float64),
+                                              (500, True, np.float32), (200, False, np.float32)])
+def test_leave_one_out_flag_sweep_rows_kernel(amd, K, weighted, dtype):
     """Every flag combination x ddof x Y/None on the route the reference's published
     leave-one-out benchmark takes (small_rows_kernel: one-row folds, rows that are not whole
     128-byte lines), against the oracle (which test_oracle_golden.py pins to the reference on
-    the same 128 configurations at K = 8)."""
+    the same 128 configurations at K = 8).  float32: against the float64 oracle with the
+    oracle's own float32 run as the yardstick."""
     import itertools
 
     rng = np.random.default_rng(1000 + K)
     N, M = 90, 3
-    X = rng.random((N, K)) * 2.0 + rng.random((1, K))
-    Y = rng.standard_normal((N, M)) + 1.0
-    w = rng.random(N) + 0.05
+    X = (rng.random((N, K)) * 2.0 + rng.random((1, K))).astype(dtype)
+    Y = (rng.standard_normal((N, M)) + 1.0).astype(dtype)
+    w = (rng.random(N) + 0.05).astype(dtype)
     w[rng.choice(N, size=9, replace=False)] = 0.0
     folds = [np.array([f]) for f in range(24)]
+    f32 = dtype is np.float32
+    X64, Y64, w64 = X.astype(np.float64), Y.astype(np.float64), w.astype(np.float64)
     for flags in itertools.product([False, True], repeat=4):
         for ddof in (0, 1):
             for hasY in (True, False):
-                m = amd.CVMatrix(*flags, ddof=ddof)
+                m = amd.CVMatrix(*flags, ddof=ddof, dtype=dtype)
                 o = OracleCVMatrix(*flags, ddof=ddof)
                 m.fit(X, Y if hasY else None, w if weighted else None)
-                o.fit(X, Y if hasY else None, w if weighted else None)
+                o.fit(X64, Y64 if hasY else None, w64 if weighted else None)
+                if f32:
+                    o32 = OracleCVMatrix(*flags, ddof=ddof, dtype=np.float32)
+                    o32.fit(X, Y if hasY else None, w if weighted else None)
                 what = f"K={K} flags={flags} ddof={ddof} Y={hasY}"
                 if hasY:
                     (bx, by), bst = m.training_XTX_XTY_batched(folds)
@@ -107,11 +127,24 @@ def test_leave_one_out_flag_sweep_rows_kernel(amd, K, weighted):
                 for f in (0, 7, 23):
                     if hasY:
                         (rx, ry), rst = o.training_XTX_XTY(folds[f])
-                        assert_normwise(by[f], ry, TOL, what + " XTY")
+                        if f32:
+                            (sx, sy), _ = o32.training_XTX_XTY(folds[f])
+                            assert_fp32_like_reference(by[f], ry, sy, what + " XTY")
+                        else:
+                            assert_normwise(by[f], ry, TOL, what + " XTY")
                     else:
                         rx, rst = o.training_XTX(folds[f])
-                    assert_normwise(bx[f], rx, TOL, what + " XTX")
-                    assert_stats(tuple(None if s is None else s[f] for s in bst), rst, TOL, what)
+                        if f32:
+                            sx, _ = o32.training_XTX(folds[f])
+                    if f32:
+                        assert_fp32_like_reference(bx[f], rx, sx, what + " XTX")
+                        for a_, b_ in zip(tuple(None if s is None else s[f] for s in bst), rst):
+                            assert (a_ is None) == (b_ is None)
+                            if b_ is not None:
+                                np.testing.assert_allclose(to_np(a_).astype(np.float64), b_, rtol=3e-5)
+                    else:
+                        assert_normwise(bx[f], rx, TOL, what + " XTX")
+                        assert_stats(tuple(None if s is None else s[f] for s in bst), rst, TOL, what)
 
 
 def test_g4_example_zero_weight_and_str_label(amd):

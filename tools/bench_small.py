@@ -30,6 +30,13 @@ def run(name, N, K, M, nv, nfolds, dtype, reps=5):
           f"{bytes_alg/ms/1e6:7.0f} GB/s algorithmic ({bytes_alg/ms/1e6/8000:.2f} of 8 TB/s)")
 
 if __name__ == "__main__":
+    if os.environ.get("SMALL_F32"):
+        run("K=500 M=10 fp32 LOOCV", 100000, 500, 10, 1, 4000, np.float32)
+        run("K=500 M=10 fp32 n_v=2", 100000, 500, 10, 2, 4000, np.float32)
+        run("K=250 M=10 fp32 LOOCV", 100000, 250, 10, 1, 8000, np.float32)
+        run("K=1000 M=10 fp32 LOOCV", 100000, 1000, 10, 1, 1000, np.float32)
+        run("K=900 M=10 fp32 LOOCV", 100000, 900, 10, 1, 1000, np.float32)
+        sys.exit(0)
     run("K=4096 M=1 fp64 n_v=16", 20000, 4096, 1, 16, 24, np.float64)
     run("K=4096 M=1 fp32 n_v=16 (C5-hbm)", 20000, 4096, 1, 16, 48, np.float32)
     run("K=500 M=10 fp64 LOOCV", 100000, 500, 10, 1, 2000, np.float64)
