@@ -26,7 +26,7 @@ EXPORTS = (
     "cvm_version", "cvm_source_hash", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
     "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_plan_fold",
     "cvm_timing_enable", "cvm_timing_read",
-    "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds", "cvm_sweep_fold_range",
+    "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds", "cvm_sweep_fold_range", "cvm_sweep_all",
     "cvm_partition_workspace_bytes", "cvm_partition_labels",
     "cvm_pls_workspace_bytes", "cvm_pls_fit", "cvm_pls_plan",
 )
@@ -84,6 +84,9 @@ def load():
     lib.cvm_sweep_fit.restype = C.c_int
     lib.cvm_sweep_fit.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int,
                                   vp, vp, vp, vp, vp, sz, vp, vp]
+    lib.cvm_sweep_all.restype = C.c_int
+    lib.cvm_sweep_all.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, u32, dbl, dbl,
+                                  vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]
     lib.cvm_sweep_folds.restype = C.c_int
     lib.cvm_sweep_folds.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int, u32, dbl, dbl, C.c_int,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i64, vp]

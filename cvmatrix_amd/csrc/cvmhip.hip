@@ -184,6 +184,27 @@ int cvm_sweep_fit(const void *X, const void *Y, const void *w, const int64_t *id
   return fail(CVM_EINVAL, "cvm_sweep_fit: dtype must be CVM_F32 or CVM_F64%s");
 }
 
+int cvm_sweep_all(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
+                  const int64_t *host_offsets, int64_t n_folds, int64_t N, int K, int M, int dtype, unsigned flags,
+                  double ddof, double resolution, void *G, void *H, double *gstats, int32_t *neg_flag,
+                  void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                  double *out_fold, void *ws, size_t ws_bytes, void *stream, int64_t *splits_out) {
+  if (!X || !idx || !offsets || !host_offsets || !G || !gstats || !ws)
+    return fail(CVM_EINVAL, "cvm_sweep_all: null pointer%s");
+  if (n_folds <= 0 || N <= 0 || K <= 0 || M < 0 || (M > 0 && (!Y || !H)) || (M == 0 && Y))
+    return fail(CVM_EINVAL, "cvm_sweep_all: bad shape%s");
+  if ((flags & CVM_RET_XTY) && M == 0) return fail(CVM_EINVAL, "cvm_sweep_all: CVM_RET_XTY needs Y and H%s");
+  if (dtype == CVM_F64)
+    return sweep_all_impl<double>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype, flags, ddof, resolution,
+                                  G, H, gstats, neg_flag, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY,
+                                  out_fold, ws, ws_bytes, (hipStream_t)stream, splits_out);
+  if (dtype == CVM_F32)
+    return sweep_all_impl<float>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype, flags, ddof, resolution,
+                                 G, H, gstats, neg_flag, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY,
+                                 out_fold, ws, ws_bytes, (hipStream_t)stream, splits_out);
+  return fail(CVM_EINVAL, "cvm_sweep_all: dtype must be CVM_F32 or CVM_F64%s");
+}
+
 int cvm_sweep_fold_range(const int64_t *offsets, int64_t n_total, int64_t fold0, int64_t n_folds, int K, int M,
                          int dtype, unsigned flags, double ddof, double resolution, int weighted, const void *G,
                          const void *H, const double *gstats, void *out_XTX, void *out_XTY, void *out_muX,

@@ -90,9 +90,10 @@ __device__ __forceinline__ void fit_stats_columns(const FinArgs &a, double *gsta
     else if (c < 2 * g.K + g.M) src = 2 * g.Kp + (c - 2 * g.K);
     else if (c < 2 * g.K + 2 * g.M) src = 2 * g.Kp + g.Mp + (c - 2 * g.K - g.M);
     else src = 2 * g.Kp + 2 * g.Mp + (c - 2 * g.K - 2 * g.M);
-    // in split order; sixteen loads in flight at a time (the chain of adds stays sequential)
-    double s = 0;
-    int p = 0;
+    // segment by segment, in split order: s = sum_seg (sum_sp partial) -- the one-sweep path sums
+    // the folds' own sums (one segment: the plain chain); sixteen loads in flight at a time
+    double s = 0, us = 0;
+    int p = 0, kk = 0;
     const int np = a.n_sum * a.s_diag;     // (the column sums come from the diagonal items)
     UnitCursor cur(a.s_diag, a.splits);
     for (; p + 16 <= np; p += 16) {
@@ -100,9 +101,12 @@ __device__ __forceinline__ void fit_stats_columns(const FinArgs &a, double *gsta
 #pragma unroll
       for (int u = 0; u < 16; ++u) v[u] = unit_stats<T>((char *)a.ws, g, cur.next())[src];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s += v[u];
+      for (int u = 0; u < 16; ++u) { us += v[u]; if (++kk == a.s_diag) { s += us; us = 0; kk = 0; } }
     }
-    for (; p < np; ++p) s += unit_stats<T>((char *)a.ws, g, cur.next())[src];
+    for (; p < np; ++p) {
+      us += unit_stats<T>((char *)a.ws, g, cur.next())[src];
+      if (++kk == a.s_diag) { s += us; us = 0; kk = 0; }
+    }
     if (c < total - 1) gstats[c] = s;
     else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
   }
@@ -116,6 +120,32 @@ __device__ __forceinline__ double lane_value(double v, int j) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
   return __hiloint2double(hi, lo);
+}
+
+// One column of one fold: training-set mean and std from the fold's column sums (sv, qv), the
+// full-data sums (gs, gq), the training-set weight sum and divisor; reference operation order
+// (cvmatrix.py:1020, 1043, 1119-1128).  Writes the fold's statistics vector and the outputs.
+template <typename T>
+__device__ __forceinline__ void fold_column_finish(const FinArgs &a, int f, bool isX, int cc, double sv, double qv,
+                                                   double gs, double gq, double swt, double divisor,
+                                                   bool want_sd, double *fs) {
+  const int K = a.g.K, M = a.g.M;
+  const double st_ = gs - sv;          // cvmatrix.py:1020
+  const double mu = st_ / swt;         // cvmatrix.py:1043
+  double sd = 1.0;
+  if (want_sd) {
+    const double qt = gq - qv;
+    double var = (-2 * mu * st_ + swt * (mu * mu) + qt) / divisor;   // 1119-1123
+    var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
+    sd = sqrt(var);
+    if (sd <= a.resolution) sd = 1.0;  // 1128
+  }
+  fs[isX ? cc : 2 * K + cc] = mu;
+  fs[isX ? K + cc : 2 * K + M + cc] = 1.0 / sd;     // the finish MULTIPLIES by reciprocal stds (below)
+  T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
+  const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
+  if (omu) omu[o] = (T)mu;
+  if (osd && want_sd) osd[o] = (T)sd;
 }
 
 // fold: training-set mean / std of every column; reference operation order
@@ -183,22 +213,7 @@ template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
     }
     const double gs = isX ? a.gstats[cc] : a.gstats[2 * K + cc];
     const double gq = isX ? a.gstats[K + cc] : a.gstats[2 * K + M + cc];
-    const double st_ = gs - sv;          // cvmatrix.py:1020
-    const double mu = st_ / swt;         // cvmatrix.py:1043
-    double sd = 1.0;
-    if (isX ? want_sdX : want_sdY) {
-      const double qt = gq - qv;
-      double var = (-2 * mu * st_ + swt * (mu * mu) + qt) / divisor;   // 1119-1123
-      var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
-      sd = sqrt(var);
-      if (sd <= a.resolution) sd = 1.0;  // 1128
-    }
-    fs[isX ? cc : 2 * K + cc] = mu;
-    fs[isX ? K + cc : 2 * K + M + cc] = 1.0 / sd;     // the finish MULTIPLIES by reciprocal stds (below)
-    T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
-    const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
-    if (omu) omu[o] = (T)mu;
-    if (osd && (isX ? want_sdX : want_sdY)) osd[o] = (T)sd;
+    fold_column_finish<T>(a, f, isX, cc, sv, qv, gs, gq, swt, divisor, isX ? want_sdX : want_sdY, fs);
   }
 }
 
@@ -465,6 +480,21 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     const int nsp = (ti == tj) ? a.s_diag : a.s_off;
     const int np = FOLD ? nsp : a.n_sum * nsp;
     auto slot = [&](int q) -> size_t { return (size_t)(FOLD ? (long)q : sum_unit(q, nsp, a.splits)) * g.unit_bytes; };
+    // fit mode over several segments (the one-sweep path): segment sums first, then their sum
+    // (v = sum_seg (sum_sp partial)); one segment or fold mode: the plain chain in uu, moved to v
+    double uu[NQ][VW];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) uu[j][e] = 0;
+    int kk = 0;
+    auto close_segment = [&]() {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { v[j][e] += uu[j][e]; uu[j][e] = 0; }
+      kk = 0;
+    };
     int p = 0;
     for (; p + UP <= np; p += UP) {
       vld_t qv[UP][NQ];
@@ -475,11 +505,13 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
         for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + so);
       }
 #pragma unroll
-      for (int u = 0; u < UP; ++u)
+      for (int u = 0; u < UP; ++u) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
 #pragma unroll
-          for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[u][j][e];
+          for (int e = 0; e < VW; ++e) uu[j][e] += (double)qv[u][j][e];
+        if (++kk == nsp) close_segment();
+      }
     }
     for (; p < np; ++p) {
       vld_t qv[NQ];
@@ -489,7 +521,8 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
 #pragma unroll
       for (int j = 0; j < NQ; ++j)
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[j][e];
+        for (int e = 0; e < VW; ++e) uu[j][e] += (double)qv[j][e];
+      if (++kk == nsp) close_segment();
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -515,9 +548,13 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
       double v = 0;
       const char *pp = ws0 + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
       const int np = FOLD ? a.s_diag : a.n_sum * a.s_diag;
+      double us = 0;
+      int kk = 0;
 #pragma unroll 4
-      for (int p = 0; p < np; ++p)
-        v += (double)*reinterpret_cast<const T *>(pp + (size_t)(FOLD ? (long)p : sum_unit(p, a.s_diag, a.splits)) * g.unit_bytes);
+      for (int p = 0; p < np; ++p) {
+        us += (double)*reinterpret_cast<const T *>(pp + (size_t)(FOLD ? (long)p : sum_unit(p, a.s_diag, a.splits)) * g.unit_bytes);
+        if (++kk == a.s_diag) { v += us; us = 0; kk = 0; }     // (segment sums, then their sum)
+      }
       if (FOLD) {
         v = (double)Ht[(size_t)ga * M + m] - v;
         if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
@@ -583,6 +620,21 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
     const int nsp = (ti == tj) ? a.s_diag : a.s_off;
     const int np = a.n_sum * nsp;                    // segment-major, split order within a segment
     UnitCursor cur(nsp, a.splits);
+    // segment sums first, then their sum (v = sum_seg (sum_sp partial): the one-sweep path's
+    // G = sum_f G_Vf with G_Vf exactly the update the fold stage subtracts; one segment: the chain)
+    double uu[NQ][VW];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) uu[j][e] = 0;
+    int kk = 0;
+    auto close_segment = [&]() {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { v[j][e] += uu[j][e]; uu[j][e] = 0; }
+      kk = 0;
+    };
     int p = 0;
     for (; p + UP <= np; p += UP) {
       vld_t qv[UP][NQ];
@@ -593,11 +645,13 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
         for (int j = 0; j < NQ; ++j) qv[u][j] = *reinterpret_cast<const vld_t *>(pp[j] + so);
       }
 #pragma unroll
-      for (int u = 0; u < UP; ++u)
+      for (int u = 0; u < UP; ++u) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
 #pragma unroll
-          for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[u][j][e];
+          for (int e = 0; e < VW; ++e) uu[j][e] += (double)qv[u][j][e];
+        if (++kk == nsp) close_segment();
+      }
     }
     for (; p < np; ++p) {
       const size_t so = (size_t)cur.next() * g.unit_bytes;
@@ -605,8 +659,9 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
       for (int j = 0; j < NQ; ++j) {
         const vld_t qv = *reinterpret_cast<const vld_t *>(pp[j] + so);
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[j][e] += (double)qv[e];
+        for (int e = 0; e < VW; ++e) uu[j][e] += (double)qv[e];
       }
+      if (++kk == nsp) close_segment();
     }
     T *out = (T *)a.out_XTX;
 #pragma unroll
@@ -664,9 +719,9 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
       const int ra = e / M, m = e - ra * M;
       const int ga = ti * TILE + pc * PR + ra;
       if (ga >= K) continue;
-      double s = 0;
+      double s = 0, us = 0;
       const char *pp = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
-      int p = 0;
+      int p = 0, kk = 0;
       const int np = a.n_sum * a.s_diag;
       UnitCursor cur(a.s_diag, a.splits);
       for (; p + 16 <= np; p += 16) {
@@ -674,10 +729,313 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
 #pragma unroll
         for (int u = 0; u < 16; ++u) t16[u] = *reinterpret_cast<const T *>(pp + (size_t)cur.next() * g.unit_bytes);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += (double)t16[u];
+        for (int u = 0; u < 16; ++u) { us += (double)t16[u]; if (++kk == a.s_diag) { s += us; us = 0; kk = 0; } }
       }
-      for (; p < np; ++p) s += (double)*reinterpret_cast<const T *>(pp + (size_t)cur.next() * g.unit_bytes);
+      for (; p < np; ++p) {
+        us += (double)*reinterpret_cast<const T *>(pp + (size_t)cur.next() * g.unit_bytes);
+        if (++kk == a.s_diag) { s += us; us = 0; kk = 0; }
+      }
       out[(size_t)ga * M + m] = (T)s;
     }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------
+// One-sweep path with few folds (<= SWF_MAX), everything in two launches after the Gram kernel:
+//   sweep_stats_kernel   full-data column sums (gstats) AND every fold's statistics
+//   sweep_finish_kernel  full-data G, H AND every fold's training matrices, each partial read once
+// (fit_apply_kernel + fold_stats_kernel + apply_kernel read the folds' partials twice: 68 MB of the
+// 91 MB they move at C3.)  A fold's raw update U_f = sum_sp partial stays in registers; G = sum_f
+// U_f in fold order -- the very sums fit_apply_kernel and apply_kernel form, so the results are
+// bit-identical to cvm_sweep_fit + cvm_sweep_folds.
+// ----------------------------------------------------------------------------------
+constexpr int SWF_MAX = 16;    // folds whose updates a thread holds
+constexpr int SWF_R = 16;      // block rows of sweep_finish_kernel (its columns: 256 bytes)
+#ifndef CVM_SWF_GROUP
+#define CVM_SWF_GROUP 8
+#endif
+#ifndef CVM_SWF_PIPE
+#define CVM_SWF_PIPE 0
+#endif
+constexpr int SWF_GROUP = CVM_SWF_GROUP;   // output matrices finished per barrier round
+
+// thread = (column cl of the block's 16, fold fl): the fold's column sums from its s_diag partials,
+// the full-data sums over the folds through LDS, then the fold's mean / std
+template <typename T> __global__ __launch_bounds__(256) void sweep_stats_kernel(const FinArgs a, double *gstats) {
+  const Geom &g = a.g;
+  const int K = g.K, M = g.M, P = a.n_seg;
+  const int tid = threadIdx.x, cl = tid & 15, fl = tid >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool cvalid = c < K + M, fvalid = fl < P;
+  const bool isX = c < K;
+  const int cc = isX ? c : c - K;
+  const int s_src = isX ? cc : 2 * g.Kp + cc;
+  const int q_src = isX ? g.Kp + cc : 2 * g.Kp + g.Mp + cc;
+  __shared__ double ss[SWF_MAX][17], qq[SWF_MAX][17], tot[3][SWF_MAX];
+  const bool weighted = a.w != nullptr;
+  double sv = 0, qv = 0, tv = 0;
+  const long u0 = (long)fl * a.splits;
+  if (fvalid) {
+    const int t_src = (int)(2 * g.Kp + 2 * g.Mp) + (cl < 3 ? cl : 0);    // sw, nz, neg of the fold (cl 0..2)
+    for (int p0 = 0; p0 < a.s_diag; p0 += 8) {
+      const int cnt = a.s_diag - p0 < 8 ? a.s_diag - p0 : 8;
+      double s8[8], q8[8], t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double *st = unit_stats<T>((char *)a.ws, g, u0 + p0 + (j < cnt ? j : 0));
+        s8[j] = cvalid ? st[s_src] : 0.0; q8[j] = cvalid ? st[q_src] : 0.0; t8[j] = st[t_src];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < cnt) { sv += s8[j]; qv += q8[j]; tv += t8[j]; }
+    }
+    ss[fl][cl] = sv; qq[fl][cl] = qv;
+    if (cl < 3) tot[cl][fl] = tv;
+  }
+  __syncthreads();
+  double gs = 0, gq = 0, gsw = 0, gnz = 0, gng = 0;
+  for (int f = 0; f < P; ++f) { gs += ss[f][cl]; gq += qq[f][cl]; gsw += tot[0][f]; gnz += tot[1][f]; gng += tot[2][f]; }
+  if (fl == 0 && cvalid) {
+    gstats[isX ? cc : 2 * K + cc] = gs;
+    gstats[isX ? K + cc : 2 * K + M + cc] = gq;
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    gstats[2 * K + 2 * M] = gsw; gstats[2 * K + 2 * M + 1] = gnz;
+    if (a.neg_flag) *a.neg_flag = (gng > 0) ? 1 : 0;
+  }
+  if (!fvalid || !a.fstats) return;
+  double swv, nzv;
+  if (weighted) { swv = tot[0][fl]; nzv = tot[1][fl]; }
+  else swv = nzv = (double)(a.offs[a.seg0 + fl + 1] - a.offs[a.seg0 + fl]);
+  const double swt = gsw - swv, nzt = gnz - nzv;
+  const double divisor = (nzt - a.ddof) * swt / nzt;
+  double *fs = a.fstats + (size_t)fl * fstat_len(K, M);
+  if (blockIdx.x == 0 && cl == 0) {
+    fs[2 * K + 2 * M] = swt;
+    if (a.out_fold) {
+      double *o = a.out_fold + 4 * (a.seg0 + fl);
+      o[0] = swt; o[1] = nzt; o[2] = swv; o[3] = nzv;
+    }
+  }
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const bool rXTY = a.flags & CVM_RET_XTY;
+  const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
+  const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
+  if (!cvalid || (isX ? !want_muX : !want_muY)) return;
+  fold_column_finish<T>(a, fl, isX, cc, sv, qv, gs, gq, swt, divisor, isX ? want_sdX : want_sdY, fs);
+}
+
+// Blocks of SWF_R rows x (256 bytes of) columns over the upper triangle of the K x K matrices (a
+// block is inside one 128 x 128 tile of the partials), then ceil(K M / 256) workgroups for XTY.
+// A thread owns one 16-byte piece: the folds' updates of it in registers, their sum = its piece of
+// G; elements below the diagonal are masked (the partials hold nothing there), every finished
+// matrix is stored as rows a / columns b and, through an LDS transpose, as rows b / columns a.
+// Needs 16-byte aligned rows (K * sizeof(T) % 16 == 0) and P <= SWF_MAX.
+template <typename T> __global__ __launch_bounds__(256) void sweep_finish_kernel(const FinArgs a, T *Gout, T *Hout) {
+  const Geom &g = a.g;
+  const int K = g.K, M = g.M, P = a.n_seg;
+  const int tid = threadIdx.x;
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int C = 16 * VW;                 // block columns
+  typedef T vld_t __attribute__((ext_vector_type(VW)));
+  const int nrb = (K + SWF_R - 1) / SWF_R, ncb = (K + C - 1) / C;
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const int x = blockIdx.x;
+  if (x >= nrb * ncb) {
+    // ---- XTY: thread = (element el of the workgroup's 16, fold fl): the fold's update from its
+    // s_diag partials, H = their sum over the folds through LDS, then the fold's own result
+    if (M == 0 || !Hout) return;
+    const int el = tid & 15, fl = tid >> 4;
+    const int e = (x - nrb * ncb) * 16 + el;
+    const bool evalid = e < K * M, fvalid = fl < P;
+    const int ga = evalid ? e / M : 0, m = evalid ? e - ga * M : 0;
+    const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
+    __shared__ double uh[SWF_MAX][17];
+    double u = 0;
+    if (fvalid) {
+      const char *pf = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T) + (size_t)fl * a.splits * g.unit_bytes;
+      for (int p0 = 0; p0 < a.s_diag; p0 += 8) {
+        const int cnt = a.s_diag - p0 < 8 ? a.s_diag - p0 : 8;
+        T t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = *reinterpret_cast<const T *>(pf + (size_t)(p0 + (j < cnt ? j : 0)) * g.unit_bytes);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < cnt) u += (double)t8[j];
+      }
+      uh[fl][el] = u;
+    }
+    __syncthreads();
+    double h = 0;
+    for (int f = 0; f < P; ++f) h += uh[f][el];
+    const T hT = (T)h;
+    if (!evalid) return;
+    if (fl == 0) Hout[(size_t)ga * M + m] = hT;
+    if (!a.out_XTY || !fvalid) return;
+    {
+      const double *fs = a.fstats + (size_t)fl * fstat_len(K, M);
+      const double swt = fs[2 * K + 2 * M];
+      double v = (double)hT - u;
+      if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
+      if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + m]);
+      else if (sX) v = v * fs[K + ga];
+      else if (sY) v = v * fs[2 * K + M + m];
+      ((T *)a.out_XTY)[((size_t)(a.seg0 + fl) * K + ga) * M + m] = (T)v;
+    }
+    return;
+  }
+  const int rb = x / ncb, cb = x - rb * ncb;
+  const int a0 = rb * SWF_R, b0 = cb * C;
+  if (b0 + C - 1 < a0) return;               // the whole block is below the diagonal
+  const int lr = tid >> 4, lc = (tid & 15) * VW;
+  const int gr = a0 + lr, gc = b0 + lc;
+  const int ti = a0 / TILE, tj = b0 / TILE;
+  const int nsp = (ti == tj) ? a.s_diag : a.s_off;
+  const size_t off = (size_t)tile_id(ti, tj, g.P) * TILE * TILE + (size_t)(a0 - ti * TILE + lr) * TILE + (b0 - tj * TILE + lc);
+  const char *pp = a.ws + off * sizeof(T);
+  // the folds' statistics of this block: [f][0..15] row means, [16..31] row 1/sd, [32..32+C) column
+  // means, [32+C..32+2C) column 1/sd, [32+2C] sw_T
+  constexpr int SL = 32 + 2 * C + 1;
+  __shared__ double stl[SWF_MAX][SL];
+  __shared__ T tm[SWF_GROUP][SWF_R][C + 1];
+  if (a.out_XTX) {
+    for (int q = tid; q < P * SL; q += 256) {
+      const int f = q / SL, i = q - f * SL;
+      const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+      double v;
+      if (i < 16) v = (cX && a0 + i < K) ? fs[a0 + i] : 0.0;
+      else if (i < 32) v = (sX && a0 + i - 16 < K) ? fs[K + a0 + i - 16] : 1.0;
+      else if (i < 32 + C) v = (cX && b0 + i - 32 < K) ? fs[b0 + i - 32] : 0.0;
+      else if (i < 32 + 2 * C) v = (sX && b0 + i - 32 - C < K) ? fs[K + b0 + i - 32 - C] : 1.0;
+      else v = fs[2 * K + 2 * M];
+      stl[f][i] = v;
+    }
+  }
+  // the folds' updates of this thread's piece, in split order, and their sum in fold order; the
+  // partials of fold f + 1 are requested before those of fold f are added (up to 8 at a time)
+  double U[SWF_MAX][VW], gsum[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) gsum[e] = 0;
+  vld_t qv[2][8];
+  auto request = [&](int f, int p0, vld_t (&q)[8]) {
+    const char *pf = pp + (size_t)f * a.splits * g.unit_bytes;
+    const int cnt = nsp - p0 < 8 ? nsp - p0 : 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const vld_t *>(pf + (size_t)(p0 + (j < cnt ? j : 0)) * g.unit_bytes);
+  };
+  auto add = [&](int p0, const vld_t (&q)[8], double (&u)[VW]) {
+    const int cnt = nsp - p0 < 8 ? nsp - p0 : 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < cnt) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) u[e] += (double)q[j][e];
+      }
+  };
+  request(0, 0, qv[0]);
+#pragma unroll
+  for (int f = 0; f < SWF_MAX; ++f) {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) U[f][e] = 0;
+    if (f < P) {
+      if (CVM_SWF_PIPE && nsp <= 8) {
+        if (f + 1 < P) request(f + 1, 0, qv[(f + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        add(0, qv[f & 1], U[f]);
+      } else {
+        add(0, qv[f & 1], U[f]);
+        for (int p0 = 8; p0 < nsp; p0 += 8) { request(f, p0, qv[f & 1]); add(p0, qv[f & 1], U[f]); }
+        if (f + 1 < P) request(f + 1, 0, qv[(f + 1) & 1]);
+      }
+#pragma unroll
+      for (int e = 0; e < VW; ++e) gsum[e] += U[f][e];
+    }
+  }
+  // element (gr, gc + e) is this thread's to finish when it is on or above the diagonal
+  bool ok[VW];
+  const bool all_ok = gr < K && gc + VW <= K && gr <= gc;
+#pragma unroll
+  for (int e = 0; e < VW; ++e) ok[e] = gr < K && gc + e < K && gr <= gc + e;
+  T gT[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) gT[e] = (T)gsum[e];
+  // output matrix o: 0 = G, o >= 1 = fold o - 1.  SWF_GROUP matrices per round: the finished
+  // pieces are stored as rows a / columns b and parked in LDS; after one barrier the images
+  // are stored transposed as rows b0 + c / columns a0 + r (strictly below the diagonal).
+  const int mc = tid / (SWF_R / VW), mr = (tid - mc * (SWF_R / VW)) * VW;
+  const int n_out = a.out_XTX ? P + 1 : 1;
+  __syncthreads();                                   // (stl)
+  for (int o0 = 0; o0 < n_out; o0 += SWF_GROUP) {
+#pragma unroll
+    for (int k = 0; k < SWF_GROUP; ++k) {
+      const int o = o0 + k;
+      if (o < n_out) {
+        T vals[VW];
+        T *out;
+        if (o == 0) {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) vals[e] = gT[e];
+          out = Gout;
+        } else {
+          // (o0 is 0 or a multiple of SWF_GROUP: the fold number is known at compile time in
+          //  each of the unrolled cases below, so U stays in registers)
+          double uf[VW];
+#pragma unroll
+          for (int e = 0; e < VW; ++e) uf[e] = 0;
+#pragma unroll
+          for (int f = 0; f < SWF_MAX; ++f)
+            if (f == o - 1) {
+#pragma unroll
+              for (int e = 0; e < VW; ++e) uf[e] = U[f][e];
+            }
+          const double *st = stl[o - 1];
+          const double swt = st[32 + 2 * C], mur = st[lr], sdr = st[16 + lr];
+#pragma unroll
+          for (int e = 0; e < VW; ++e) {
+            double v = (double)gT[e] - uf[e];
+            if (cX) v -= swt * (mur * st[32 + lc + e]);
+            if (sX) v = v * (sdr * st[32 + C + lc + e]);
+            vals[e] = (T)v;
+          }
+          out = (T *)a.out_XTX + (size_t)(a.seg0 + o - 1) * K * K;
+        }
+        T *dst = out + (size_t)gr * K + gc;
+        if (all_ok) {
+          vld_t vv;
+#pragma unroll
+          for (int e = 0; e < VW; ++e) vv[e] = vals[e];
+          if (o) out_store(reinterpret_cast<vld_t *>(dst), vv); else *reinterpret_cast<vld_t *>(dst) = vv;
+        } else {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) if (ok[e]) dst[e] = vals[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VW; ++e) tm[k][lr][lc + e] = vals[e];
+      }
+    }
+    __syncthreads();
+    const int orow = b0 + mc, ocol = a0 + mr;
+    if (orow < K) {
+#pragma unroll
+      for (int k = 0; k < SWF_GROUP; ++k) {
+        const int o = o0 + k;
+        if (o < n_out) {
+          T *out = o ? (T *)a.out_XTX + (size_t)(a.seg0 + o - 1) * K * K : Gout;
+          T *md = out + (size_t)orow * K + ocol;
+          if (ocol + VW <= K && ocol + VW - 1 < orow) {
+            vld_t vv;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) vv[e] = tm[k][mr + e][mc];
+            if (o) out_store(reinterpret_cast<vld_t *>(md), vv); else *reinterpret_cast<vld_t *>(md) = vv;
+          } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) if (ocol + e < K && ocol + e < orow) md[e] = tm[k][mr + e][mc];
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
 }

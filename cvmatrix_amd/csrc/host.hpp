@@ -747,3 +747,69 @@ int sweep_folds_impl(const int64_t *offsets, int64_t n_total, int64_t fold0, int
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
+
+// cvm_sweep_all: cvm_sweep_fit and cvm_sweep_folds in one call.  With few folds (<= SWF_MAX) and
+// 16-byte aligned rows the finalize half is two launches that read every partial once
+// (sweep_stats_kernel, sweep_finish_kernel); otherwise the two calls' own kernels.  Same bits.
+template <typename T>
+int sweep_all_impl(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
+                   const int64_t *host_offsets, int64_t n_folds, int64_t N, int K, int M, int dtype, unsigned flags,
+                   double ddof, double resolution, void *G, void *H, double *gstats, int32_t *neg_flag,
+                   void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                   double *out_fold, void *ws, size_t ws_bytes, hipStream_t st, int64_t *splits_out) {
+  static const bool no_merge = getenv("CVM_NO_SWEEP_MERGE") != nullptr;     // tests: the separate kernels
+  const bool want_xtx = flags & CVM_RET_XTX, want_xty = flags & CVM_RET_XTY;
+  const bool merged = !no_merge && n_folds <= SWF_MAX && ((size_t)K * sizeof(T)) % 16 == 0 &&
+                      ((uintptr_t)G % 16 == 0) && (!want_xtx || (uintptr_t)out_XTX % 16 == 0);
+  if (!merged) {
+    int64_t token = 0;
+    int rc = sweep_fit_impl<T>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype, G, H, gstats, neg_flag,
+                               ws, ws_bytes, st, &token);
+    if (rc != CVM_OK) return rc;
+    if (splits_out) *splits_out = token;
+    return sweep_folds_impl<T>(offsets, n_folds, 0, n_folds, K, M, dtype, flags, ddof, resolution, w != nullptr, G, H,
+                               gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws,
+                               carve_queue(ws, ws_bytes).usable, token, st);
+  }
+  int64_t max_rows = 0;
+  for (int64_t f = 0; f < n_folds; ++f) {
+    const int64_t n = host_offsets[f + 1] - host_offsets[f];
+    if (n < 0) return fail(CVM_EINVAL, "cvm_sweep_all: offsets must be non-decreasing%s");
+    if (n > max_rows) max_rows = n;
+  }
+  if (host_offsets[n_folds] - host_offsets[0] != N)
+    return fail(CVM_EINVAL, "cvm_sweep_all: the folds must cover each of the N rows exactly once%s");
+  const WsCarve wq = carve_queue(ws, ws_bytes);
+  ws_bytes = wq.usable;
+  Plan p;
+  int rc = make_plan(n_folds, max_rows, K, M, dtype, CVM_RET_XTX | CVM_RET_XTY, ws_bytes, true, p);
+  if (rc != CVM_OK || p.folds_per_batch < n_folds)
+    return fail(CVM_EWORKSPACE, "cvm_sweep_all: the workspace must hold the partials of all folds%s");
+  WgramArgs<T> a;
+  memset(&a, 0, sizeof(a));
+  a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+  a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = 0;
+  set_items(a, p, n_folds);
+  a.ws = (char *)ws;
+  rc = launch_wgram<T>(a, w != nullptr, true, rows_aligned(X, K, sizeof(T)), st, KIND_FOLD, wq.queue);
+  if (rc != CVM_OK) return rc;
+  const size_t units = (size_t)n_folds * (size_t)p.splits * p.g.unit_bytes;
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = p.g; set_fin_splits(f, p, 1); f.n_seg = (int)n_folds; f.seg0 = 0; f.ws = (const char *)ws;
+  f.fstats = (double *)((char *)ws + units);
+  f.offs = offsets; f.w = w; f.G = G; f.H = H; f.gstats = gstats; f.neg_flag = neg_flag;
+  f.out_XTX = want_xtx ? out_XTX : nullptr;
+  f.out_XTY = want_xty ? out_XTY : nullptr;
+  f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
+  f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
+  hipLaunchKernelGGL((sweep_stats_kernel<T>), dim3((unsigned)((K + M + 15) / 16)), dim3(256), 0, st, f, gstats);
+  constexpr int C = 16 * (16 / (int)sizeof(T));
+  const unsigned xb = (unsigned)(((K + SWF_R - 1) / SWF_R) * ((K + C - 1) / C));
+  const unsigned hb = (Y && M > 0) ? (unsigned)(((size_t)K * M + 15) / 16) : 0u;
+  hipLaunchKernelGGL((sweep_finish_kernel<T>), dim3(xb + hb), dim3(256), 0, st, f, (T *)G, (T *)((Y && M > 0) ? H : nullptr));
+  HIP_OK(hipGetLastError());
+  if (splits_out) *splits_out = (int64_t)p.s_off | ((int64_t)p.s_diag << 20);
+  return CVM_OK;
+}
+

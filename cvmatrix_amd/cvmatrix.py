@@ -264,12 +264,13 @@ class CVMatrix:
         """Hook: the full-data matrices of this process have just been launched (multi-GPU
         subclasses exchange them here)."""
 
-    def _lazy_sweep(self, batch) -> None:
-        """First use after a lazy ``fit`` is a batched call: if its folds partition the rows,
-        form the full-data matrices as the sum of the folds' validation matrices."""
-        if not self.__dict__.get("_pending", False):
-            return
-        lib = _lib.load()
+    def _exchanges_globals(self) -> bool:
+        """Does ``_after_globals`` change the full-data matrices (a multi-GPU exchange)?  Then the
+        fold stage cannot share a call with the sweep that forms them."""
+        return False
+
+    def _sweep_worth(self, lib, batch) -> bool:
+        """Do the folds of ``batch`` partition the rows, and is the one-sweep path the faster one?"""
         sizes = batch.sizes
         # worth it when the folds are large: the sweep saves one pass of the Gram kernel over all
         # rows and costs a write + read of every fold's K x (K+M) partials (about 256 rows of
@@ -277,7 +278,15 @@ class CVMatrix:
         worth = (batch.n_folds > 0 and int(sizes.min()) > 32 and self.N >= 256 * batch.n_folds
                  and lib.cvm_sweep_workspace_bytes(batch.n_folds, int(sizes.max()), self.K, self.M or 0,
                                                    self._cdt) <= (4 << 30))
-        if worth and batch._n_rows == self.N and batch.is_partition:
+        return bool(worth and batch._n_rows == self.N and batch.is_partition)
+
+    def _lazy_sweep(self, batch) -> None:
+        """First use after a lazy ``fit`` is a batched call: if its folds partition the rows,
+        form the full-data matrices as the sum of the folds' validation matrices."""
+        if not self.__dict__.get("_pending", False):
+            return
+        lib = _lib.load()
+        if self._sweep_worth(lib, batch):
             self._pending = False
             with torch.cuda.device(self.device):
                 neg = torch.empty(1, dtype=torch.int32, device=self.device)
@@ -428,13 +437,16 @@ class CVMatrix:
             self._sweep_ws.data_ptr(), self._sweep_ws.numel(), self._stream(), C.byref(splits),
         )
         _lib.check(rc, "cvm_sweep_fit")
-        self._sweep = (batch, int(splits.value))
+        self._remember_sweep(batch, int(splits.value))
+
+    def _remember_sweep(self, batch, token: int) -> None:
+        self._sweep = (batch, token)
         self.sweep_folds = batch
         # the folds of a Partitioner can later be asked for one at a time with the very arrays it
         # holds (the reference's loop): remember them by identity + a cheap fingerprint
         src = batch._source
         self._sweep_ids = None
-        if src is not None and len(src._fold_arrays) == P:
+        if src is not None and len(src._fold_arrays) == batch.n_folds:
             arrs = src._fold_arrays
             self._sweep_ids = ({id(a): i for i, a in enumerate(arrs)}, [self._fingerprint(a) for a in arrs], arrs)
 
@@ -773,12 +785,15 @@ class CVMatrix:
             raise ValueError(MSG_NZ_DDOF)
 
     def _run(self, batch: FoldBatch, rXTX: bool, rXTY: bool, stat_flags=None,
-             stats_only: bool = False, sweep_fold: Optional[int] = None):
+             stats_only: bool = False, sweep_fold: Optional[int] = None, sweep_all: bool = False):
         """One cvm_fold_update call over ``batch``.  Returns raw stacked device tensors.
         ``stats_only``: keep the return flags (they select which statistics the kernel
-        derives, cvmatrix.py:828-831) but produce no matrices."""
+        derives, cvmatrix.py:828-831) but produce no matrices.  ``sweep_all``: a lazy fit is
+        pending and ``batch`` partitions the rows -- the fit and the fold stage as one call
+        (cvm_sweep_all)."""
         lib = _lib.load()
-        self._ensure_fit()
+        if not sweep_all:
+            self._ensure_fit()
         K, M, P = self.K, self.M or 0, (batch.n_folds if sweep_fold is None else 1)
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         if stat_flags is not None:
@@ -797,6 +812,30 @@ class CVMatrix:
             muY = stat[2 * P * K:2 * P * K + P * M].view(P, 1, M) if M else None
             sdY = stat[2 * P * K + P * M:].view(P, 1, M) if M else None
             out_fold = None       # (per-fold [sw_T, nz_T, sw_V, nz_V]: diagnostics, not requested)
+            if sweep_all:
+                import ctypes as C
+
+                want = lib.cvm_sweep_workspace_bytes(P, int(batch.sizes.max()), K, M, self._cdt)
+                if (getattr(self, "_sweep_ws", None) is None or self._sweep_ws.numel() < want
+                        or self._sweep_ws.device != dev):
+                    self._sweep_ws = torch.empty(int(want), dtype=torch.uint8, device=dev)
+                neg = torch.empty(1, dtype=torch.int32, device=dev)
+                token = C.c_int64(0)
+                self._pending = False
+                rc = lib.cvm_sweep_all(
+                    self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), batch.idx.data_ptr(),
+                    batch.offsets.data_ptr(), batch.host_offsets.ctypes.data, P, self.N, K, M, self._cdt,
+                    flags, float(self.ddof), float(self.resolution),
+                    self._G.data_ptr(), _lib.ptr(self._H), self._gs.data_ptr(), neg.data_ptr(),
+                    _lib.ptr(out_XTX), _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(),
+                    _lib.ptr(muY), _lib.ptr(sdY), _lib.ptr(out_fold),
+                    self._sweep_ws.data_ptr(), self._sweep_ws.numel(), self._stream(), C.byref(token),
+                )
+                _lib.check(rc, "cvm_sweep_all")
+                self._neg = neg
+                self._remember_sweep(batch, int(token.value))
+                self._after_globals()
+                return out_XTX, out_XTY, (muX, sdX, muY, sdY), out_fold
             sweep = getattr(self, "_sweep", None)
             if sweep is not None and sweep[0] is batch:
                 # the partials of exactly these folds are still in the sweep workspace
@@ -842,10 +881,15 @@ class CVMatrix:
         if rXTY and self.Y is None:
             raise ValueError(MSG_NO_Y)
         batch = self.prepare_folds(folds)
+        if (self.__dict__.get("_pending", False) and not self._exchanges_globals()
+                and self._sweep_worth(_lib.load(), batch)):
+            # a lazy fit is pending, the folds partition the rows and nothing is exchanged between
+            # the two halves (one process): the sweep and the fold stage in one call
+            return self._finish(batch, rXTX, rXTY, sweep_all=True)
         self._lazy_sweep(batch)
         return self._finish(batch, rXTX, rXTY)
 
-    def _finish(self, batch, rXTX: bool, rXTY: bool, sweep_fold: Optional[int] = None):
+    def _finish(self, batch, rXTX: bool, rXTY: bool, sweep_fold: Optional[int] = None, sweep_all: bool = False):
         """Validity checks + the fold-stage launch for ``batch`` (or for fold ``sweep_fold`` of the
         batch the sweep served)."""
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
@@ -860,7 +904,7 @@ class CVMatrix:
         late = self._totals_in_flight()
         if not late:
             self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
-        xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY, sweep_fold=sweep_fold)
+        xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY, sweep_fold=sweep_fold, sweep_all=sweep_all)
         if late:
             self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
         o = self._out

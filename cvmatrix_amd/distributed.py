@@ -178,6 +178,9 @@ class ShardedCVMatrix(CVMatrix):
         else:
             broadcast_globals(self._G, self._H, self._gs, self.src, self.group, flat=self._globals)
 
+    def _exchanges_globals(self) -> bool:
+        return self.world > 1
+
     def _totals_in_flight(self) -> bool:
         return bool(self._tail_pending)
 

@@ -124,8 +124,8 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
  * benchmark and README build them (benchmarks/benchmark.py:232, README.md:120-141) -- the
  * full-data matrices of cvm_gram_fit are the sum of the folds' validation matrices.
  *   cvm_sweep_fit    runs the Gram kernel once over all folds (rows gathered by idx), writes
- *                    G, H, gstats, neg_flag exactly like cvm_gram_fit (summation order: fold-
- *                    major) and leaves the per-fold partials in ws; *splits_out receives an
+ *                    G, H, gstats, neg_flag like cvm_gram_fit (as the sum over the folds of each
+ *                    fold's own sum over its row splits) and leaves the per-fold partials in ws; *splits_out receives an
  *                    opaque token (the row-split plan) to be handed back to cvm_sweep_folds
  *   cvm_sweep_folds  = the finalize half of cvm_fold_update on those partials (same outputs),
  *                    valid while ws is untouched; `weighted` = 1 if cvm_sweep_fit got w != NULL
@@ -141,6 +141,17 @@ int cvm_sweep_folds(const int64_t *offsets, int64_t n_folds, int K, int M, int d
                     const double *gstats, void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX,
                     void *out_muY, void *out_sdY, double *out_fold, void *ws, size_t ws_bytes,
                     int64_t splits, void *stream);
+
+/* cvm_sweep_fit followed by cvm_sweep_folds over all folds, as one call (same arguments, same
+ * results to the bit, the partials stay in ws for cvm_sweep_fold_range).  With at most 16 folds
+ * and 16-byte aligned rows the finalize half runs as two launches that read every partial once:
+ * a fold's update stays in registers while the full-data matrix is formed as the sum of the
+ * folds' updates. */
+int cvm_sweep_all(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
+                  const int64_t *host_offsets, int64_t n_folds, int64_t N, int K, int M, int dtype, unsigned flags,
+                  double ddof, double resolution, void *G, void *H, double *gstats, int32_t *neg_flag,
+                  void *out_XTX, void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                  double *out_fold, void *ws, size_t ws_bytes, void *stream, int64_t *splits_out);
 
 /* The same for folds [fold0, fold0 + n_folds) of the n_total folds of the sweep; outputs are written
  * from index 0.  Serves the reference's one-call-per-fold loop (README.md:120-141) from the sweep's

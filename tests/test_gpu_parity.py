@@ -1211,6 +1211,73 @@ def test_lazy_fit_one_sweep_equals_eager_and_oracle(amd, weighted, flags):
     assert torch_equal(a3, a4) and torch_equal(b3, b4) and torch_equal(a3, a)
 
 
+@pytest.mark.parametrize("dtype,N,K,M,P,weighted", [
+    (np.float64, 9000, 136, 6, 5, True), (np.float64, 9000, 260, 0, 3, False), (np.float64, 12000, 512, 16, 10, True),
+    (np.float64, 20000, 132, 40, 16, True), (np.float64, 20000, 132, 2, 17, True), (np.float64, 9000, 135, 3, 4, True),
+    (np.float32, 9000, 136, 5, 6, True), (np.float32, 9000, 516, 1, 4, False), (np.float32, 9000, 130, 3, 4, True)])
+def test_sweep_all_one_call_equals_the_two_calls(amd, dtype, N, K, M, P, weighted):
+    """cvm_sweep_all (a lazy fit followed by a batched call over a partition: the folds' updates
+    stay in registers while G is formed, two finalize launches) against cvm_sweep_fit +
+    cvm_sweep_folds (fit(folds=...), then the batched call): the same bits in the full-data
+    matrices, the column sums, every fold's matrices and statistics -- for aligned rows with up to
+    16 folds (the merged kernels) and beyond (17 folds, K * itemsize not a multiple of 16: the
+    separate kernels behind the same entry point); and against the oracle."""
+    rng = np.random.default_rng(N + K + P)
+    X = rng.random((N, K)).astype(dtype)
+    Y = rng.random((N, M)).astype(dtype) if M else None
+    w = rng.random(N).astype(dtype) if weighted else None
+    if weighted:
+        w[::13] = 0
+    part = amd.Partitioner(rng.integers(0, P, N))
+    for flags in ((True,) * 4, (False,) * 4, (True, False, False, True)):
+        one = amd.CVMatrix(*flags, dtype=dtype, lazy_fit=True)
+        two = amd.CVMatrix(*flags, dtype=dtype, lazy_fit=False)
+        one.fit(X, Y, w)
+        two.fit(X, Y, w, folds=part)
+        assert one._pending
+        if M:
+            (ax, ay), ast = one.training_XTX_XTY_batched(part)
+            (bx, by), bst = two.training_XTX_XTY_batched(two.sweep_folds)
+            assert torch_equal(ay, by)
+        else:
+            ax, ast = one.training_XTX_batched(part)
+            bx, bst = two.training_XTX_batched(two.sweep_folds)
+        assert not one._pending and one._sweep is not None
+        assert torch_equal(ax, bx)
+        assert torch_equal(one.XTX, two.XTX) and torch_equal(one._gstats, two._gstats)
+        if M:
+            assert torch_equal(one.XTY, two.XTY)
+        for s_, t_ in zip(ast, bst):
+            assert (s_ is None) == (t_ is None)
+            if s_ is not None:
+                assert torch_equal(s_, t_)
+        assert bool((ax[0] == ax[0].transpose(0, 1)).all())
+        # matrices of one kind only, from a fresh pending fit
+        one.fit(X, Y, w)
+        cx, _ = one.training_XTX_batched(part)
+        assert torch_equal(cx, ax)
+        if M:
+            one.fit(X, Y, w)
+            cy, _ = one.training_XTY_batched(part)
+            two.fit(X, Y, w, folds=part)
+            dy, _ = two.training_XTY_batched(two.sweep_folds)
+            assert torch_equal(cy, dy)
+        # single folds afterwards are served from the same partials
+        keys = list(part.folds_dict)
+        o = OracleCVMatrix(*flags, dtype=np.float64)
+        o.fit(X.astype(np.float64), None if Y is None else Y.astype(np.float64), None if w is None else w.astype(np.float64))
+        tol = TOL if dtype is np.float64 else 3e-4
+        for f in (0, P - 1):
+            v = part.get_validation_indices(keys[f])
+            if M:
+                (rx, ry), rst = o.training_XTX_XTY(v)
+                assert_normwise(ay[f].double(), ry, tol, "XTY")
+            else:
+                rx, rst = o.training_XTX(v)
+            assert_normwise(ax[f].double(), rx, tol, "XTX")
+        assert_normwise(one.XTX.double(), o.XTX, 1e-12 if dtype is np.float64 else 2e-5, "full-data XTX")
+
+
 def torch_equal(x, y):
     import torch
     return bool(torch.equal(x, y))
