@@ -18,6 +18,7 @@ There is no CPU path in this module: it raises if the extension or a GPU is miss
 from __future__ import annotations
 
 import os
+import weakref
 
 from typing import Iterable, Optional, Sequence, Tuple, Union
 
@@ -182,6 +183,8 @@ class CVMatrix:
         self._stage_bufs = None
         self._ws = None
         self._sweep = None
+        self._sweep_cache = None
+        self._pbatches = weakref.WeakKeyDictionary()   # Partitioner -> (FoldBatch, fingerprints)
         self._sweep_ws = None
         self._sweep_ids = None
         self._auto_sweep_tried = None
@@ -358,6 +361,7 @@ class CVMatrix:
         self.device = self._pick_device()
         # nothing of an earlier fit may survive a fit that raises half-way
         self._sweep = None
+        self._sweep_cache = None
         self._sweep_ids = None
         self._auto_sweep_tried = None
         self._pending = False
@@ -441,6 +445,7 @@ class CVMatrix:
 
     def _remember_sweep(self, batch, token: int) -> None:
         self._sweep = (batch, token)
+        self._sweep_cache = None
         self.sweep_folds = batch
         # the folds of a Partitioner can later be asked for one at a time with the very arrays it
         # holds (the reference's loop): remember them by identity + a cheap fingerprint
@@ -588,6 +593,9 @@ class CVMatrix:
         labels = None
         source = None
         if isinstance(folds, Partitioner):
+            cached = self._cached_partitioner_batch(folds)
+            if cached is not None:
+                return self.prepare_folds(cached)      # (row count / weights checks of a FoldBatch)
             source = folds
             labels = list(folds.folds_dict)
             folds = list(folds.folds_dict.values())
@@ -640,6 +648,23 @@ class CVMatrix:
         d_off, d_idx = d_all[:n_off], d_all[n_off:]
         fb = FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N, w_gen=self._w_gen)
         fb._source = source
+        fb._device = self.device
+        if source is not None and len(parts) <= 4096:
+            # the same Partitioner again (a fit + per-fold loop repeated, another model on the same
+            # folds): the uploaded indices are reused while its arrays still hold what they held
+            self._pbatches[source] = (fb, [self._fingerprint(a) for a in source._fold_arrays])
+        return fb
+
+    def _cached_partitioner_batch(self, p) -> Optional[FoldBatch]:
+        ent = self._pbatches.get(p)
+        if ent is None:
+            return None
+        fb, prints = ent
+        arrs = p._fold_arrays
+        if (fb._n_rows != self.N or fb._device != self.device or len(arrs) != len(prints)
+                or any(self._fingerprint(a) != q for a, q in zip(arrs, prints))):
+            del self._pbatches[p]
+            return None
         return fb
 
     def _nz_counts_host(self, idx: np.ndarray, host_offsets: np.ndarray, sizes: np.ndarray) -> np.ndarray:
@@ -938,7 +963,7 @@ class CVMatrix:
             mats = mats[0]
         return mats, tuple(None if s is None else s[0] for s in stats)
 
-    def _sweep_fold_of(self, v) -> Optional[int]:
+    def _sweep_fold_of(self, v, rXTX: bool = True, rXTY: bool = True) -> Optional[int]:
         """Is ``v`` -- handed to a one-fold call -- the very index array a ``Partitioner`` holds
         for one of the folds a sweep has served (or can serve: a lazy fit is pending and the
         Partitioner's folds partition the rows)?  Then its number in that sweep, else None.
@@ -952,7 +977,20 @@ class CVMatrix:
             if p is not None and p is not self._auto_sweep_tried:
                 self._auto_sweep_tried = p          # (one attempt per fit and Partitioner)
                 batch = self.prepare_folds(p)
-                self._lazy_sweep(batch)             # sweeps if the folds partition the rows and are large
+                lib = _lib.load()
+                K, M = self.K, self.M or 0
+                if (not self._exchanges_globals() and batch.n_folds <= 16 and self._sweep_worth(lib, batch)
+                        and (rXTY is False or self.Y is not None)
+                        and batch.n_folds * K * (K + M) * self.X.element_size() <= (1 << 30)):
+                    # one process, few folds: the sweep and EVERY fold's matrices in one call
+                    # (cvm_sweep_all); the loop's calls are then handed their fold's slices, each
+                    # once (a second request for a fold recomputes it: the caller may have changed
+                    # its matrices in place).  The data-dependent raises stay per call.
+                    xtx, xty, st, _ = self._run(batch, rXTX, rXTY, sweep_all=True)
+                    self._sweep_cache = {"key": (rXTX, rXTY), "xtx": xtx, "xty": xty, "stats": st,
+                                         "left": set(range(batch.n_folds))}
+                else:
+                    self._lazy_sweep(batch)         # sweeps if the folds partition the rows and are large
         ids = self._sweep_ids
         if ids is None or self._sweep is None:
             return None
@@ -983,7 +1021,7 @@ class CVMatrix:
             if (type(v) is np.ndarray and v.ndim == 1 and 0 < v.size <= 32 and v.dtype == np.int64
                     and v.flags.c_contiguous):
                 return self._one_small_fold(v, return_XTX, return_XTY)
-            i = self._sweep_fold_of(v)
+            i = self._sweep_fold_of(v, return_XTX, return_XTY)
             if i is not None:
                 return self._finish_sweep_fold(i, return_XTX, return_XTY)
         return self._first(
@@ -1080,6 +1118,19 @@ class CVMatrix:
         r_sdX = sX
         r_sdY = rXTY and sY
         self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=i)
+        cache = self._sweep_cache
+        if cache is not None and cache["key"] == (rXTX, rXTY) and i in cache["left"]:
+            cache["left"].discard(i)
+            xtx, xty = cache["xtx"], cache["xty"]
+            muX, sdX, muY, sdY = cache["stats"]
+            if not cache["left"]:
+                self._sweep_cache = None
+            o = self._out
+            stats = (o(muX[i]) if r_muX else None, o(sdX[i]) if r_sdX else None,
+                     o(muY[i]) if r_muY else None, o(sdY[i]) if r_sdY else None)
+            if rXTX and rXTY:
+                return (o(xtx[i]), o(xty[i])), stats
+            return (o(xtx[i]) if rXTX else o(xty[i])), stats
         flags = ((_lib.RET_XTX if rXTX else 0) | (_lib.RET_XTY if rXTY else 0)
                  | (_lib.CENTER_X if cX else 0) | (_lib.CENTER_Y if cY else 0)
                  | (_lib.SCALE_X if sX else 0) | (_lib.SCALE_Y if sY else 0))

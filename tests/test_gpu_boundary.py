@@ -195,7 +195,9 @@ def test_reference_loop_is_served_from_one_sweep(amd, hip_device):
         assert_normwise(xty, by[i].cpu().numpy(), 1e-11, "loop XTY")
         for a, b in zip(st, bst):
             np.testing.assert_allclose(a.cpu().numpy(), b[i].cpu().numpy(), rtol=1e-11)
-    # bits of the batched sweep path
+        xtx.zero_(); xty.zero_()                     # the caller owns what it was handed ...
+    assert m._sweep_cache is None                    # (every fold's slice was handed out once)
+    # ... a second request for a fold is computed again: bits of the batched sweep path
     m2 = amd.CVMatrix()
     m2.fit(X, Y, w)
     (sx, sy), sst = m2.training_XTX_XTY_batched(p)
