@@ -18,6 +18,7 @@ constexpr int TARGET_WG_1 = 256;  // resident workgroups (both Gram kernels: one
 constexpr int TARGET_WG_2 = 256;
 constexpr int QUEUE_STRIDE = 32;       // unsigneds between the 8 queue heads (one 128-byte line each)
 constexpr size_t QUEUE_BYTES = 8 * QUEUE_STRIDE * sizeof(unsigned);
+constexpr int QUEUE_DONE = 8;          // index of the exit counter (in the first head's line)
 // LDS bank note.  MFMA 16x16x4 operand reads: lane l reads row k0+(l>>4), column c0+(l&15).
 // f64 / ds_read_b64 (64 banks of 4 B): lanes 0-15 cover 128 B = 32 banks; lanes 16-31 read
 // the next row, so the pitch must be = 128 B mod 256 B: 144*8 = 1152 = 4*256+128.  f32 /
@@ -98,8 +99,8 @@ template <typename T> struct WgramArgs {
   Geom g;
   long n_items0, ipx0;  // class 0: items, items per XCD
   long n_items1, ipx1;  // class 1
-  unsigned *queue;      // wgram4_kernel: 8 work-queue heads (one per XCD, QUEUE_STRIDE apart), zeroed
-                        // before the launch
+  unsigned *queue;      // wgram4_kernel: 8 work-queue heads (one per XCD, QUEUE_STRIDE apart) and the exit
+                        // counter, all zero at launch; the last workgroup to leave zeroes them again
   char *ws;             // unit u at ws + u*unit_bytes
   // fused single-split fold update (wgram4_kernel<.., FUSED>): finish in the epilogue
   const double *fstats; // per fold of the batch: means / stds / sw_train (fold_stats_kernel)

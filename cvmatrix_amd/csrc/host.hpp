@@ -272,8 +272,8 @@ template <typename T> bool wgram4_ok(const WgramArgs<T> &a, bool aligned) {
   return ((uintptr_t)a.Y % 4 == 0) && ((uintptr_t)a.w % 4 == 0);   // float32: Y and w by dwords
 }
 
-// The persistent LDS-DMA kernel pulls its work items from 8 queue heads in device memory: they
-// live in the last QUEUE_BYTES of the caller's workspace (128-byte aligned) and are zeroed on the
+// (Earlier versions kept the queue heads in the last QUEUE_BYTES of the caller's workspace: the
+// reserve is still carved out so that workspace sizes do not change.)  They were zeroed on the
 // stream before every launch.
 struct WsCarve { size_t usable; unsigned *queue; };
 WsCarve carve_queue(void *ws, size_t ws_bytes) {
@@ -283,7 +283,35 @@ WsCarve carve_queue(void *ws, size_t ws_bytes) {
 }
 constexpr size_t QUEUE_RESERVE = QUEUE_BYTES + 256;   // what the workspace-size functions add for it
 
-__global__ void queue_zero_kernel(unsigned *q) { q[threadIdx.x] = 0u; }
+// Work-queue blocks of the persistent Gram kernel (8 heads + an exit counter, QUEUE_BYTES each):
+// a pool per device, allocated and zeroed once; a launch takes the next block round-robin and its
+// last workgroup leaves it zeroed.  (The heads used to live in the caller's workspace and were
+// zeroed on the stream before every launch: a 5 us kernel in front of every Gram launch.)
+// QUEUE_POOL blocks: more than launches can be in flight on one device at a time.
+constexpr unsigned QUEUE_POOL = 1024;
+unsigned *acquire_queue(int dev) {
+  static std::mutex mu;
+  static unsigned *pool[64];
+  static std::atomic<unsigned> next[64];
+  const int d = dev & 63;
+  unsigned *p = __atomic_load_n(&pool[d], __ATOMIC_ACQUIRE);
+  if (!p) {
+    std::lock_guard<std::mutex> lock(mu);
+    p = pool[d];
+    if (!p) {
+      void *mem = nullptr;
+      if (hipMalloc(&mem, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess) return nullptr;
+      if (hipMemset(mem, 0, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(mem);
+        return nullptr;
+      }
+      p = (unsigned *)mem;
+      __atomic_store_n(&pool[d], p, __ATOMIC_RELEASE);
+    }
+  }
+  const unsigned b = next[d].fetch_add(1u, std::memory_order_relaxed) % QUEUE_POOL;
+  return p + (size_t)b * (QUEUE_BYTES / sizeof(unsigned));
+}
 
 int device_cu_count(int dev) {
   static std::atomic<int> cus[64];
@@ -342,9 +370,9 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   if (fused && !(fast && gather && sizeof(T) == 8))
     return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
   if (fast) {
-    if (!queue) return fail(CVM_EWORKSPACE, "launch_wgram: no room for the work-queue heads in the workspace%s");
-    // (a one-workgroup kernel: the runtime's fill kernel takes 5.6 us for these 1 KiB)
-    hipLaunchKernelGGL(queue_zero_kernel, dim3(1), dim3(QUEUE_BYTES / 4), 0, st, queue);
+    (void)queue;
+    args.queue = acquire_queue(dev);
+    if (!args.queue) return fail(CVM_ELAUNCH, "launch_wgram: cannot allocate the work-queue pool%s");
     // persistent workgroups: one per CU (fewer when the lists are shorter than that)
     long wgs = 8 * (a.ipx0 + a.ipx1);
     const long cus = device_cu_count(dev);

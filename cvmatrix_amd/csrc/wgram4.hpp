@@ -969,6 +969,17 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     }
     __syncthreads();                             // the item is finished with the LDS ring; s_next is visible
   }
+  // the queue block is the library's (host.hpp: queue pool) and must be all zero again for its
+  // next launch: the last workgroup to leave -- every other one has made its last fetch -- clears it
+  if (threadIdx.x == 0) {
+    const unsigned left = __hip_atomic_fetch_add(a.queue + QUEUE_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+        __hip_atomic_store(a.queue + x * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.queue + QUEUE_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 #ifdef CVM_STAMPS
   {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();

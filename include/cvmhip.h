@@ -27,8 +27,10 @@
  *   - results are deterministic: no floating-point atomics, fixed-order reductions;
  *   - threads: every entry point may be called concurrently from several host threads (one
  *     per stream / device is the intended use).  The library's only process-wide state is the
- *     optional launch-timing recorder below (mutex-guarded) and once-per-device kernel
- *     attributes (atomic flags); planning depends on the arguments alone.
+ *     optional launch-timing recorder below (mutex-guarded), once-per-device kernel
+ *     attributes (atomic flags) and one 1 MiB device allocation per device, made on first use
+ *     and kept (work-queue blocks of the persistent Gram kernel, handed out by an atomic
+ *     counter); planning depends on the arguments alone.
  */
 #ifndef CVMHIP_H
 #define CVMHIP_H
