@@ -6,6 +6,9 @@ Tolerance: fp64 norm-wise 1e-10 (max|d| <= 1e-10 max|ref
 Frobenius), statistics element-wise rtol 1e-10.  fp32: compared with the fp64 reference;
 error must not exceed 2x the reference's own float32 error (stored with the digests)."""
 
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -75,6 +78,9 @@ def test_g3_leave_one_out_sweep(amd, chunk):
     for name in cases[chunk::8]:
         pc.run_g3loo_case(name, make_factory(amd), TOL)
         pc.run_g3loo_case(name, make_factory(amd), TOL, batched=True)
+
+
+FP32_FLOOR = 2e-5   # a few hundred float32 roundings of the scale: sums of thousands of rows
 
 
 def assert_fp32_like_reference(got, ref64, ref32, what, floor=2e-6):
@@ -1133,7 +1139,8 @@ def test_float32_shape_sweep(amd, K, M, route):
     """float32: K a multiple of 4 takes the LDS-DMA kernel (any M: the Y tile rows go by
     dwords), other K the general kernel (the last case); a few large folds and many mid-size
     folds; against the float64 oracle on the float32-rounded inputs, error bounded by a small
-    multiple of float32 rounding of the sums involved."""
+    multiple of float32 rounding of the sums involved: at most twice the error of the reference's
+    algorithm in NumPy float32 on the same inputs plus FP32_FLOOR."""
     rng = np.random.default_rng(500 + K + M)
     N = 9000
     X = (rng.random((N, K)) + 0.1).astype(np.float32)
@@ -1148,9 +1155,11 @@ def test_float32_shape_sweep(amd, K, M, route):
     for flags in [(True,) * 4, (False,) * 4]:
         m = amd.CVMatrix(*flags, dtype=np.float32)
         o = OracleCVMatrix(*flags, dtype=np.float64)
+        o32 = OracleCVMatrix(*flags, dtype=np.float32)      # the reference's own float32 arithmetic
         m.fit(X, Y, w)
         o.fit(X.astype(np.float64), None if Y is None else Y.astype(np.float64), w.astype(np.float64))
-        assert_normwise(m.XTX.double(), o.XTX, 2e-5, "fit XTX")
+        o32.fit(X, Y, w)
+        assert_fp32_like_reference(m.XTX, o.XTX, o32.XTX, "fit XTX", floor=FP32_FLOOR)
         if M:
             (bx, by), bst = m.training_XTX_XTY_batched(folds)
         else:
@@ -1158,10 +1167,12 @@ def test_float32_shape_sweep(amd, K, M, route):
         for f in (0, len(folds) - 1):
             if M:
                 (rx, ry), rst = o.training_XTX_XTY(folds[f])
-                assert_normwise(by[f].double(), ry, 3e-4 if flags[0] else 2e-5, f"fold{f} XTY")
+                (sx, sy), _ = o32.training_XTX_XTY(folds[f])
+                assert_fp32_like_reference(by[f], ry, sy, f"fold{f} XTY", floor=FP32_FLOOR)
             else:
                 rx, rst = o.training_XTX(folds[f])
-            assert_normwise(bx[f].double(), rx, 3e-4 if flags[0] else 2e-5, f"fold{f} XTX")
+                sx, _ = o32.training_XTX(folds[f])
+            assert_fp32_like_reference(bx[f], rx, sx, f"fold{f} XTX", floor=FP32_FLOOR)
             for a_, b_ in zip(bst, rst):
                 assert (a_ is None) == (b_ is None)
                 if b_ is not None:
@@ -1278,6 +1289,21 @@ def test_sweep_all_one_call_equals_the_two_calls(amd, dtype, N, K, M, P, weighte
         assert_normwise(one.XTX.double(), o.XTX, 1e-12 if dtype is np.float64 else 2e-5, "full-data XTX")
 
 
+@pytest.mark.parametrize("plan", ["7,2", "3,5", "1,4", "2,1"])
+def test_forced_split_plans(plan):
+    """The two classes of work items (off-diagonal / diagonal tiles) under row-split plans the
+    planner would not pick for these shapes, both orders of s_off and s_diag: two-stage path, sweep
+    and one-fold calls against the oracle at 1e-10 (tests/forced_plan_check.py in a subprocess --
+    the library reads CVM_FORCE_SPLITS once)."""
+    import subprocess
+
+    env = dict(os.environ, CVM_FORCE_SPLITS=plan)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "forced_plan_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "worst norm-wise error" in r.stdout
+
+
 def torch_equal(x, y):
     import torch
     return bool(torch.equal(x, y))
@@ -1376,17 +1402,25 @@ def test_leave_one_out_rows_kernel(amd, dtype, K):
     w = rng.random(N).astype(dtype)
     w[::11] = 0
     folds = [np.array([i]) for i in range(40)] + [np.array([100 + 2 * i, 101 + 2 * i]) for i in range(20)]
-    tol = TOL if dtype is np.float64 else 3e-4
+    f32 = dtype is np.float32
     for flags, ww in (((True,) * 4, w), ((False,) * 4, None), ((True, False, True, False), w)):
         m = amd.CVMatrix(*flags, dtype=dtype)
         m.fit(X, Y, ww)
         (bx, by), bst = m.training_XTX_XTY_batched(folds)
         o = OracleCVMatrix(*flags, dtype=np.float64)
         o.fit(X.astype(np.float64), Y.astype(np.float64), None if ww is None else ww.astype(np.float64))
+        if f32:
+            o32 = OracleCVMatrix(*flags, dtype=np.float32)      # the reference's own float32 arithmetic
+            o32.fit(X, Y, ww)
         for f in (0, 13, 39, 40, 59):
             (rx, ry), rst = o.training_XTX_XTY(folds[f])
-            assert_normwise(bx[f].double(), rx, tol, f"fold{f} XTX")
-            assert_normwise(by[f].double(), ry, tol, f"fold{f} XTY")
+            if f32:
+                (sx, sy), _ = o32.training_XTX_XTY(folds[f])
+                assert_fp32_like_reference(bx[f], rx, sx, f"fold{f} XTX", floor=FP32_FLOOR)
+                assert_fp32_like_reference(by[f], ry, sy, f"fold{f} XTY", floor=FP32_FLOOR)
+            else:
+                assert_normwise(bx[f].double(), rx, TOL, f"fold{f} XTX")
+                assert_normwise(by[f].double(), ry, TOL, f"fold{f} XTY")
             assert bool((bx[f] == bx[f].T).all())
         bx1 = m.training_XTX_batched(folds)[0]
         assert bool((bx1 == bx).all())
