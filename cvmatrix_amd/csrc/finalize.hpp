@@ -341,68 +341,89 @@ __device__ __forceinline__ void finish_tile_preload(T (&gpre)[NQ][16 / sizeof(T)
   }
 }
 
-// The same finishing step for ONE WAVE inside wgram4_kernel<.., FUSED> (float64, K even): the raw
-// update of a 64x64 block is in Ts, the row/column means and stds in rs[0..255].  A wave has no
-// other wave to hide its latency behind, so the G loads go out eight rows at a time.
-// Direct half: rows 2*it + (lane >> 5) for it in [it_lo, it_hi) of the 64-row block (it_hi - it_lo a
-// multiple of 8).  Finished values are parked in Ts for the mirrored store (off the diagonal).
-template <int TP>
-__device__ __forceinline__ void fused_finish_direct(double (*Ts)[TP], const double *rs, bool diagb, int a0,
-                                                    int b0, int K, const double *Gt, double *out,
-                                                    double swt, bool cX, bool sX, int lane, int it_lo, int it_hi) {
-  typedef double v2 __attribute__((ext_vector_type(2)));
-  const int half = lane >> 5, lc = 2 * (lane & 31);
+// The same finishing step for ONE WAVE inside wgram4_kernel<.., FUSED> (rows of K elements 16-byte
+// aligned): the raw update of a 64x64 block is in Ts (in the accumulators' type), the row/column
+// means and reciprocal stds in rs[0..255].  A wave has no other wave to hide its latency behind, so
+// the G loads go out sixteen rows at a time.  A lane owns 16 bytes of a row (VW = 2 float64 /
+// 4 float32 columns), the wave covers VW rows per instruction.
+// Direct half: rows [row_lo, row_hi) of the 64-row block (multiples of 16).  Finished values are
+// parked in Ts for the mirrored store (off the diagonal).
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_direct(T (*Ts)[TP], const double *rs, bool diagb, int a0,
+                                                    int b0, int K, const T *Gt, T *out,
+                                                    double swt, bool cX, bool sX, int lane, int row_lo, int row_hi) {
+  constexpr int VW = 16 / (int)sizeof(T);          // columns per lane
+  constexpr int LPR = 64 / VW;                     // lanes per row
+  constexpr int JB = 16 / VW;                      // wave instructions per 16 rows
+  typedef T vt __attribute__((ext_vector_type(VW)));
+  const int sub = lane / LPR, lc = VW * (lane - sub * LPR);
   const int gc = b0 + lc;
-  const bool col_ok = gc < K;                      // K is even: gc + 1 < K too
-  const double muc0 = rs[128 + lc], muc1 = rs[128 + lc + 1];
-  const double sdc0 = rs[192 + lc], sdc1 = rs[192 + lc + 1];
-#pragma unroll 1
-  for (int it0 = it_lo; it0 < it_hi; it0 += 8) {
-    v2 gv[8];
+  const bool col_ok = gc < K;                      // K is a multiple of VW: the whole piece is inside
+  double muc[VW], sdc[VW];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int lr = 2 * (it0 + j) + half, gr = a0 + lr;
-      gv[j] = (col_ok && gr < K) ? *reinterpret_cast<const v2 *>(Gt + (size_t)gr * K + gc) : (v2){0, 0};
+  for (int e = 0; e < VW; ++e) { muc[e] = rs[128 + lc + e]; sdc[e] = rs[192 + lc + e]; }
+#pragma unroll 1
+  for (int r0 = row_lo; r0 < row_hi; r0 += 16) {
+    vt gv[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int lr = r0 + VW * j + sub, gr = a0 + lr;
+      vt z;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) z[e] = (T)0;
+      gv[j] = (col_ok && gr < K) ? *reinterpret_cast<const vt *>(Gt + (size_t)gr * K + gc) : z;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int lr = 2 * (it0 + j) + half, gr = a0 + lr;
+    for (int j = 0; j < JB; ++j) {
+      const int lr = r0 + VW * j + sub, gr = a0 + lr;
       if (!(col_ok && gr < K)) continue;
       const double mur = rs[lr], sdr = rs[64 + lr];
-      const double u0 = (diagb && lr > lc) ? Ts[lc][lr] : Ts[lr][lc];
-      const double u1 = (diagb && lr > lc + 1) ? Ts[lc + 1][lr] : Ts[lr][lc + 1];
-      double v0 = gv[j][0] - u0, v1 = gv[j][1] - u1;
-      if (cX) { v0 -= swt * (mur * muc0); v1 -= swt * (mur * muc1); }
-      if (sX) { v0 = v0 * (sdr * sdc0); v1 = v1 * (sdr * sdc1); }
-      out_store(reinterpret_cast<v2 *>(out + (size_t)gr * K + gc), (v2){v0, v1});
-      if (!diagb) { Ts[lr][lc] = v0; Ts[lr][lc + 1] = v1; }   // parked for the mirrored store
+      vt vv;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        const double u = (double)((diagb && lr > lc + e) ? Ts[lc + e][lr] : Ts[lr][lc + e]);
+        double v = (double)gv[j][e] - u;
+        if (cX) v -= swt * (mur * muc[e]);
+        if (sX) v = v * (sdr * sdc[e]);
+        vv[e] = (T)v;
+      }
+      out_store(reinterpret_cast<vt *>(out + (size_t)gr * K + gc), vv);
+      if (!diagb) {                                // parked for the mirrored store
+#pragma unroll
+        for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = vv[e];
+      }
     }
   }
 }
-// Mirrored half: rows b0 + 2*it + (lane >> 5), columns a0..; out[b0 + r][a0 + c] = finished[c][r]
-template <int TP>
-__device__ __forceinline__ void fused_finish_mirror(double (*Ts)[TP], int a0, int b0, int K, double *out, int lane,
-                                                    int it_lo, int it_hi) {
-  typedef double v2 __attribute__((ext_vector_type(2)));
-  const int half = lane >> 5, lc = 2 * (lane & 31);
+// Mirrored half: rows b0 + r for r in [row_lo, row_hi), columns a0..; out[b0 + r][a0 + c] = finished[c][r]
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_mirror(T (*Ts)[TP], int a0, int b0, int K, T *out, int lane,
+                                                    int row_lo, int row_hi) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int LPR = 64 / VW;
+  typedef T vt __attribute__((ext_vector_type(VW)));
+  const int sub = lane / LPR, lc = VW * (lane - sub * LPR);
   const int gc2 = a0 + lc;
   if (gc2 >= K) return;
 #pragma unroll 4
-  for (int it = it_lo; it < it_hi; ++it) {
-    const int lr = 2 * it + half, gr = b0 + lr;
+  for (int r = row_lo; r < row_hi; r += VW) {
+    const int lr = r + sub, gr = b0 + lr;
     if (gr >= K) continue;
-    out_store(reinterpret_cast<v2 *>(out + (size_t)gr * K + gc2), (v2){Ts[lc][lr], Ts[lc + 1][lr]});
+    vt vv;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) vv[e] = Ts[lc + e][lr];
+    out_store(reinterpret_cast<vt *>(out + (size_t)gr * K + gc2), vv);
   }
 }
-template <int TP>
-__device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const double *rs, bool diagb, int a0,
-                                                   int b0, int K, const double *Gt, double *out,
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_block(T (*Ts)[TP], const double *rs, bool diagb, int a0,
+                                                   int b0, int K, const T *Gt, T *out,
                                                    double swt, bool cX, bool sX, int lane) {
-  fused_finish_direct<TP>(Ts, rs, diagb, a0, b0, K, Gt, out, swt, cX, sX, lane, 0, 32);
+  fused_finish_direct<T, TP>(Ts, rs, diagb, a0, b0, K, Gt, out, swt, cX, sX, lane, 0, 64);
   if (diagb) return;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  fused_finish_mirror<TP>(Ts, a0, b0, K, out, lane, 0, 32);
+  fused_finish_mirror<T, TP>(Ts, a0, b0, K, out, lane, 0, 64);
 }
 
 // One 64x64 sub-tile of a 128x128 upper tile (or one 128 x M panel of H) of one segment:

@@ -367,8 +367,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   }
   if (tl) HIP_OK(hipEventRecord(tl->a, st));
   const bool fast = wgram4_ok<T>(a, aligned) && !(dbg_env & 16);
-  if (fused && !(fast && gather && sizeof(T) == 8))
-    return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the float64 fast path%s");
+  if (fused && !(fast && gather))
+    return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the LDS-DMA kernel%s");
   if (fast) {
     (void)queue;
     args.queue = acquire_queue(dev);
@@ -379,7 +379,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     if (wgs > cus) wgs = cus;
     const dim3 grid((unsigned)wgs);
     const dim3 block4(NT4);
-    const size_t lds4 = lds4_bytes<T>();
+    // (the fused epilogue reuses the stage ring for its tiles: a little more than the ring in float32)
+    const size_t lds4 = fused && fused_lds_bytes<T>() > lds4_bytes<T>() ? fused_lds_bytes<T>() : lds4_bytes<T>();
 #define CVM_LAUNCH4(W, GA, FU)                                                              \
   do {                                                                                      \
     static std::atomic<unsigned long long> attr_done{0};                                    \
@@ -391,9 +392,7 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     hipLaunchKernelGGL((wgram4_kernel<T, W, GA, FU>), grid, block4, lds4, st, args);        \
   } while (0)
     if (fused) {
-      if constexpr (sizeof(T) == 8) {
-        if (weighted) CVM_LAUNCH4(true, true, true); else CVM_LAUNCH4(false, true, true);
-      }
+      if (weighted) CVM_LAUNCH4(true, true, true); else CVM_LAUNCH4(false, true, true);
     } else if (weighted) { if (gather) CVM_LAUNCH4(true, true, false); else CVM_LAUNCH4(true, false, false); }
     else { if (gather) CVM_LAUNCH4(false, true, false); else CVM_LAUNCH4(false, false, false); }
 #undef CVM_LAUNCH4
@@ -616,7 +615,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     WgramArgs<T> probe;
     memset(&probe, 0, sizeof(probe));
     probe.Y = (const T *)Y; probe.w = (const T *)w; probe.g = p.g;
-    if (sizeof(T) == 8 && p.splits == 1 && want_xtx && !no_fused && wgram4_ok<T>(probe, aligned)) {
+    if (p.splits == 1 && want_xtx && !no_fused && wgram4_ok<T>(probe, aligned)) {
       Geom gs = make_geom(K, M, sizeof(T), 1);
       gs.tile_elems = 0; gs.h_elems = 0;
       gs.unit_bytes = align_up(gs.stat_len * 8, 256);

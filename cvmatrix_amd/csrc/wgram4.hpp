@@ -40,40 +40,50 @@ template <typename T> constexpr size_t lds4_bytes() { return (size_t)NBUF4 * BUF
 //   ROLER 0/1/2: compute wave without sums / with X column sums / with Y column sums
 //   ROLER 3: loader wave
 __host__ __device__ inline size_t fstat_len(int K, int M);
-template <int TP>
-__device__ __forceinline__ void fused_finish_block(double (*Ts)[TP], const double *rs, bool diagb, int a0,
-                                                   int b0, int K, const double *Gt, double *out,
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_block(T (*Ts)[TP], const double *rs, bool diagb, int a0,
+                                                   int b0, int K, const T *Gt, T *out,
                                                    double swt, bool cX, bool sX, int lane);
-template <int TP>
-__device__ __forceinline__ void fused_finish_direct(double (*Ts)[TP], const double *rs, bool diagb, int a0,
-                                                    int b0, int K, const double *Gt, double *out,
-                                                    double swt, bool cX, bool sX, int lane, int it_lo, int it_hi);
-template <int TP>
-__device__ __forceinline__ void fused_finish_mirror(double (*Ts)[TP], int a0, int b0, int K, double *out, int lane,
-                                                    int it_lo, int it_hi);
-constexpr int WAVE_LDS_DOUBLES = 64 * 65 + 256;   // a wave's 64x64 block + row/column means and stds
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_direct(T (*Ts)[TP], const double *rs, bool diagb, int a0,
+                                                    int b0, int K, const T *Gt, T *out,
+                                                    double swt, bool cX, bool sX, int lane, int row_lo, int row_hi);
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_mirror(T (*Ts)[TP], int a0, int b0, int K, T *out, int lane,
+                                                    int row_lo, int row_hi);
+// LDS of the fused epilogue (it reuses the stage ring): per compute wave a 64x64 block in the
+// accumulators' type (pitch 65) + 256 float64 row/column means and reciprocal stds; a diagonal
+// tile: one 128x128 image (pitch 129) + three such statistics blocks
+template <typename T> constexpr size_t wave_tile_bytes() { return ((size_t)64 * 65 * sizeof(T) + 7) / 8 * 8; }
+template <typename T> constexpr size_t wave_lds_bytes() { return wave_tile_bytes<T>() + 256 * 8; }
+template <typename T> constexpr size_t diag_tile_bytes() { return ((size_t)TILE * (TILE + 1) * sizeof(T) + 7) / 8 * 8; }
+template <typename T> constexpr size_t fused_lds_bytes() {
+  return 4 * wave_lds_bytes<T>() > diag_tile_bytes<T>() + 3 * 256 * 8 ? 4 * wave_lds_bytes<T>()
+                                                                     : diag_tile_bytes<T>() + 3 * 256 * 8;
+}
 
 // Fused epilogue of a DIAGONAL 128x128 tile, shared by all eight waves of the workgroup (the four
 // loader waves are idle by then): the tile's raw update is in Td (LDS), the statistics of block b in
 // rs_b = rs0 + 256 b.  Blocks: 0 = (0,0) and 2 = (1,1) on the diagonal, 1 = (0,1) off it (stored
-// mirrored too).  Phase 0: twelve units of eight row pairs (block u / 4, rows 16 (u % 4) ..), wave v
+// mirrored too).  Phase 0: twelve units of sixteen rows (block u / 4, rows 16 (u % 4) ..), wave v
 // takes units v and v + 8; phase 1 (after a barrier): the mirrored store of block 1, waves 0..3.
-template <int TP>
-__device__ __forceinline__ void diag_tile_finish(double (*Td)[TP], double *rs0, int v, int phase, int ti, int K,
-                                                 const double *Gt, double *out, double swt, bool cX, bool sX,
+// (a unit = sixteen rows)
+template <typename T, int TP>
+__device__ __forceinline__ void diag_tile_finish(T (*Td)[TP], double *rs0, int v, int phase, int ti, int K,
+                                                 const T *Gt, T *out, double swt, bool cX, bool sX,
                                                  int lane) {
   if (phase == 0) {
     for (int u = v; u < 12; u += 8) {
       const int b = u >> 2, si = b == 2, sj = b >= 1;
       const int a0 = ti * TILE + 64 * si, b0 = ti * TILE + 64 * sj;
       if (a0 >= K || b0 >= K) continue;
-      fused_finish_direct<TP>(reinterpret_cast<double (*)[TP]>(&Td[64 * si][64 * sj]), rs0 + 256 * b, si == sj, a0,
-                              b0, K, Gt, out, swt, cX, sX, lane, (u & 3) * 8, (u & 3) * 8 + 8);
+      fused_finish_direct<T, TP>(reinterpret_cast<T (*)[TP]>(&Td[64 * si][64 * sj]), rs0 + 256 * b, si == sj, a0,
+                                 b0, K, Gt, out, swt, cX, sX, lane, (u & 3) * 16, (u & 3) * 16 + 16);
     }
   } else if (v < 4) {
     const int a0 = ti * TILE, b0 = ti * TILE + 64;
     if (b0 < K)
-      fused_finish_mirror<TP>(reinterpret_cast<double (*)[TP]>(&Td[0][64]), a0, b0, K, out, lane, 8 * v, 8 * v + 8);
+      fused_finish_mirror<T, TP>(reinterpret_cast<T (*)[TP]>(&Td[0][64]), a0, b0, K, out, lane, 16 * v, 16 * v + 16);
   }
 }
 
@@ -285,7 +295,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing in flight at wave exit
     if (FUSEDR) __builtin_amdgcn_s_barrier();       // the compute waves reuse the ring in their epilogue
-    if constexpr (FUSEDR && sizeof(T) == 8) {
+    if constexpr (FUSEDR) {
       if (do_g && diag && a.out_XTX) {
         // diagonal tile of the fused route: share the epilogue (diag_tile_finish), waves 4..7
         constexpr int TP = TILE + 1;
@@ -293,14 +303,13 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
         const double swt = fs[2 * K + 2 * M];
         const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
-        double *smd = reinterpret_cast<double *>(smem);
-        double (*Td)[TP] = reinterpret_cast<double (*)[TP]>(smd);
-        double *rs0 = smd + (size_t)TILE * TP;
-        double *outp = (double *)a.out_XTX + (size_t)(a.seg0 + seg) * (size_t)K * K;
+        T (*Td)[TP] = reinterpret_cast<T (*)[TP]>(smem_raw);
+        double *rs0 = reinterpret_cast<double *>(smem_raw + diag_tile_bytes<T>());
+        T *outp = (T *)a.out_XTX + (size_t)(a.seg0 + seg) * (size_t)K * K;
         __syncthreads();   // B_dump
-        diag_tile_finish<TP>(Td, rs0, wave_all, 0, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
+        diag_tile_finish<T, TP>(Td, rs0, wave_all, 0, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
         __syncthreads();   // B_parked
-        diag_tile_finish<TP>(Td, rs0, wave_all, 1, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
+        diag_tile_finish<T, TP>(Td, rs0, wave_all, 1, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
       }
       if (do_g && !diag) {
         // off-diagonal tile of the fused route: help compute wave d with the second half of its
@@ -312,15 +321,15 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         const size_t fo = (size_t)(a.seg0 + seg);
         const int a0 = ti * TILE + 64 * (d >> 1), b0 = tj * TILE + 64 * (d & 1);
         const bool active = a.out_XTX && a0 < K && b0 < K;
-        double *slice = reinterpret_cast<double *>(smem) + (size_t)d * WAVE_LDS_DOUBLES;
-        double (*Ts)[65] = reinterpret_cast<double (*)[65]>(slice);
-        const double *rs = slice + 64 * 65;
-        double *outp = (double *)a.out_XTX + fo * (size_t)K * K;
+        char *slice = smem_raw + (size_t)d * wave_lds_bytes<T>();
+        T (*Ts)[65] = reinterpret_cast<T (*)[65]>(slice);
+        const double *rs = reinterpret_cast<const double *>(slice + wave_tile_bytes<T>());
+        T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
         __syncthreads();   // B_dump
         if (active)
-          fused_finish_direct<65>(Ts, rs, false, a0, b0, K, (const double *)a.G, outp, swt, cX, sX, lane, 16, 32);
+          fused_finish_direct<T, 65>(Ts, rs, false, a0, b0, K, (const T *)a.G, outp, swt, cX, sX, lane, 32, 64);
         __syncthreads();   // B_parked
-        if (active) fused_finish_mirror<65>(Ts, a0, b0, K, outp, lane, 16, 32);
+        if (active) fused_finish_mirror<T, 65>(Ts, a0, b0, K, outp, lane, 32, 64);
       }
     }
 #ifdef CVM_STAMPS
@@ -478,7 +487,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
   }
 #endif
 
-  if constexpr (FUSEDR && sizeof(T) == 8) {
+  if constexpr (FUSEDR) {
 #ifdef CVM_STAMPS
     unsigned long long f0, f1, f2, f3, f4, f5;
     STAMP(f0);
@@ -496,8 +505,8 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
     const size_t fo = (size_t)(a.seg0 + seg);
     if (h_wave) {
       if (a.out_XTY && M > 0) {
-        double *out = (double *)a.out_XTY + fo * (size_t)K * M;
-        const double *Ht = (const double *)a.H;
+        T *out = (T *)a.out_XTY + fo * (size_t)K * M;
+        const T *Ht = (const T *)a.H;
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -506,12 +515,12 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
             for (int r = 0; r < 4; ++r) {
               const int row = ti * TILE + 16 * m + MF<T>::drow(lane, r), col = yc * YT + 16 * n + lc;
               if (row < K && col < M) {
-                double v = Ht[(size_t)row * M + col] - acc[m * 2 + n][r];
+                double v = (double)Ht[(size_t)row * M + col] - (double)acc[m * 2 + n][r];
                 if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
                 if (sX && sY) v = v * (fs[K + row] * fs[2 * K + M + col]);
                 else if (sX) v = v * fs[K + row];
                 else if (sY) v = v * fs[2 * K + M + col];
-                out[(size_t)row * M + col] = v;
+                out[(size_t)row * M + col] = (T)v;
               }
             }
       }
@@ -522,10 +531,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       // are parked for the mirrored store
       const int a0 = ti * TILE + 64 * wr, b0 = tj * TILE + 64 * wc;
       const bool active = a.out_XTX && a0 < K && b0 < K;
-      double *slice = smem + (size_t)wave * WAVE_LDS_DOUBLES;
-      double (*Ts)[65] = reinterpret_cast<double (*)[65]>(slice);
-      double *rs = slice + 64 * 65;
-      double *outp = (double *)a.out_XTX + fo * (size_t)K * K;
+      char *slice = smem_raw + (size_t)wave * wave_lds_bytes<T>();
+      T (*Ts)[65] = reinterpret_cast<T (*)[65]>(slice);
+      double *rs = reinterpret_cast<double *>(slice + wave_tile_bytes<T>());
+      T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
       if (active) {
         rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
         rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
@@ -547,7 +556,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       STAMP(f2);
 #endif
       if (active)
-        fused_finish_direct<65>(Ts, rs, false, a0, b0, K, (const double *)a.G, outp, swt, cX, sX, lane, 0, 16);
+        fused_finish_direct<T, 65>(Ts, rs, false, a0, b0, K, (const T *)a.G, outp, swt, cX, sX, lane, 0, 32);
 #ifdef CVM_STAMPS
       STAMP(f3);
 #endif
@@ -555,7 +564,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
 #ifdef CVM_STAMPS
       STAMP(f4);
 #endif
-      if (active) fused_finish_mirror<65>(Ts, a0, b0, K, outp, lane, 0, 16);
+      if (active) fused_finish_mirror<T, 65>(Ts, a0, b0, K, outp, lane, 0, 32);
 #ifdef CVM_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP(f5);
@@ -740,7 +749,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
     __syncthreads();   // B_s
   }
 
-  if constexpr (FUSEDR && sizeof(T) == 8) {
+  if constexpr (FUSEDR) {
     // ---- fused epilogue (one unit per fold): the four waves put their tiles of the upper
     // triangle into one 128 x 128 image in the LDS ring, then waves 0, 1 and 3 finish the
     // 64 x 64 blocks (0,0), (0,1) and (1,1) as in wgram4_body; every wave finishes the XTY
@@ -753,8 +762,8 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
     const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
     const size_t fo = (size_t)(a.seg0 + seg);
     if (a.out_XTY && M > 0) {
-      double *out = (double *)a.out_XTY + fo * (size_t)K * M;
-      const double *Ht = (const double *)a.H;
+      T *out = (T *)a.out_XTY + fo * (size_t)K * M;
+      const T *Ht = (const T *)a.H;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -763,18 +772,18 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
           for (int r = 0; r < 4; ++r) {
             const int row = ti * TILE + 16 * (i ? R1 : R0) + MF<T>::drow(lane, r), col = 16 * n + lc;
             if (row < K && col < M) {
-              double v = Ht[(size_t)row * M + col] - acch[i * NBY + n][r];
+              double v = (double)Ht[(size_t)row * M + col] - (double)acch[i * NBY + n][r];
               if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
               if (sX && sY) v = v * (fs[K + row] * fs[2 * K + M + col]);
               else if (sX) v = v * fs[K + row];
               else if (sY) v = v * fs[2 * K + M + col];
-              out[(size_t)row * M + col] = v;
+              out[(size_t)row * M + col] = (T)v;
             }
           }
     }
     if (a.out_XTX) {
       constexpr int TP = TILE + 1;
-      double (*Td)[TP] = reinterpret_cast<double (*)[TP]>(smem);
+      T (*Td)[TP] = reinterpret_cast<T (*)[TP]>(smem_raw);
 #pragma unroll
       for (int j = 0; j < NB0; ++j)
 #pragma unroll
@@ -783,7 +792,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
       for (int j = 0; j < W + 1; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Td[16 * R1 + MF<T>::drow(lane, r)][16 * (R1 + j) + lc] = acc[NB0 + j][r];
-      double *rs0 = smem + (size_t)TILE * TP;
+      double *rs0 = reinterpret_cast<double *>(smem_raw + diag_tile_bytes<T>());
       if (W != 2) {
         // waves 0, 1, 3 set up the statistics of blocks 0, 1, 2
         const int bb = W == 3 ? 2 : W, si = bb == 2, sj = bb >= 1;
@@ -795,10 +804,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
         rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
       }
       __syncthreads();   // B_dump: the tile and the statistics are in LDS (all eight waves)
-      double *outp = (double *)a.out_XTX + fo * (size_t)K * K;
-      diag_tile_finish<TP>(Td, rs0, W, 0, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
+      T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
+      diag_tile_finish<T, TP>(Td, rs0, W, 0, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
       __syncthreads();   // B_parked
-      diag_tile_finish<TP>(Td, rs0, W, 1, ti, K, (const double *)a.G, outp, swt, cX, sX, lane);
+      diag_tile_finish<T, TP>(Td, rs0, W, 1, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
     }
     ROLE_EXIT();
   }

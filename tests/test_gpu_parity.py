@@ -798,6 +798,53 @@ def test_fused_single_split_epilogue_matches_oracle(amd, K, M):
             assert bool((t == t.T).all())
 
 
+@pytest.mark.parametrize("K,M", [(132, 16), (200, 0), (384, 33), (516, 1)])
+def test_fused_single_split_epilogue_float32(amd, K, M):
+    """The same route in float32 (the LDS-DMA kernel finishes every fold in its own epilogue, tiles
+    of float accumulators in LDS): against the float64 oracle with the oracle's own float32 run as
+    the yardstick, every flag family, weighted and unweighted, ragged folds with an empty one;
+    exactly symmetric; the same bits with and without XTY."""
+    rng = np.random.default_rng(K * 11 + M)
+    N = 24000
+    X = (rng.standard_normal((N, K)) + 0.5).astype(np.float32)
+    Y = rng.random((N, M)).astype(np.float32) if M else None
+    w = rng.random(N).astype(np.float32)
+    w[rng.choice(N, 800, replace=False)] = 0
+    folds = _midsize_folds(rng, N, 120)
+    check = [0, 3, 4, len(folds) // 2, len(folds) - 1]
+    X64, Y64, w64 = X.astype(np.float64), None if Y is None else Y.astype(np.float64), w.astype(np.float64)
+    for flags in [(True,) * 4, (False,) * 4, (True, False, True, False)]:
+        for weights, weights64 in ((w, w64), (None, None)):
+            m = amd.CVMatrix(*flags, ddof=1, dtype=np.float32)
+            o = OracleCVMatrix(*flags, ddof=1)
+            o32 = OracleCVMatrix(*flags, ddof=1, dtype=np.float32)
+            m.fit(X, Y, weights)
+            o.fit(X64, Y64, weights64)
+            o32.fit(X, Y, weights)
+            if M:
+                (bx, by), bst = m.training_XTX_XTY_batched(folds)
+            else:
+                bx, bst = m.training_XTX_batched(folds)
+            bx1, _ = m.training_XTX_batched(folds)
+            assert torch_equal(bx, bx1)
+            for i in check:
+                v = folds[i]
+                if M:
+                    (rx, ry), rst = o.training_XTX_XTY(v)
+                    (sx, sy), _ = o32.training_XTX_XTY(v)
+                    assert_fp32_like_reference(by[i], ry, sy, f"fold{i} XTY", floor=FP32_FLOOR)
+                else:
+                    rx, rst = o.training_XTX(v)
+                    sx, _ = o32.training_XTX(v)
+                assert_fp32_like_reference(bx[i], rx, sx, f"fold{i} XTX", floor=FP32_FLOOR)
+                for a_, b_ in zip(bst, rst):
+                    assert (a_ is None) == (b_ is None)
+                    if b_ is not None:
+                        np.testing.assert_allclose(to_np(a_[i]).astype(np.float64), b_, rtol=3e-5, atol=1e-6)
+            t = bx[check[1] + 1]
+            assert bool((t == t.T).all())
+
+
 def test_fused_epilogue_equals_two_stage_path(amd):
     """CVM_NO_FUSED=1 (read once per process) keeps the partials + apply_kernel route for the
     same problem: both routes must agree to rounding, bitwise-reproducibly within a route."""

@@ -20,6 +20,11 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int PITCH = 144, ROWS = 16, PANEL = ROWS * PITCH, BUF = 2 * PANEL + 16;
 
+// V = 9, 10, 11: variants 1, 2, 3 with the accumulators in AccVGPRs (inline-asm MFMA, "+a")
+template <bool AG> __device__ __forceinline__ void mfma_acc(d4& acc, double a, double b) {
+  if (AG) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
 template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in, double* out, int stages) {
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,6 +179,8 @@ template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in
       __syncthreads();
     }
   } else {
+    constexpr bool AG = V >= 9;
+    constexpr int W = AG ? V - 8 : V;
 #pragma unroll 1
     for (int s = 0; s < stages; ++s) {
       const double* buf = smem + (s & 3) * BUF;
@@ -181,15 +188,14 @@ template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int c = ks & 1;
-        if (V >= 1) { if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1); }
+        if (W >= 1) { if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m * 4 + n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) mfma_acc<AG>(acc[m * 4 + n], af[c][m], bf[c][n]);
         __builtin_amdgcn_sched_barrier(0);
-        if (V >= 2) {
+        if (W >= 2) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) af[c ^ 1][m] *= wv[c ^ 1];
         }
@@ -197,11 +203,10 @@ template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in
 #pragma unroll
         for (int m = 2; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m * 4 + n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) mfma_acc<AG>(acc[m * 4 + n], af[c][m], bf[c][n]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (V >= 3) __syncthreads();
+      if (W >= 3) __syncthreads();
     }
   }
   double sacc = 0;
@@ -304,6 +309,9 @@ int main() {
   run<1>(din, dout, "+ 9 LDS fragment reads per k-step");
   run<2>(din, dout, "+ 4 weighting multiplies per k-step");
   run<3>(din, dout, "+ one barrier per stage (4 waves)");
+  run<9>(din, dout, "AccVGPR accumulators: + 9 LDS fragment reads per k-step");
+  run<10>(din, dout, "AccVGPR accumulators: + 4 weighting multiplies");
+  run<11>(din, dout, "AccVGPR accumulators: + one barrier per stage");
   run<5>(din, dout, "same, reads and multiplies spread between the MFMAs");
   run<6>(din, dout, "as the barrier line, fragments by ds_read_b128");
   run<7>(din, dout, "diagonal tile wave 0: 11 MFMAs, 10 b64 reads per k-step", 44.0);
