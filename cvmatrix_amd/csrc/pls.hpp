@@ -584,6 +584,13 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
   if (s == 0 && tid == 0) a.n_fit[f] = fit;
 }
 
+// Before the launches of a call: the folds' barrier counters and the status word
+__global__ void pls_zero_kernel(unsigned *cnt, int64_t n, int32_t *status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cnt[i] = 0u;
+  if (i == 0) *status = 0;
+}
+
 // After the launches of a call: if any barrier timed out (status != 0: the slices of a fold were
 // not co-resident), nothing of the call can be trusted -- every coefficient becomes NaN and every
 // n_fit -1, so that a caller who does not read the status word cannot consume half-written models.
@@ -693,8 +700,9 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
   a.cnt = reinterpret_cast<unsigned *>(d);
   a.status = status;
   a.eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
-  HIP_OK(hipMemsetAsync(a.cnt, 0, (size_t)F * sizeof(unsigned), st));
-  HIP_OK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+  // the barrier counters and the status word, zeroed by one small kernel (two runtime fills cost
+  // two 5 us kernels in front of a 0.9 ms fit)
+  hipLaunchKernelGGL(pls_zero_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, a.cnt, F, status);
   void (*kern)(const PlsArgs) = p.S > 1 ? (p.xres ? pls_kernel<T, true, true> : pls_kernel<T, false, true>)
                                         : (p.xres ? pls_kernel<T, true, false> : pls_kernel<T, false, false>);
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
