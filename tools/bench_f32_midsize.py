@@ -1,5 +1,7 @@
+"""Mid-size folds in float32 (one unit per fold: the Gram kernel's fused epilogue; CVM_NO_FUSED=1: the
+two-stage route): batched training_XTX_XTY, N rows in P strided folds."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cvmatrix_amd import CVMatrix
 dev="cuda"
 for (N,K,M,P) in ((100000,512,16,1000),(100000,512,16,3000),(100000,512,16,300),(200000,1024,4,1000)):

@@ -32,6 +32,10 @@ mkdir -p $O/smallpmc
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/smallpmc/pmc_fetch -- python3 $ROOT/tools/bench_small.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/smallpmc/pmc_write -- python3 $ROOT/tools/bench_small.py > /dev/null 2>&1
 mkdir -p $D/small_tmp; python3 $ROOT/tools/summarize_rocprof.py $O/smallpmc $D/small_tmp > /dev/null; mv $D/small_tmp/pmc_summary.json $D/small_folds_pmc_summary.json; rm -rf $D/small_tmp
+# the statistics-only call and the float32 mid-size folds
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_only -- python3 $ROOT/tools/bench_stats.py > $D/bench_statistics.txt 2> $O/stats_only.log
+cp $(ls $O/stats_only/*/*_kernel_stats.csv | head -1) $D/statistics_kernel_stats.csv 2>/dev/null
+python3 $ROOT/tools/bench_f32_midsize.py > $D/bench_f32_midsize.txt 2>/dev/null
 # the consumer step (PLS) under the same tracer
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pls -- python3 $ROOT/tools/bench_pls.py > $D/bench_pls.txt 2> $O/pls.log
 cp $(ls $O/pls/*/*_kernel_stats.csv | head -1) $D/pls_kernel_stats.csv 2>/dev/null
