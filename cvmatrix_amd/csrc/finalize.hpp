@@ -772,7 +772,12 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
 // bit-identical to cvm_sweep_fit + cvm_sweep_folds.
 // ----------------------------------------------------------------------------------
 constexpr int SWF_MAX = 16;    // folds whose updates a thread holds
-constexpr int SWF_R = 16;      // block rows of sweep_finish_kernel (its columns: 256 bytes)
+#ifndef CVM_SWF_R
+#define CVM_SWF_R 16
+#endif
+constexpr int SWF_R = CVM_SWF_R;      // block rows of sweep_finish_kernel (its columns: 256 bytes)
+constexpr int SWF_T = 16 * SWF_R;     // its threads: one 16-byte piece each
+constexpr int SWF_EPW = SWF_T / SWF_MAX;   // XTY elements per workgroup
 #ifndef CVM_SWF_GROUP
 #define CVM_SWF_GROUP 8
 #endif
@@ -854,7 +859,7 @@ template <typename T> __global__ __launch_bounds__(256) void sweep_stats_kernel(
 // G; elements below the diagonal are masked (the partials hold nothing there), every finished
 // matrix is stored as rows a / columns b and, through an LDS transpose, as rows b / columns a.
 // Needs 16-byte aligned rows (K * sizeof(T) % 16 == 0) and P <= SWF_MAX.
-template <typename T> __global__ __launch_bounds__(256) void sweep_finish_kernel(const FinArgs a, T *Gout, T *Hout) {
+template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kernel(const FinArgs a, T *Gout, T *Hout) {
   const Geom &g = a.g;
   const int K = g.K, M = g.M, P = a.n_seg;
   const int tid = threadIdx.x;
@@ -869,8 +874,8 @@ template <typename T> __global__ __launch_bounds__(256) void sweep_finish_kernel
     // ---- XTY: thread = (element el of the workgroup's 16, fold fl): the fold's update from its
     // s_diag partials, H = their sum over the folds through LDS, then the fold's own result
     if (M == 0 || !Hout) return;
-    const int el = tid & 15, fl = tid >> 4;
-    const int e = (x - nrb * ncb) * 16 + el;
+    const int el = tid % SWF_EPW, fl = tid / SWF_EPW;
+    const int e = (x - nrb * ncb) * SWF_EPW + el;
     const bool evalid = e < K * M, fvalid = fl < P;
     const int ga = evalid ? e / M : 0, m = evalid ? e - ga * M : 0;
     const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
@@ -922,7 +927,7 @@ template <typename T> __global__ __launch_bounds__(256) void sweep_finish_kernel
   __shared__ double stl[SWF_MAX][SL];
   __shared__ T tm[SWF_GROUP][SWF_R][C + 1];
   if (a.out_XTX) {
-    for (int q = tid; q < P * SL; q += 256) {
+    for (int q = tid; q < P * SL; q += SWF_T) {
       const int f = q / SL, i = q - f * SL;
       const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
       double v;

@@ -833,8 +833,8 @@ int sweep_all_impl(const void *X, const void *Y, const void *w, const int64_t *i
   hipLaunchKernelGGL((sweep_stats_kernel<T>), dim3((unsigned)((K + M + 15) / 16)), dim3(256), 0, st, f, gstats);
   constexpr int C = 16 * (16 / (int)sizeof(T));
   const unsigned xb = (unsigned)(((K + SWF_R - 1) / SWF_R) * ((K + C - 1) / C));
-  const unsigned hb = (Y && M > 0) ? (unsigned)(((size_t)K * M + 15) / 16) : 0u;
-  hipLaunchKernelGGL((sweep_finish_kernel<T>), dim3(xb + hb), dim3(256), 0, st, f, (T *)G, (T *)((Y && M > 0) ? H : nullptr));
+  const unsigned hb = (Y && M > 0) ? (unsigned)(((size_t)K * M + SWF_EPW - 1) / SWF_EPW) : 0u;
+  hipLaunchKernelGGL((sweep_finish_kernel<T>), dim3(xb + hb), dim3(SWF_T), 0, st, f, (T *)G, (T *)((Y && M > 0) ? H : nullptr));
   HIP_OK(hipGetLastError());
   if (splits_out) *splits_out = (int64_t)p.s_off | ((int64_t)p.s_diag << 20);
   return CVM_OK;
