@@ -284,33 +284,33 @@ WsCarve carve_queue(void *ws, size_t ws_bytes) {
 constexpr size_t QUEUE_RESERVE = QUEUE_BYTES + 256;   // what the workspace-size functions add for it
 
 // Work-queue blocks of the persistent Gram kernel (8 heads + an exit counter, QUEUE_BYTES each):
-// a pool per device, allocated and zeroed once; a launch takes the next block round-robin and its
-// last workgroup leaves it zeroed.  (The heads used to live in the caller's workspace and were
-// zeroed on the stream before every launch: a 5 us kernel in front of every Gram launch.)
-// QUEUE_POOL blocks: more than launches can be in flight on one device at a time.
-constexpr unsigned QUEUE_POOL = 1024;
-unsigned *acquire_queue(int dev) {
+// a pool per device, allocated and zeroed once.  Every stream gets its own block (launches on one
+// stream run one after the other, and the last workgroup of a launch leaves the block zeroed;
+// launches on different streams may overlap and never share a block).  (The heads used to live in
+// the caller's workspace and were zeroed on the stream before every launch: a 5 us kernel in front
+// of every Gram launch.)
+constexpr unsigned QUEUE_POOL = 1024;       // streams per device that can run Gram launches
+unsigned *acquire_queue(int dev, hipStream_t st) {
   static std::mutex mu;
   static unsigned *pool[64];
-  static std::atomic<unsigned> next[64];
+  static std::map<hipStream_t, unsigned> block_of[64];
   const int d = dev & 63;
-  unsigned *p = __atomic_load_n(&pool[d], __ATOMIC_ACQUIRE);
-  if (!p) {
-    std::lock_guard<std::mutex> lock(mu);
-    p = pool[d];
-    if (!p) {
-      void *mem = nullptr;
-      if (hipMalloc(&mem, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess) return nullptr;
-      if (hipMemset(mem, 0, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipFree(mem);
-        return nullptr;
-      }
-      p = (unsigned *)mem;
-      __atomic_store_n(&pool[d], p, __ATOMIC_RELEASE);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool[d]) {
+    void *mem = nullptr;
+    if (hipMalloc(&mem, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess) return nullptr;
+    if (hipMemset(mem, 0, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipFree(mem);
+      return nullptr;
     }
+    pool[d] = (unsigned *)mem;
   }
-  const unsigned b = next[d].fetch_add(1u, std::memory_order_relaxed) % QUEUE_POOL;
-  return p + (size_t)b * (QUEUE_BYTES / sizeof(unsigned));
+  auto it = block_of[d].find(st);
+  if (it == block_of[d].end()) {
+    if (block_of[d].size() >= QUEUE_POOL) return nullptr;
+    it = block_of[d].emplace(st, (unsigned)block_of[d].size()).first;
+  }
+  return pool[d] + (size_t)it->second * (QUEUE_BYTES / sizeof(unsigned));
 }
 
 int device_cu_count(int dev) {
@@ -371,8 +371,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the LDS-DMA kernel%s");
   if (fast) {
     (void)queue;
-    args.queue = acquire_queue(dev);
-    if (!args.queue) return fail(CVM_ELAUNCH, "launch_wgram: cannot allocate the work-queue pool%s");
+    args.queue = acquire_queue(dev, st);
+    if (!args.queue) return fail(CVM_ELAUNCH, "launch_wgram: no work-queue block (allocation failed, or more than 1024 streams)%s");
     // persistent workgroups: one per CU (fewer when the lists are shorter than that)
     long wgs = 8 * (a.ipx0 + a.ipx1);
     const long cus = device_cu_count(dev);

@@ -182,6 +182,7 @@ class CVMatrix:
         self._nz_mask = None
         self._stage_bufs = None
         self._ws = None
+        self._nz_total_gen, self._nz_total_w = None, 0
         self._sweep = None
         self._sweep_cache = None
         self._pbatches = weakref.WeakKeyDictionary()   # Partitioner -> (FoldBatch, fingerprints)
@@ -490,8 +491,12 @@ class CVMatrix:
         (a row-sharded multi-GPU fit overrides them with the all-reduced values)."""
         self._sum_w = None
         self._n_total = self.N
-        self._nz_total = (self.N if self.weights is None
-                          else int(np.count_nonzero(self._w_host)))
+        if self.weights is None:
+            self._nz_total = self.N
+        else:
+            if self._nz_total_gen != self._w_gen:          # (once per set of weights, not per fit)
+                self._nz_total_w, self._nz_total_gen = int(np.count_nonzero(self._w_host)), self._w_gen
+            self._nz_total = self._nz_total_w
 
     def _resolve_totals(self) -> None:
         """Hook: make ``_n_total`` / ``_nz_total`` current (multi-GPU subclasses fetch the

@@ -29,8 +29,8 @@
  *     per stream / device is the intended use).  The library's only process-wide state is the
  *     optional launch-timing recorder below (mutex-guarded), once-per-device kernel
  *     attributes (atomic flags) and one 1 MiB device allocation per device, made on first use
- *     and kept (work-queue blocks of the persistent Gram kernel, handed out by an atomic
- *     counter); planning depends on the arguments alone.
+ *     and kept (work-queue blocks of the persistent Gram kernel, one per stream, handed out
+ *     under a mutex); planning depends on the arguments alone.
  */
 #ifndef CVMHIP_H
 #define CVMHIP_H
