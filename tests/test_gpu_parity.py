@@ -1351,6 +1351,19 @@ def test_forced_split_plans(plan):
     assert "worst norm-wise error" in r.stdout
 
 
+@pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["60", "101"]), ("fuzz_small.py", ["120", "102"])])
+def test_randomised_routes_against_the_oracle(tool, args):
+    """tools/fuzz_all.py / fuzz_small.py: random shapes, fold structures, element types, flags,
+    weights, ddof, lazy or eager fit and call styles through every route of the fold stage,
+    against the oracle (float64 1e-10; float32 twice the oracle's own float32 error + 2e-5)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), *args], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def torch_equal(x, y):
     import torch
     return bool(torch.equal(x, y))

@@ -1,0 +1,126 @@
+"""Randomised check of every route of the fold stage against the NumPy oracle: random shapes (K aligned
+and not, M from 0 to beyond one workgroup's columns), fold structures (partitions by random or strided
+labels -> the sweep, one call or two; arbitrary ragged subsets with an empty fold -> the two-stage path,
+the fused epilogue, the small-fold kernels), element types, flags, weights with zeros, ddof, lazy or
+eager fit, call styles (batched, the reference's per-fold loop over a Partitioner's arrays, statistics
+only).  float64: 1e-10 norm-wise; float32: twice the oracle's own float32 error + 2e-5.
+  python tools/fuzz_all.py [cases] [seed]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cvmatrix_amd import CVMatrix, Partitioner
+from oracle.cvmatrix_oracle import OracleCVMatrix
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def nerr(got, ref):
+    got = got.double().cpu().numpy() if hasattr(got, "cpu") else np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300))
+
+
+worst = 0.0
+for c in range(cases):
+    dt = np.float64 if rng.random() < 0.65 else np.float32
+    K = int(rng.choice([5, 36, 64, 100, 128, 132, 200, 256, 260, 384, 500, 512, 516, 640]))
+    if rng.random() < 0.2:
+        K += int(rng.integers(1, 4))
+    M = int(rng.choice([0, 1, 2, 5, 16, 33, 70, 300]))
+    N = int(rng.choice([300, 2000, 6000, 15000, 30000]))
+    kind = rng.choice(["partition_random", "partition_strided", "subsets"])
+    P = int(rng.choice([2, 3, 5, 10, 16, 17, 40, 120]))
+    P = min(P, N // 8)
+    X = (rng.random((N, K)) + 0.2 * rng.standard_normal((1, K))).astype(dt)
+    Y = rng.random((N, M)).astype(dt) if M else None
+    w = rng.random(N).astype(dt) if rng.random() < 0.6 else None
+    if w is not None:
+        w[rng.choice(N, N // 11, replace=False)] = 0
+    flags = tuple(bool(b) for b in rng.integers(0, 2, 4))
+    ddof = int(rng.integers(0, 2))
+    lazy = bool(rng.integers(0, 2))
+    if kind == "subsets":
+        perm = rng.permutation(N)
+        cuts = np.sort(rng.choice(np.arange(1, N), P - 1, replace=False))
+        folds = [f[: max(1, int(len(f) * rng.uniform(0.3, 1.0)))] for f in np.split(perm, cuts)]
+        folds.insert(min(2, len(folds)), np.zeros(0, dtype=np.int64))
+        part = None
+    else:
+        labels = rng.integers(0, P, N) if kind == "partition_random" else np.arange(N) % P
+        part = Partitioner(labels)
+        folds = [part.get_validation_indices(k) for k in part.folds_dict]
+    m = CVMatrix(*flags, ddof=ddof, dtype=dt, lazy_fit=lazy)
+    o = OracleCVMatrix(*flags, ddof=ddof)
+    o32 = OracleCVMatrix(*flags, ddof=ddof, dtype=np.float32) if dt is np.float32 else None
+    m.fit(X, Y, w)
+    o.fit(X.astype(np.float64), None if Y is None else Y.astype(np.float64), None if w is None else w.astype(np.float64))
+    if o32 is not None:
+        o32.fit(X, Y, w)
+    style = rng.choice(["batched", "loop", "batched_xtx", "stats"])
+    what = (c, kind, style, N, K, M, len(folds), dt.__name__, flags, ddof, lazy, w is not None)
+    try:
+        if style == "stats":
+            bst = m.training_statistics_batched(part if part is not None else folds)
+            bx = by = None
+        elif style == "loop":
+            outs = [m.training_XTX_XTY(v) if M else m.training_XTX(v) for v in folds]
+            bx = [(r[0][0] if M else r[0]) for r in outs]
+            by = [r[0][1] for r in outs] if M else None
+            bst = None
+        elif style == "batched_xtx" or not M:
+            bx, bst = m.training_XTX_batched(part if part is not None else folds)
+            by = None
+        else:
+            (bx, by), bst = m.training_XTX_XTY_batched(part if part is not None else folds)
+    except ValueError as e:
+        try:
+            for v in folds:
+                if style == "stats":
+                    o.training_statistics(v)
+                elif M and style in ("batched", "loop"):
+                    o.training_XTX_XTY(v)
+                else:
+                    o.training_XTX(v)
+            raise AssertionError(f"{what}: product raised {e!r}, oracle did not")
+        except ValueError as e2:
+            assert str(e) == str(e2), (what, str(e), str(e2))
+        continue
+    for f in rng.choice(len(folds), min(len(folds), 3), replace=False):
+        v = folds[f]
+        if style == "stats":
+            rst = o.training_statistics(v)
+            for a_, b_ in zip(bst, rst):
+                assert (a_ is None) == (b_ is None), what
+                if b_ is not None:
+                    np.testing.assert_allclose(a_[f].double().cpu().numpy(), b_, rtol=1e-10 if dt is np.float64 else 3e-5,
+                                               atol=0 if dt is np.float64 else 1e-6, err_msg=str(what))
+            continue
+        if by is not None:
+            (rx, ry), _ = o.training_XTX_XTY(v)
+        else:
+            rx, _ = o.training_XTX(v)
+            ry = None
+        if o32 is not None:
+            if by is not None:
+                (sx, sy), _ = o32.training_XTX_XTY(v)
+            else:
+                sx, _ = o32.training_XTX(v)
+                sy = None
+        ex = nerr(bx[f], rx)
+        tolx = 1e-10 if dt is np.float64 else 2 * nerr(sx, rx) + 2e-5
+        assert ex <= tolx, (what, "XTX", ex, tolx)
+        if by is not None:
+            ey = nerr(by[f], ry)
+            toly = 1e-10 if dt is np.float64 else 2 * nerr(sy, ry) + 2e-5
+            assert ey <= toly, (what, "XTY", ey, toly)
+            if dt is np.float64:
+                worst = max(worst, ey)
+        if dt is np.float64:
+            worst = max(worst, ex)
+        t = bx[f]
+        assert bool((t == t.T).all()), (what, "symmetry")
+    if c % 10 == 9:
+        print(f"{c + 1} cases, worst float64 norm-wise error so far {worst:.2e}", flush=True)
+print(f"{cases} cases ok, worst float64 norm-wise error {worst:.2e}")
