@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .partitioner import Partitioner, partitioner_of
+from .partitioner import Partitioner, partitioner_of, partitioner_pos
 
 MSG_NEG_W = "Weights must be non-negative."
 MSG_NZ_ZERO = (
@@ -112,6 +112,12 @@ class FoldBatch:
         return self._sizes
 
 
+class _ReadAhead:
+    """State of a read-ahead over a Partitioner's folds (CVMatrix._ra_*)."""
+    __slots__ = ("p", "arrs", "n", "batch", "key", "pos", "start", "count", "chunk", "max_chunk", "xtx", "xty",
+                 "stats", "need_stats", "need_std", "bad_zero", "bad_ddof", "sizes", "first", "last", "sums")
+
+
 class CVMatrix:
     """Fast training-set ``XᵀWX`` / ``XᵀWY`` for cross-validation (Engstrøm & Jensen),
     computed on an MI355X.  Parameters as cvmatrix.py:109-155; ``dtype`` must be
@@ -185,6 +191,7 @@ class CVMatrix:
         self._nz_total_gen, self._nz_total_w = None, 0
         self._sweep = None
         self._sweep_cache = None
+        self._ra = None                                 # read-ahead of a per-fold loop (_ReadAhead)
         self._pbatches = weakref.WeakKeyDictionary()   # Partitioner -> (FoldBatch, fingerprints)
         self._sweep_ws = None
         self._sweep_ids = None
@@ -363,6 +370,7 @@ class CVMatrix:
         # nothing of an earlier fit may survive a fit that raises half-way
         self._sweep = None
         self._sweep_cache = None
+        self._ra = None
         self._sweep_ids = None
         self._auto_sweep_tried = None
         self._pending = False
@@ -609,8 +617,16 @@ class CVMatrix:
         if folds and all(type(v) is np.ndarray and v.ndim == 1 and v.dtype.kind in "iu" for v in folds):
             # integer index arrays (what a Partitioner holds): one bounds check / wrap for the
             # whole batch instead of one per fold (100 000 leave-one-out folds: 0.2 s -> ms)
-            sizes = np.fromiter((v.size for v in folds), dtype=np.int64, count=len(folds))
-            idx = np.concatenate(folds).astype(np.int64, copy=False)
+            if (source is not None and source._base is not None and source._starts is None
+                    and source._base.ndim == 2 and source._base.shape[0] == len(folds)
+                    and source._base.flags.c_contiguous):
+                # equal folds kept as the rows of one matrix (arange(N) % P, leave-one-out): that
+                # matrix IS the concatenation (100 000 one-row folds: 30 ms of np.concatenate saved)
+                sizes = np.full(len(folds), source._base.shape[1], dtype=np.int64)
+                idx = np.array(source._base.reshape(-1), dtype=np.int64)      # (a private copy)
+            else:
+                sizes = np.fromiter((v.size for v in folds), dtype=np.int64, count=len(folds))
+                idx = np.concatenate(folds).astype(np.int64, copy=False)
             if idx.size:
                 lo, hi = int(idx.min()), int(idx.max())
                 if lo < -self.N or hi >= self.N:
@@ -1023,14 +1039,135 @@ class CVMatrix:
             raise ValueError(MSG_NO_Y)
         if self.X is not None:
             v = val_indices
-            if (type(v) is np.ndarray and v.ndim == 1 and 0 < v.size <= 32 and v.dtype == np.int64
-                    and v.flags.c_contiguous):
+            ra = self._ra
+            if ra is not None and ra.key == (return_XTX, return_XTY):
+                # a per-fold loop over a Partitioner with many folds is being read ahead
+                if ra.pos < ra.n and v is ra.arrs[ra.pos]:
+                    res = self._ra_serve(ra, v)
+                    if res is not None:
+                        return res
+                self._ra = ra = None
+            small = (type(v) is np.ndarray and v.ndim == 1 and 0 < v.size <= 32 and v.dtype == np.int64
+                     and v.flags.c_contiguous)
+            if small:
+                if ra is None and v.base is not None and self._ra_start(v, return_XTX, return_XTY):
+                    res = self._ra_serve(self._ra, v)
+                    if res is not None:
+                        return res
+                    self._ra = None
                 return self._one_small_fold(v, return_XTX, return_XTY)
             i = self._sweep_fold_of(v, return_XTX, return_XTY)
             if i is not None:
                 return self._finish_sweep_fold(i, return_XTX, return_XTY)
+            if (ra is None and type(v) is np.ndarray and v.base is not None
+                    and self._ra_start(v, return_XTX, return_XTY)):
+                res = self._ra_serve(self._ra, v)
+                if res is not None:
+                    return res
+                self._ra = None
         return self._first(
             self._training_matrices_batched(return_XTX, return_XTY, [val_indices]))
+
+    # ---- read-ahead of the reference's per-fold loop over a Partitioner with MANY folds ----------
+    # (leave-one-out: 100 000 calls of training_XTX_XTY with one row each, benchmarks/benchmark.py:
+    #  153-158).  A call costs the host 25-80 us, the device 0.5 us: when the array handed to a call
+    # is the very array a Partitioner holds for fold number pos, the folds pos .. pos + C - 1 are
+    # computed by ONE batched launch sequence and the following calls -- recognised by the identity
+    # of their arrays, in the Partitioner's order -- are handed their slices (each once).  The
+    # data-dependent raises stay per call; an array changed in place since the chunk was computed
+    # (size, ends, sum) ends the read-ahead.  Few large folds take the sweep instead (_sweep_fold_of).
+    def _ra_start(self, v: np.ndarray, rXTX: bool, rXTY: bool) -> bool:
+        p, pos = partitioner_pos(v)
+        if p is None or len(p._fold_arrays) <= 16:
+            return False
+        if rXTY and self.Y is None:
+            return False
+        batch = self.prepare_folds(p)
+        if self._sweep_worth(_lib.load(), batch) and not self._exchanges_globals():
+            return False                            # (the sweep serves this loop)
+        if self._sweep is not None and self._sweep[0] is batch:
+            return False
+        K, M = self.K, self.M or 0
+        per_fold = K * ((K if rXTX else 0) + (M if rXTY else 0)) * self.X.element_size()
+        ra = _ReadAhead()
+        ra.p, ra.arrs, ra.n, ra.batch, ra.key = p, p._fold_arrays, len(p._fold_arrays), batch, (rXTX, rXTY)
+        ra.pos = ra.start = pos
+        ra.count = 0
+        ra.chunk = 16
+        ra.max_chunk = int(max(16, min(4096, (256 << 20) // max(per_fold, 1))))
+        self._ra = ra
+        return True
+
+    def _ra_fill(self, ra: "_ReadAhead") -> None:
+        """Folds ra.pos .. of the Partitioner in one batched call; per-fold witnesses and verdicts."""
+        full = ra.batch
+        a, b = ra.pos, min(ra.n, ra.pos + ra.chunk)
+        ho = full.host_offsets
+        sub = FoldBatch(full.idx, full.offsets[a:b + 1], ho[a:b + 1], full.nz_val[a:b], None, None, full._n_rows,
+                        device=self.device, w_gen=full._w_gen)
+        sub._sizes = full.sizes[a:b]
+        rXTX, rXTY = ra.key
+        xtx, xty, (muX, sdX, muY, sdY), _ = self._run(sub, rXTX, rXTY)
+        cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
+        r_muX, r_muY, r_sdX, r_sdY = cX or (rXTY and cY), rXTY and (cX or cY), sX, rXTY and sY
+        ra.xtx = xtx.unbind(0) if xtx is not None else None
+        ra.xty = xty.unbind(0) if xty is not None else None
+        ra.stats = (muX.unbind(0) if r_muX else None, sdX.unbind(0) if r_sdX else None,
+                    muY.unbind(0) if (r_muY and muY is not None) else None,
+                    sdY.unbind(0) if (r_sdY and sdY is not None) else None)
+        ra.need_stats, ra.need_std = bool(r_muX or r_muY or r_sdX or r_sdY), bool(r_sdX or r_sdY)
+        # the reference's raises (cvmatrix.py:612-630, 1074-1078), decided for the whole chunk
+        ra.bad_zero = ra.bad_ddof = None
+        if ra.need_stats:
+            self._resolve_totals()
+            if self.weights is not None:
+                nz_train = self._nz_total - full.nz_val[a:b]
+                ra.bad_zero = (nz_train == 0).tolist()
+            else:
+                nz_train = self._n_total - full.sizes[a:b]
+            if ra.need_std:
+                ra.bad_ddof = (nz_train <= self.ddof).tolist()
+        # witnesses of the index arrays as they were when the chunk was computed
+        hidx = full._host_idx
+        o = ho[a:b + 1]
+        seg = hidx[o[0]:o[-1]]
+        sizes = np.diff(o)
+        ra.sizes = sizes.tolist()
+        nonempty = sizes > 0
+        first = np.zeros(b - a, dtype=np.int64)
+        last = np.zeros(b - a, dtype=np.int64)
+        sums = np.zeros(b - a, dtype=np.int64)
+        if seg.size:
+            rel = (o[:-1] - o[0])
+            first[nonempty] = seg[rel[nonempty]]
+            last[nonempty] = seg[(o[1:] - o[0] - 1)[nonempty]]
+            sums[nonempty] = np.add.reduceat(seg, rel[nonempty])
+        ra.first, ra.last, ra.sums = first.tolist(), last.tolist(), sums.tolist()
+        ra.start, ra.count = a, b - a
+        ra.chunk = min(ra.max_chunk, ra.chunk * 2)
+
+    def _ra_serve(self, ra: "_ReadAhead", v: np.ndarray):
+        j = ra.pos - ra.start
+        if j >= ra.count or j < 0:
+            self._ra_fill(ra)
+            j = 0
+        n = v.size
+        if n != ra.sizes[j] or (n and (int(v[0]) != ra.first[j] or int(v[-1]) != ra.last[j]
+                                       or (n > 2 and int(v.sum()) != ra.sums[j]))):
+            return None                             # changed in place since the chunk was computed
+        if ra.need_stats:
+            if ra.bad_zero is not None and ra.bad_zero[j]:
+                raise ValueError(MSG_NZ_ZERO)
+            if ra.bad_ddof is not None and ra.bad_ddof[j]:
+                raise ValueError(MSG_NZ_DDOF)
+        ra.pos += 1
+        o = self._out
+        st = ra.stats
+        stats = (None if st[0] is None else o(st[0][j]), None if st[1] is None else o(st[1][j]),
+                 None if st[2] is None else o(st[2][j]), None if st[3] is None else o(st[3][j]))
+        if ra.xtx is not None and ra.xty is not None:
+            return (o(ra.xtx[j]), o(ra.xty[j])), stats
+        return (o(ra.xtx[j]) if ra.xtx is not None else o(ra.xty[j])), stats
 
     def _one_small_fold(self, v: np.ndarray, rXTX: bool, rXTY: bool):
         """One fold of at most 32 rows given as an int64 index array -- the call of the reference's

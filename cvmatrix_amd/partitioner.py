@@ -23,6 +23,33 @@ _OWNER: "weakref.WeakValueDictionary[int, Partitioner]" = weakref.WeakValueDicti
 _REGISTER_MAX_FOLDS = 4096
 
 
+# id(base array) -> Partitioner, for folds that are views of one array the Partitioner made (integer
+# labels: every fold is a row of a matrix or a slice of the sorted order): any number of folds at
+# one registry entry; the fold's position follows from its address.
+_BASE_OWNER: "weakref.WeakValueDictionary[int, Partitioner]" = weakref.WeakValueDictionary()
+
+
+def partitioner_pos(indices):
+    """(Partitioner, position of the fold in its ``folds_dict`` order) if ``indices`` is the very
+    array object a live Partitioner holds for one of its folds, else (None, None)."""
+    p = _OWNER.get(id(indices))
+    if p is not None:
+        pos = p._fold_pos.get(id(indices))
+        if pos is not None and p._fold_arrays[pos] is indices:
+            return p, pos
+        return None, None
+    b = getattr(indices, "base", None)
+    if b is None:
+        return None, None
+    p = _BASE_OWNER.get(id(b))
+    if p is None or p._base is not b:
+        return None, None
+    pos = p._pos_from_address(indices)
+    if pos is None or p._fold_arrays[pos] is not indices:
+        return None, None
+    return p, pos
+
+
 def partitioner_of(indices) -> "Optional[Partitioner]":
     """The live ``Partitioner`` whose ``folds_dict`` holds exactly this array object, if any."""
     p = _OWNER.get(id(indices))
@@ -53,6 +80,28 @@ class Partitioner:
             for i, a in enumerate(self._fold_arrays):
                 self._fold_pos[id(a)] = i
                 _OWNER[id(a)] = self
+        # folds that are views of one array of this object: found by address, whatever their number
+        self._base = None
+        self._addr_pos = None
+        self._starts = getattr(self, "_starts", None)   # ragged folds: their starts inside the sorted order
+        if self._fold_arrays:
+            b = getattr(self._fold_arrays[0], "base", None)
+            if b is not None and all(getattr(a, "base", None) is b for a in self._fold_arrays[:3]):
+                self._base = b
+                _BASE_OWNER[id(b)] = self
+
+    def _pos_from_address(self, a) -> Optional[int]:
+        b = self._base
+        off = a.__array_interface__["data"][0] - b.__array_interface__["data"][0]
+        if self._addr_pos is None:      # (built on first use: start of every fold inside the base -> position)
+            sizes = np.fromiter((f.size for f in self._fold_arrays), dtype=np.int64, count=len(self._fold_arrays))
+            if self._starts is None:    # rows of a matrix, in order
+                st = np.zeros(sizes.size, dtype=np.int64)
+                np.cumsum(sizes[:-1], out=st[1:])
+            else:
+                st = self._starts
+            self._addr_pos = dict(zip((st * b.itemsize).tolist(), range(sizes.size)))
+        return self._addr_pos.get(off)
 
     def get_validation_indices(self, fold: Hashable) -> npt.NDArray[np.int_]:
         """Index array of the samples labelled ``fold`` (partitioner.py:61-87)."""
@@ -80,6 +129,7 @@ class Partitioner:
                 vals = list(order.reshape(P, arr.size // P)[by_first])
             else:
                 bounds = np.r_[starts, arr.size]
+                self._starts = np.asarray(bounds[by_first], dtype=np.int64)
                 lo, hi = bounds[by_first].tolist(), bounds[by_first + 1].tolist()
                 vals = [order[a:b] for a, b in zip(lo, hi)]
             out = dict(zip(keys, vals))

@@ -233,3 +233,93 @@ def test_reference_loop_is_served_from_one_sweep(amd, hip_device):
     sub = q.get_validation_indices(0)[:500].copy()
     m3.training_XTX_XTY(sub)
     assert m3._sweep is None and not m3._pending
+
+
+@pytest.mark.parametrize("N,K,M,labels_kind,dtype", [(700, 50, 3, "loo", np.float64), (6000, 36, 2, "mod150", np.float64),
+                                                     (5000, 40, 0, "random400", np.float64), (900, 64, 1, "loo", np.float32)])
+def test_per_fold_loop_over_many_folds_is_read_ahead(amd, N, K, M, labels_kind, dtype):
+    """The reference's loop ``for fold in p.folds_dict: cvm.training_XTX_XTY(p.get_validation_indices(fold))``
+    over a Partitioner with MANY folds (leave-one-out, benchmarks/benchmark.py:153-158): the calls are
+    recognised by the identity of the Partitioner's arrays and served from chunks computed by one
+    batched launch sequence each -- same bits as the batched call, the reference's raises still at the
+    offending call, arrays changed in place (and copies) take the ordinary route."""
+    import torch
+
+    rng = np.random.default_rng(N + K)
+    X = rng.random((N, K)).astype(dtype)
+    Y = rng.random((N, M)).astype(dtype) if M else None
+    w = rng.random(N).astype(dtype)
+    w[rng.choice(N, N // 7, replace=False)] = 0
+    labels = {"loo": np.arange(N), "mod150": np.arange(N) % 150, "random400": rng.integers(0, 400, N)}[labels_kind]
+    p = amd.Partitioner(labels)
+    keys = list(p.folds_dict)
+    ref = amd.CVMatrix(dtype=dtype, lazy_fit=False)
+    ref.fit(X, Y, w)
+    if M:
+        (bx, by), bst = ref.training_XTX_XTY_batched(p)
+    else:
+        bx, bst = ref.training_XTX_batched(p)
+    m = amd.CVMatrix(dtype=dtype)
+    m.fit(X, Y, w)
+    served = 0
+    # folds of at most 32 rows go through kernels without row splits: the same bits however the folds
+    # are batched; larger folds get the row-split plan of their batch (a chunk here, all folds there)
+    exact = labels_kind == "loo"
+    tol = 1e-12 if dtype is np.float64 else 1e-5
+
+    def same(a, b, what):
+        if exact:
+            assert torch.equal(a, b), what
+        else:
+            assert_normwise(a.double(), b.double().cpu().numpy(), tol, what)
+
+    for i, k in enumerate(keys):
+        v = p.get_validation_indices(k)
+        if M:
+            (xtx, xty), st = m.training_XTX_XTY(v)
+            same(xty, by[i], "XTY")
+        else:
+            xtx, st = m.training_XTX(v)
+        served += m._ra is not None
+        same(xtx, bx[i], (i, labels_kind))
+        for a, b in zip(st, bst):
+            assert (a is None) == (b is None)
+            if a is not None:
+                np.testing.assert_allclose(a.double().cpu().numpy(), b[i].double().cpu().numpy(), rtol=1e-11 if dtype is np.float64 else 1e-5)
+        xtx.zero_()                                   # the caller owns what it was handed
+    assert served >= len(keys) - 1                    # (the read-ahead was on from the first call)
+    # the loop again (second pass over the same folds: computed again, not the zeroed slices)
+    for i, k in enumerate(keys[:40]):
+        v = p.get_validation_indices(k)
+        xtx = (m.training_XTX_XTY(v) if M else m.training_XTX(v))[0]
+        xtx = xtx[0] if M else xtx
+        same(xtx, bx[i], "second pass")
+    # a copy of an array and an array changed in place: ordinary route, same numbers to rounding
+    v = p.get_validation_indices(keys[41]).copy()
+    xtx = m.training_XTX(v)[0]
+    assert_normwise(xtx.double(), bx[41].double().cpu().numpy(), 1e-11 if dtype is np.float64 else 1e-5, "copy")
+    v = p.get_validation_indices(keys[42])
+    m.training_XTX(p.get_validation_indices(keys[41]))          # (read-ahead positioned at fold 42)
+    saved = v.copy()
+    other = int(p.get_validation_indices(keys[43])[0])
+    v[0] = other
+    xtx = m.training_XTX(v)[0]
+    v[:] = saved
+    o = amd.CVMatrix(dtype=dtype, lazy_fit=False)
+    o.fit(X, Y, w)
+    chk = saved.copy(); chk[0] = other
+    assert_normwise(xtx.double(), o.training_XTX(chk.copy())[0].double().cpu().numpy(), 1e-11 if dtype is np.float64 else 1e-5,
+                    "changed in place")
+    # the reference's raise arrives at the offending call, not before: all weight in one fold
+    if labels_kind == "loo":
+        w2 = np.zeros(N, dtype=dtype)
+        w2[5] = 1.0
+        m2 = amd.CVMatrix(dtype=dtype, ddof=0)
+        m2.fit(X, Y, w2)
+        for i, k in enumerate(keys[:12]):
+            v = p.get_validation_indices(k)
+            if i == 5:
+                with pytest.raises(ValueError, match="non-zero weights"):
+                    m2.training_XTX(v)
+            else:
+                m2.training_XTX(v)

@@ -42,6 +42,7 @@ cp $(ls $O/pls/*/*_kernel_stats.csv | head -1) $D/pls_kernel_stats.csv 2>/dev/nu
 cd $ROOT
 python3 bench.py > $O/plain.out 2>&1; grep "^{" $O/plain.out | tail -1 > $D/bench_bench_plain.json
 python3 tools/bench_foldsizes.py > $D/fold_size_sweep.txt 2>/dev/null
+rm -f $D/benchmark_protocol_hip.csv; python3 tools/benchmark_protocol.py --csv $D/benchmark_protocol_hip.csv > $D/benchmark_protocol.log 2>&1
 python3 tools/power_probe.py C3 C3fit C3fold C3two C4 C4fit C5 2>/dev/null > $D/power_probe.txt
 for p in "500:250" "240:280,280:120" "240:280,240:135" "480:145,560:65"; do ./tools/dispatch_probe "$p" > /tmp/dp.txt; python3 tools/dispatch_analyze.py /tmp/dp.txt | sed -n 1,7p | cut -c1-400; echo; done > $D/dispatch_probe.txt 2>&1
 tail -3 $O/stats.log
