@@ -178,7 +178,8 @@ class CVMatrix:
         self._device_arg = device
         self.device: Optional[torch.device] = None
         self.X = self.Y = self.weights = None
-        self.N = self.K = self.M = None
+        self.N = self._Kd = self._Md = None           # device dims (columns padded to 16-byte rows)
+        self._Ku = self._Mu = None                    # the caller's K, M
         self.XTX = self.XTY = None
         self._sum_w = None
         self._n_total = self._nz_total = None
@@ -221,10 +222,77 @@ class CVMatrix:
             self._np_cache[key] = t.cpu().numpy()
         return self._np_cache[key]
 
+    # Results whose last dimensions are the DEVICE dims (the columns of the private device copies
+    # may be padded, see ``fit``): cut back to the caller's K, M.  ``key``: an attribute (the cut
+    # copy is kept per fit).  Unpadded problems pass through untouched.
+    def _cut_t(self, t, kind: str):
+        """The tensor cut to the caller's dims (a contiguous copy when anything is cut off)."""
+        if t is None:
+            return None
+        K, M, Kd, Md = self._Ku, self._Mu or 0, self._Kd, self._Md or 0
+        if Kd == K and Md == M:
+            return t
+        if kind == "XX":
+            t = t[..., :K, :K]
+        elif kind == "XY":
+            t = t[..., :K, :M]
+        elif kind == "X":
+            t = t[..., :K]
+        else:
+            t = t[..., :M]
+        return t.contiguous()
+
+    def _cut(self, t, kind: str, key=None):
+        if t is None:
+            return None
+        if self._Kd == self._Ku and (self._Md or 0) == (self._Mu or 0):
+            return self._out(t, key)
+        if key is not None:
+            if ("cut", key) not in self._np_cache:
+                self._np_cache[("cut", key)] = self._cut_t(t, kind)
+            return self._out(self._np_cache[("cut", key)], key)
+        return self._out(self._cut_t(t, kind))
+
+    def _oXX(self, t, key=None):
+        return self._cut(t, "XX", key)
+
+    def _oXY(self, t, key=None):
+        return self._cut(t, "XY", key)
+
+    def _oX(self, t, key=None):
+        return self._cut(t, "X", key)
+
+    def _oY(self, t, key=None):
+        return self._cut(t, "Y", key)
+
+    def _device_dims(self, K: int, M: int):
+        """Columns of the device copies of X and Y: padded with zero columns to rows of whole
+        16-byte pieces (float64: even K and M; float32: K a multiple of 4) when the object owns
+        private copies anyway (``copy=True``) -- every shape then takes the LDS-DMA Gram kernel
+        (K=511 at the C3 shape: 0.77 -> 0.51 ms per step) at the price of a cut of the results back
+        to K x K.  A zero column has mean 0 and std 0 -> 1 and contributes nothing to any other
+        element.  ``copy=False`` (inputs aliased) and CVM_PAD=0 keep the caller's shape (the
+        general kernels)."""
+        if not self.copy or os.environ.get("CVM_PAD", "1") == "0":
+            return K, M
+        a = 16 // np.dtype(self._npdt).itemsize
+        Kd = -(-K // a) * a
+        Md = M + (M & 1) if (M and a == 2) else M
+        return Kd, Md
+
+    @property
+    def K(self):
+        """Number of columns of X (the caller's; the device copy may be padded, see ``fit``)."""
+        return self._Ku
+
+    @property
+    def M(self):
+        return self._Mu
+
     @property
     def XTX(self):
         self._ensure_fit()
-        return self._out(self._G, "XTX")
+        return self._oXX(self._G, "XTX")
 
     @XTX.setter
     def XTX(self, v):
@@ -233,7 +301,7 @@ class CVMatrix:
     @property
     def XTY(self):
         self._ensure_fit()
-        return self._out(self._H, "XTY")
+        return self._oXY(self._H, "XTY")
 
     @XTY.setter
     def XTY(self, v):
@@ -259,11 +327,11 @@ class CVMatrix:
 
     def _launch_fit(self, lib) -> None:
         """The fit-stage kernel over all rows (cvm_gram_fit)."""
-        M = self.M or 0
+        M = self._Md or 0
         neg = torch.empty(1, dtype=torch.int32, device=self.device)   # always written by fit_stats_kernel
-        ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self.K, M, self._cdt))
+        ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self._Kd, M, self._cdt))
         rc = lib.cvm_gram_fit(
-            self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), self.N, self.K,
+            self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights), self.N, self._Kd,
             M, self._cdt, self._G.data_ptr(), _lib.ptr(self._H),
             self._gs.data_ptr(), neg.data_ptr(), ws.data_ptr(), ws.numel(),
             self._stream(),
@@ -287,7 +355,7 @@ class CVMatrix:
         # rows and costs a write + read of every fold's K x (K+M) partials (about 256 rows of
         # Gram work per fold at float64); small folds have their own direct route anyway
         worth = (batch.n_folds > 0 and int(sizes.min()) > 32 and self.N >= 256 * batch.n_folds
-                 and lib.cvm_sweep_workspace_bytes(batch.n_folds, int(sizes.max()), self.K, self.M or 0,
+                 and lib.cvm_sweep_workspace_bytes(batch.n_folds, int(sizes.max()), self._Kd, self._Md or 0,
                                                    self._cdt) <= (4 << 30))
         return bool(worth and batch._n_rows == self.N and batch.is_partition)
 
@@ -319,21 +387,39 @@ class CVMatrix:
         d = torch.device(d if not isinstance(d, int) else f"cuda:{d}")
         return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
 
-    def _init_mat(self, mat) -> torch.Tensor:
-        """cvmatrix.py:1131-1151 on the device: cast, copy iff needed, 1-D -> (N,1)."""
+    @staticmethod
+    def _cols_of(mat) -> int:
+        shp = tuple(mat.shape) if hasattr(mat, "shape") else np.asarray(mat).shape
+        if len(shp) == 1:
+            return 1
+        if len(shp) != 2:
+            raise ValueError("expected a 1-D or 2-D array")
+        return int(shp[1])
+
+    def _init_mat(self, mat, pad_cols: Optional[int] = None) -> torch.Tensor:
+        """cvmatrix.py:1131-1151 on the device: cast, copy iff needed, 1-D -> (N,1).
+        ``pad_cols`` > columns: the private copy gets that many columns (zeros behind the data) and
+        the returned tensor is the view of its first columns (same address, row stride pad_cols)."""
         if isinstance(mat, torch.Tensor):
             t = mat
+            fresh = False
             if t.device != self.device or t.dtype != self._tdt or not t.is_contiguous():
                 t = t.to(device=self.device, dtype=self._tdt).contiguous()
-            elif self.copy:
-                t = t.clone()
+                fresh = True
         else:
             h = np.ascontiguousarray(np.asarray(mat, dtype=self._npdt))
             t = torch.from_numpy(h).to(self.device)  # the upload is the private copy
+            fresh = True
         if t.ndim == 1:
             t = t.reshape(-1, 1)
         if t.ndim != 2:
             raise ValueError("expected a 1-D or 2-D array")
+        if pad_cols is not None and pad_cols > t.shape[1]:
+            store = torch.zeros((t.shape[0], pad_cols), dtype=self._tdt, device=self.device)
+            store[:, :t.shape[1]].copy_(t)
+            return store[:, :t.shape[1]]
+        if self.copy and not fresh:
+            t = t.clone()
         return t
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
@@ -376,15 +462,18 @@ class CVMatrix:
         self._pending = False
         self._np_cache = {}
         with torch.cuda.device(self.device):
-            self.X = self._init_mat(X)
-            self.N, self.K = self.X.shape
+            Ku = self._cols_of(X)
+            Mu = self._cols_of(Y) if Y is not None else None
+            self._Kd, Md = self._device_dims(Ku, Mu or 0)
+            self.X = self._init_mat(X, self._Kd)         # (a view of the padded copy when padded)
+            self.N, self._Ku = self.X.shape
             if Y is not None:
-                self.Y = self._init_mat(Y)
-                self.M = self.Y.shape[1]
+                self.Y = self._init_mat(Y, Md)
+                self._Mu, self._Md = self.Y.shape[1], Md
                 if self.Y.shape[0] != self.N:
                     raise ValueError("X and Y must have the same number of rows")
             else:
-                self.Y, self.M = None, None
+                self.Y, self._Mu, self._Md = None, None, None
             if weights is not None:
                 self._check_weights_host(weights)
                 self.weights = self._init_mat(weights)
@@ -394,8 +483,8 @@ class CVMatrix:
                 if self.weights is not None or self._w_host is not None:
                     self._w_gen += 1
                 self.weights, self._w_host, self._w_checked, self._w_checked_src = None, None, None, None
-            M = self.M or 0
-            self._alloc_globals(lib.cvm_gstats_len(self.K, M))
+            M = self._Md or 0
+            self._alloc_globals(lib.cvm_gstats_len(self._Kd, M))
             self._neg = None
             if folds is not None:
                 neg = torch.empty(1, dtype=torch.int32, device=self.device)
@@ -414,7 +503,7 @@ class CVMatrix:
         buffer ``[G | H | gstats]`` (float64 problems): the multi-GPU exchange is then a single
         collective on that buffer with nothing to pack.  float32 problems keep separate
         tensors (the statistics stay float64)."""
-        K, M, dev = self.K, self.M or 0, self.device
+        K, M, dev = self._Kd, self._Md or 0, self.device
         hasY = self.Y is not None
         if self._tdt == torch.float64:
             nG, nH = K * K, (K * M if hasY else 0)
@@ -435,7 +524,7 @@ class CVMatrix:
         batch = self.prepare_folds(folds)
         if not batch.is_partition:
             raise ValueError("fit(folds=...) needs folds that contain every row exactly once")
-        K, M, P = self.K, self.M or 0, batch.n_folds
+        K, M, P = self._Kd, self._Md or 0, batch.n_folds
         want = lib.cvm_sweep_workspace_bytes(P, int(batch.sizes.max()), K, M, self._cdt)
         if (getattr(self, "_sweep_ws", None) is None or self._sweep_ws.numel() < want
                 or self._sweep_ws.device != self.device):
@@ -528,23 +617,23 @@ class CVMatrix:
 
     @property
     def sum_X(self):
-        return self._gslice(0, self.K, self.center_X or self.center_Y or self.scale_X)
+        return self._gslice(0, self._Ku, self.center_X or self.center_Y or self.scale_X)
 
     @property
     def sum_sq_X(self):
-        return self._gslice(self.K, 2 * self.K, self.scale_X)
+        return self._gslice(self._Kd, self._Kd + self._Ku, self.scale_X)
 
     @property
     def sum_Y(self):
-        M = self.M or 0
-        return self._gslice(2 * self.K, 2 * self.K + M,
+        M = self._Mu or 0
+        return self._gslice(2 * self._Kd, 2 * self._Kd + M,
                             (self.center_X or self.center_Y or self.scale_Y)
                             and self.Y is not None)
 
     @property
     def sum_sq_Y(self):
-        M = self.M or 0
-        return self._gslice(2 * self.K + M, 2 * self.K + 2 * M,
+        M, Md = self._Mu or 0, self._Md or 0
+        return self._gslice(2 * self._Kd + Md, 2 * self._Kd + Md + M,
                             self.scale_Y and self.Y is not None)
 
     @property
@@ -566,7 +655,7 @@ class CVMatrix:
             self._resolve_totals()
             return self._n_total
         if self._sum_w is None:
-            K, M = self.K, self.M or 0
+            K, M = self._Kd, self._Md or 0
             self._sum_w = self.dtype(self._gstats[2 * K + 2 * M].item())
         return self._sum_w
 
@@ -840,7 +929,7 @@ class CVMatrix:
         lib = _lib.load()
         if not sweep_all:
             self._ensure_fit()
-        K, M, P = self.K, self.M or 0, (batch.n_folds if sweep_fold is None else 1)
+        K, M, P = self._Kd, self._Md or 0, (batch.n_folds if sweep_fold is None else 1)
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         if stat_flags is not None:
             cX, cY, sX, sY = stat_flags
@@ -953,12 +1042,12 @@ class CVMatrix:
         xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY, sweep_fold=sweep_fold, sweep_all=sweep_all)
         if late:
             self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
-        o = self._out
-        stats = (o(muX) if r_muX else None, o(sdX) if r_sdX else None,
-                 o(muY) if r_muY else None, o(sdY) if r_sdY else None)
+        o, oXX, oXY, oX, oY = self._out, self._oXX, self._oXY, self._oX, self._oY
+        stats = (oX(muX) if r_muX else None, oX(sdX) if r_sdX else None,
+                 oY(muY) if r_muY else None, oY(sdY) if r_sdY else None)
         if rXTX and rXTY:
-            return (o(xtx), o(xty)), stats
-        return (o(xtx) if rXTX else o(xty)), stats
+            return (oXX(xtx), oXY(xty)), stats
+        return (oXX(xtx) if rXTX else oXY(xty)), stats
 
     # ------------------------------------------------------------------ public API
     def training_XTX_batched(self, folds):
@@ -999,7 +1088,7 @@ class CVMatrix:
                 self._auto_sweep_tried = p          # (one attempt per fit and Partitioner)
                 batch = self.prepare_folds(p)
                 lib = _lib.load()
-                K, M = self.K, self.M or 0
+                K, M = self._Kd, self._Md or 0
                 if (not self._exchanges_globals() and batch.n_folds <= 16 and self._sweep_worth(lib, batch)
                         and (rXTY is False or self.Y is not None)
                         and batch.n_folds * K * (K + M) * self.X.element_size() <= (1 << 30)):
@@ -1008,7 +1097,9 @@ class CVMatrix:
                     # once (a second request for a fold recomputes it: the caller may have changed
                     # its matrices in place).  The data-dependent raises stay per call.
                     xtx, xty, st, _ = self._run(batch, rXTX, rXTY, sweep_all=True)
-                    self._sweep_cache = {"key": (rXTX, rXTY), "xtx": xtx, "xty": xty, "stats": st,
+                    c = self._cut_t                 # (padded device copies: cut once, for all folds)
+                    st = (c(st[0], "X"), c(st[1], "X"), c(st[2], "Y"), c(st[3], "Y"))
+                    self._sweep_cache = {"key": (rXTX, rXTY), "xtx": c(xtx, "XX"), "xty": c(xty, "XY"), "stats": st,
                                          "left": set(range(batch.n_folds))}
                 else:
                     self._lazy_sweep(batch)         # sweeps if the folds partition the rows and are large
@@ -1087,7 +1178,7 @@ class CVMatrix:
             return False                            # (the sweep serves this loop)
         if self._sweep is not None and self._sweep[0] is batch:
             return False
-        K, M = self.K, self.M or 0
+        K, M = self._Kd, self._Md or 0
         per_fold = K * ((K if rXTX else 0) + (M if rXTY else 0)) * self.X.element_size()
         ra = _ReadAhead()
         ra.p, ra.arrs, ra.n, ra.batch, ra.key = p, p._fold_arrays, len(p._fold_arrays), batch, (rXTX, rXTY)
@@ -1110,11 +1201,12 @@ class CVMatrix:
         xtx, xty, (muX, sdX, muY, sdY), _ = self._run(sub, rXTX, rXTY)
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         r_muX, r_muY, r_sdX, r_sdY = cX or (rXTY and cY), rXTY and (cX or cY), sX, rXTY and sY
-        ra.xtx = xtx.unbind(0) if xtx is not None else None
-        ra.xty = xty.unbind(0) if xty is not None else None
-        ra.stats = (muX.unbind(0) if r_muX else None, sdX.unbind(0) if r_sdX else None,
-                    muY.unbind(0) if (r_muY and muY is not None) else None,
-                    sdY.unbind(0) if (r_sdY and sdY is not None) else None)
+        c = self._cut_t                             # (padded device copies: cut the chunk once)
+        ra.xtx = c(xtx, "XX").unbind(0) if xtx is not None else None
+        ra.xty = c(xty, "XY").unbind(0) if xty is not None else None
+        ra.stats = (c(muX, "X").unbind(0) if r_muX else None, c(sdX, "X").unbind(0) if r_sdX else None,
+                    c(muY, "Y").unbind(0) if (r_muY and muY is not None) else None,
+                    c(sdY, "Y").unbind(0) if (r_sdY and sdY is not None) else None)
         ra.need_stats, ra.need_std = bool(r_muX or r_muY or r_sdX or r_sdY), bool(r_sdX or r_sdY)
         # the reference's raises (cvmatrix.py:612-630, 1074-1078), decided for the whole chunk
         ra.bad_zero = ra.bad_ddof = None
@@ -1161,7 +1253,7 @@ class CVMatrix:
             if ra.bad_ddof is not None and ra.bad_ddof[j]:
                 raise ValueError(MSG_NZ_DDOF)
         ra.pos += 1
-        o = self._out
+        o, oXX, oXY, oX, oY = self._out, self._oXX, self._oXY, self._oX, self._oY
         st = ra.stats
         stats = (None if st[0] is None else o(st[0][j]), None if st[1] is None else o(st[1][j]),
                  None if st[2] is None else o(st[2][j]), None if st[3] is None else o(st[3][j]))
@@ -1177,7 +1269,7 @@ class CVMatrix:
         without building a ``FoldBatch``, without a fold axis, with three allocations."""
         lib = _lib.load()
         self._ensure_fit()
-        N, K, M = self.N, self.K, self.M or 0
+        N, K, M = self.N, self._Kd, self._Md or 0
         n = v.size
         if n == 1:
             lo = hi = int(v[0])
@@ -1232,14 +1324,14 @@ class CVMatrix:
             0, ws.data_ptr(), ws.numel(), self._stream(),
         )
         _lib.check(rc, "cvm_fold_update")
-        if self.output == "numpy":
-            o = self._out
-            stats = (o(stat[:K].view(1, K)) if r_muX else None, o(stat[K:2 * K].view(1, K)) if r_sdX else None,
-                     o(stat[2 * K:2 * K + M].view(1, M)) if r_muY else None,
-                     o(stat[2 * K + M:].view(1, M)) if r_sdY else None)
+        if self.output == "numpy" or K != self._Ku or M != (self._Mu or 0):
+            o, oXX, oXY, oX, oY = self._out, self._oXX, self._oXY, self._oX, self._oY
+            stats = (oX(stat[:K].view(1, K)) if r_muX else None, oX(stat[K:2 * K].view(1, K)) if r_sdX else None,
+                     oY(stat[2 * K:2 * K + M].view(1, M)) if r_muY else None,
+                     oY(stat[2 * K + M:].view(1, M)) if r_sdY else None)
             if rXTX and rXTY:
-                return (o(xtx), o(xty)), stats
-            return (o(xtx) if rXTX else o(xty)), stats
+                return (oXX(xtx), oXY(xty)), stats
+            return (oXX(xtx) if rXTX else oXY(xty)), stats
         stats = (stat[:K].view(1, K) if r_muX else None, stat[K:2 * K].view(1, K) if r_sdX else None,
                  stat[2 * K:2 * K + M].view(1, M) if r_muY else None,
                  stat[2 * K + M:].view(1, M) if r_sdY else None)
@@ -1253,7 +1345,7 @@ class CVMatrix:
         the statistics, results without a fold axis."""
         lib = _lib.load()
         batch, token = self._sweep
-        K, M = self.K, self.M or 0
+        K, M = self._Kd, self._Md or 0
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         r_muX = cX or (rXTY and cY)                 # cvmatrix.py:828-831
         r_muY = rXTY and (cX or cY)
@@ -1267,7 +1359,7 @@ class CVMatrix:
             muX, sdX, muY, sdY = cache["stats"]
             if not cache["left"]:
                 self._sweep_cache = None
-            o = self._out
+            o = self._out                           # (the cache holds tensors already cut to K, M)
             stats = (o(muX[i]) if r_muX else None, o(sdX[i]) if r_sdX else None,
                      o(muY[i]) if r_muY else None, o(sdY[i]) if r_sdY else None)
             if rXTX and rXTY:
@@ -1292,14 +1384,14 @@ class CVMatrix:
             self._sweep_ws.data_ptr(), self._sweep_ws.numel(), token, self._stream(),
         )
         _lib.check(rc, "cvm_sweep_fold_range")
-        o = self._out
-        stats = (o(stat[:K].view(1, K)) if r_muX else None,
-                 o(stat[K:2 * K].view(1, K)) if r_sdX else None,
-                 o(stat[2 * K:2 * K + M].view(1, M)) if r_muY else None,
-                 o(stat[2 * K + M:].view(1, M)) if r_sdY else None)
+        o, oXX, oXY, oX, oY = self._out, self._oXX, self._oXY, self._oX, self._oY
+        stats = (oX(stat[:K].view(1, K)) if r_muX else None,
+                 oX(stat[K:2 * K].view(1, K)) if r_sdX else None,
+                 oY(stat[2 * K:2 * K + M].view(1, M)) if r_muY else None,
+                 oY(stat[2 * K + M:].view(1, M)) if r_sdY else None)
         if rXTX and rXTY:
-            return (o(xtx), o(xty)), stats
-        return (o(xtx) if rXTX else o(xty)), stats
+            return (oXX(xtx), oXY(xty)), stats
+        return (oXX(xtx) if rXTX else oXY(xty)), stats
 
     def training_XTX(self, validation_indices):
         """Training-set ``XᵀWX`` for every sample except ``validation_indices`` and
@@ -1332,9 +1424,9 @@ class CVMatrix:
         # this method's own map (cvmatrix.py:570-573); surplus statistics are dropped
         _, _, (muX, sdX, muY, sdY), _ = self._run(
             batch, False, hasY, stat_flags=(r_muX, r_muY, r_sdX, r_sdY), stats_only=True)
-        o = self._out
-        return (o(muX) if r_muX else None, o(sdX) if r_sdX else None,
-                o(muY) if r_muY else None, o(sdY) if r_sdY else None)
+        o, oXX, oXY, oX, oY = self._out, self._oXX, self._oXY, self._oX, self._oY
+        return (oX(muX) if r_muX else None, oX(sdX) if r_sdX else None,
+                oY(muY) if r_muY else None, oY(sdY) if r_sdY else None)
 
     def training_statistics(self, validation_indices):
         """(mean_X, std_X, mean_Y, std_Y) of the training set; cvmatrix.py:519-574."""

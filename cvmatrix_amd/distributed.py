@@ -167,7 +167,7 @@ class ShardedCVMatrix(CVMatrix):
             # (cvmatrix.py:612-630, 1074-1078) ride in the all-reduced statistics vector
             # ([... | sw | nz]: sw = N when unweighted): fetch them without stalling ``fit`` --
             # an asynchronous copy into pinned memory, awaited by the first check that needs them
-            K, M = self.K, self.M or 0
+            K, M = self._Kd, self._Md or 0
             if self._tail_host is None:
                 self._tail_host = torch.empty(2, dtype=torch.float64, pin_memory=True)
                 self._tail_event = torch.cuda.Event()

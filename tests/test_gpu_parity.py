@@ -28,9 +28,11 @@ TOL = 1e-10
 
 @pytest.fixture(scope="module", params=["lazy_fit", "eager_fit"])
 def amd(hip_device, request):
-    """Every test runs twice: with the package default (fit() lazy: a batched call over folds that
-    partition the rows is served by one sweep) and with CVM_LAZY_FIT=0 (fit kernel, then the fold
-    update kernels), so both routes see all the cases."""
+    """Every test runs twice: with the package defaults (fit() lazy: a batched call over folds that
+    partition the rows is served by one sweep; private device copies padded to 16-byte rows, so
+    every shape takes the LDS-DMA kernels) and with CVM_LAZY_FIT=0 CVM_PAD=0 (fit kernel, then the
+    fold update kernels; the caller's shapes as they are: unaligned ones take the general kernels),
+    so both routes and both kernel families see all the cases."""
     import os
 
     import cvmatrix_amd
@@ -38,13 +40,15 @@ def amd(hip_device, request):
     from cvmatrix_amd import _lib
 
     _lib.load()  # fails loudly if the extension is missing
-    old = os.environ.get("CVM_LAZY_FIT")
+    old = {k: os.environ.get(k) for k in ("CVM_LAZY_FIT", "CVM_PAD")}
     os.environ["CVM_LAZY_FIT"] = "1" if request.param == "lazy_fit" else "0"
+    os.environ["CVM_PAD"] = "1" if request.param == "lazy_fit" else "0"
     yield cvmatrix_amd
-    if old is None:
-        os.environ.pop("CVM_LAZY_FIT", None)
-    else:
-        os.environ["CVM_LAZY_FIT"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def make_factory(amd):
