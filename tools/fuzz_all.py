@@ -23,6 +23,7 @@ def nerr(got, ref):
 
 
 worst = 0.0
+worst_what = None
 for c in range(cases):
     dt = np.float64 if rng.random() < 0.65 else np.float32
     K = int(rng.choice([5, 36, 64, 100, 128, 132, 200, 256, 260, 384, 500, 512, 516, 640]))
@@ -115,12 +116,14 @@ for c in range(cases):
             ey = nerr(by[f], ry)
             toly = 1e-10 if dt is np.float64 else 2 * nerr(sy, ry) + 2e-5
             assert ey <= toly, (what, "XTY", ey, toly)
-            if dt is np.float64:
-                worst = max(worst, ey)
-        if dt is np.float64:
-            worst = max(worst, ex)
+            if dt is np.float64 and ey > worst:
+                worst, worst_what = ey, (what, "XTY", int(f))
+        if dt is np.float64 and ex > worst:
+            worst, worst_what = ex, (what, "XTX", int(f))
         t = bx[f]
         assert bool((t == t.T).all()), (what, "symmetry")
     if c % 10 == 9:
         print(f"{c + 1} cases, worst float64 norm-wise error so far {worst:.2e}", flush=True)
 print(f"{cases} cases ok, worst float64 norm-wise error {worst:.2e}")
+if len(sys.argv) > 3:
+    print("worst case:", worst_what)
