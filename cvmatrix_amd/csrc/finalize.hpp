@@ -781,9 +781,6 @@ constexpr int SWF_EPW = SWF_T / SWF_MAX;   // XTY elements per workgroup
 #ifndef CVM_SWF_GROUP
 #define CVM_SWF_GROUP 8
 #endif
-#ifndef CVM_SWF_PIPE
-#define CVM_SWF_PIPE 0
-#endif
 constexpr int SWF_GROUP = CVM_SWF_GROUP;   // output matrices finished per barrier round
 
 // thread = (column cl of the block's 16, fold fl): the fold's column sums from its s_diag partials,
@@ -939,8 +936,8 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
       stl[f][i] = v;
     }
   }
-  // the folds' updates of this thread's piece, in split order, and their sum in fold order; the
-  // partials of fold f + 1 are requested before those of fold f are added (up to 8 at a time)
+  // the folds' updates of this thread's piece, in split order (up to 8 partials requested at a
+  // time), and their sum in fold order
   double U[SWF_MAX][VW], gsum[VW];
 #pragma unroll
   for (int e = 0; e < VW; ++e) gsum[e] = 0;
@@ -966,15 +963,11 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
 #pragma unroll
     for (int e = 0; e < VW; ++e) U[f][e] = 0;
     if (f < P) {
-      if (CVM_SWF_PIPE && nsp <= 8) {
-        if (f + 1 < P) request(f + 1, 0, qv[(f + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        add(0, qv[f & 1], U[f]);
-      } else {
-        add(0, qv[f & 1], U[f]);
-        for (int p0 = 8; p0 < nsp; p0 += 8) { request(f, p0, qv[f & 1]); add(p0, qv[f & 1], U[f]); }
-        if (f + 1 < P) request(f + 1, 0, qv[(f + 1) & 1]);
-      }
+      // (requesting fold f + 1 BEFORE fold f is added was measured slower, 25 -> 49 us: the unrolled
+      //  code with its masked tails grows past the instruction cache; tools/exp_sweepfin.sh)
+      add(0, qv[f & 1], U[f]);
+      for (int p0 = 8; p0 < nsp; p0 += 8) { request(f, p0, qv[f & 1]); add(p0, qv[f & 1], U[f]); }
+      if (f + 1 < P) request(f + 1, 0, qv[(f + 1) & 1]);
 #pragma unroll
       for (int e = 0; e < VW; ++e) gsum[e] += U[f][e];
     }
