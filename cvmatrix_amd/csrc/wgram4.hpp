@@ -258,7 +258,14 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
     auto wait_one_stage_in_flight = [&]() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); };
     int64_t rn[4];
     bool ok[4];
-    __builtin_amdgcn_s_setprio(3);
+    // (The loaders used to raise their wave priority to 3 -- a round-1 choice.  Measured in round 2
+    //  (tools/exp_prio.sh): any setting in which the loaders rank ABOVE the compute waves costs the
+    //  MFMA stream issue slots -- C3 Gram launch 0.469 ms at loader 3 / compute 0 and at 1 / 0, 0.463 at
+    //  3 / 2, 0.452-0.453 at 0 / 0, 0 / 1..3, 1 / 3, 2 / 3; C4 16.89 -> 16.29 ms, C5 28.56 -> 26.96 ms.
+    //  Everybody stays at the default priority 0.)
+#ifdef CVM_LOADER_PRIO
+    __builtin_amdgcn_s_setprio(CVM_LOADER_PRIO);
+#endif
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       row_numbers(t, rn, ok);
@@ -354,6 +361,9 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
   const int a_off = a_col + lc;
   const int b_off = h_wave ? PANEL_ELEMS + lc : (diag ? 0 : PANEL_ELEMS) + b_col + lc;
 
+#ifdef CVM_COMPUTE_PRIO
+  __builtin_amdgcn_s_setprio(CVM_COMPUTE_PRIO);
+#endif
   __syncthreads();   // B_a
   __syncthreads();   // B_-1: stage 0 is in buffer 0
 
@@ -687,6 +697,9 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   for (int n = 0; n < NBY; ++n) sy[n] = qy[n] = 0;
 
   const int lk = lane >> 4, lc = lane & 15;
+#ifdef CVM_COMPUTE_PRIO
+  __builtin_amdgcn_s_setprio(CVM_COMPUTE_PRIO);
+#endif
   __syncthreads();   // B_a
   __syncthreads();   // B_-1: stage 0 is in buffer 0
 
