@@ -170,9 +170,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
     write_lds(0);
     __syncthreads();
   }
-  // the second-dispatched half of the workgroup loses issue arbitration to the older
-  // half on every k-step (MI355X_MICROARCH "Two waves per SIMD" item 4): static priority
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // (Round 1 gave the second-dispatched half of the workgroup a static priority of 1 against the
+  //  arbitration advantage of the older half, MI355X_MICROARCH "Two waves per SIMD" item 4; measured
+  //  again in round 2 next to the LDS-DMA kernel's priorities: 1-2 % faster without it,
+  //  tools/bench_odd_k.py K=511 0.808 -> 0.797 ms, K=510 / M=15 0.719 -> 0.704 ms.)
 
 #ifdef CVM_STAMPS
   unsigned long long t_a = 0, t_b = 0, t_c = 0, t0, t1, t2, t3;
