@@ -30,6 +30,9 @@
 // One s_barrier per 16-row stage joins all eight waves.
 // ----------------------------------------------------------------------------------
 constexpr int NT4 = 512;
+#ifndef CVM_INTERLEAVE
+#define CVM_INTERLEAVE 1
+#endif
 constexpr int NBUF4 = 4;        // LDS stage buffers
 constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;   // float64; float32 uses half of it
 template <typename T> constexpr size_t lds4_bytes() { return (size_t)NBUF4 * BUF_ELEMS * sizeof(T); }
@@ -453,7 +456,29 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
 #endif
     const T *buf = smem + (s % NBUF4) * BUF_ELEMS;
     const T *nbuf = smem + ((s + 1) % NBUF4) * BUF_ELEMS;
-    if (MFM || ROLE != 0) {
+    if constexpr (CVM_INTERLEAVE && MFM && !HW && ROLE == 0) {
+      // the plain off-diagonal wave (16 MFMAs per k-step, no column sums): ONE other instruction
+      // -- an LDS fragment read of the next k-step, then its four weighting multiplies -- right
+      // behind each MFMA, the order pinned by a scheduling barrier after every pair.  The wave's
+      // other instructions then issue while the matrix pipe is busy with the MFMA in front of
+      // them; issued in two clumps per k-step they hold up the next MFMA (tools/mfma_mix.hip:
+      // 70.5 -> 72.0 TFLOP/s in isolation).
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        const T *rb = ks < 3 ? buf : nbuf;
+        const int r = 4 * (ks < 3 ? ks + 1 : 0) + lk;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          acc[i] = MF<T>::mfma(af[c][i >> 2], bf[c][i & 3], acc[i]);
+          if (i < 4) af[c ^ 1][i] = rb[a_off + r * PITCH + 16 * i];
+          else if (i < 8) bf[c ^ 1][i - 4] = rb[b_off + r * PITCH + 16 * (i - 4)];
+          else if (i == 8) wv[c ^ 1] = rb[2 * PANEL_ELEMS + r];
+          else if (WEIGHTED && i >= 11 && i < 15) af[c ^ 1][i - 11] *= wv[c ^ 1];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if (MFM || ROLE != 0) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int c = ks & 1;
@@ -743,6 +768,37 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = ks & 1;
+#if CVM_INTERLEAVE
+      // one LDS read of the next k-step right behind each MFMA, the order pinned (see the
+      // off-diagonal wave in wgram4_body): first what the weighting / column sums need (w, the two
+      // A-side fragments, the Y fragments), then the other fragments; the weighting and the sums of
+      // the next k-step behind the last MFMA.  NR = NB0 + NBY + 1 reads for NM = 9 + 2 NBY MFMAs.
+      constexpr int NR = NB0 + NBY + 1, NM = NG + 2 * NBY;
+      static_assert(NR <= NM, "more fragment reads than MFMAs in a k-step");
+      const T *rb = ks < 3 ? buf : nbuf;
+      const int r = 4 * (ks < 3 ? ks + 1 : 0) + lk;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i < NB0) acc[i] = MF<T>::mfma(aw[c][0], bf[c][i], acc[i]);
+        else if (i < NG) acc[i] = MF<T>::mfma(aw[c][1], bf[c][R1 - W + (i - NB0)], acc[i]);
+        else {
+          const int h = i - NG, n = h >> 1;                 // (row R0, Y tile n), (row R1, Y tile n)
+          if ((h & 1) == 0) acch[n] = MF<T>::mfma(aw[c][0], yf[c][n], acch[n]);
+          else acch[NBY + n] = MF<T>::mfma(aw[c][1], yf[c][n], acch[NBY + n]);
+        }
+        if (i == 0) wv[c ^ 1] = rb[2 * PANEL_ELEMS + r];
+        else if (i == 1) bf[c ^ 1][0] = rb[r * PITCH + 16 * W + lc];
+        else if (i == 2) bf[c ^ 1][R1 - W] = rb[r * PITCH + 16 * R1 + lc];
+        else if (i < 3 + NBY) yf[c ^ 1][i - 3] = rb[PANEL_ELEMS + r * YPITCH + 16 * (i - 3) + lc];
+        else if (i < NR) {
+          const int k = i - (3 + NBY);                      // the other fragments, in order
+          const int j = (k + 1 < R1 - W) ? k + 1 : k + 2;
+          bf[c ^ 1][j] = rb[r * PITCH + 16 * (W + j) + lc];
+        }
+        if (i == NM - 1) prepare(c ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -758,6 +814,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
         acch[NBY + n] = MF<T>::mfma(aw[c][1], yf[c][n], acch[NBY + n]);
       }
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     __syncthreads();   // B_s
   }

@@ -136,6 +136,32 @@ template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in
       __syncthreads();
     }
     acc[11][0] = st_s[0] + st_q[0] + st_s[1] + st_q[1];
+  } else if (V == 12 || V == 13) {
+    // one LDS read (or one multiply) right behind each MFMA, the order pinned by a scheduling barrier
+    // after every pair: the wave's other instructions issue while the matrix pipe is busy
+    // (V == 13: without the stage barrier)
+#pragma unroll 1
+    for (int s = 0; s < stages; ++s) {
+      const double* buf = smem + (s & 3) * BUF;
+      const double* nbuf = smem + ((s + 1) & 3) * BUF;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks & 1;
+        const double* rb = ks < 3 ? buf : nbuf;
+        const int r = 4 * (ks < 3 ? ks + 1 : 0) + lk;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = i >> 2, n = i & 3;
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[i], 0, 0, 0);
+          if (i < 4) af[c ^ 1][i] = rb[a_off + r * PITCH + 16 * i];
+          else if (i < 8) bf[c ^ 1][i - 4] = rb[b_off + r * PITCH + 16 * (i - 4)];
+          else if (i == 8) wv[c ^ 1] = rb[2 * PANEL + r];
+          else if (i >= 11 && i < 15) af[c ^ 1][i - 11] *= wv[c ^ 1];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (V == 12) __syncthreads();
+    }
   } else if (V == 4) {
     for (int s = 0; s < stages * 8; ++s) {
 #pragma unroll
@@ -313,6 +339,8 @@ int main() {
   run<10>(din, dout, "AccVGPR accumulators: + 4 weighting multiplies");
   run<11>(din, dout, "AccVGPR accumulators: + one barrier per stage");
   run<5>(din, dout, "same, reads and multiplies spread between the MFMAs");
+  run<12>(din, dout, "one read / multiply behind each MFMA, order pinned, + barrier");
+  run<13>(din, dout, "one read / multiply behind each MFMA, order pinned, no barrier");
   run<6>(din, dout, "as the barrier line, fragments by ds_read_b128");
   run<7>(din, dout, "diagonal tile wave 0: 11 MFMAs, 10 b64 reads per k-step", 44.0);
   run<8>(din, dout, "diagonal tile wave 0: 11 MFMAs, 6 reads (b128)", 44.0);
