@@ -59,8 +59,9 @@ bool fast_shape(int K, int M, int esize) {
 // stages times the per-stage cost of its kind plus a fixed prologue/epilogue of about one stage.
 // The constants are fitted to measured launch times of 23 split pairs at the C3 shape (11 of the
 // 10-fold sweep, 12 of the fit stage; tools/exp_splits.sh, tools/exp_fit_splits.py): the simulation
-// below reproduces them to 1.9 % rms with 2.05 us per off-diagonal stage (1.98 us since the loader
-// waves stopped outranking the compute waves, wgram4.hpp) and a diagonal tile costing 0.78 of it -- more than its 11/16 share of the MFMAs: it reads almost twice the LDS fragments per
+// below reproduces them to 1.9 % rms with 2.05 us per off-diagonal stage (1.93 us since the loader
+// waves stopped outranking the compute waves and the k-step's reads follow its MFMAs one by one,
+// wgram4.hpp) and a diagonal tile costing 0.78 of it -- more than its 11/16 share of the MFMAs: it reads almost twice the LDS fragments per
 // MFMA, and those reads are what the loop pays for beyond the matrix instructions.  Per-stage costs, in units of an off-diagonal tile's stage (16 MFMAs per wave and
 // k-step): a diagonal tile in the LDS-DMA kernel issues 9 + 2*NBY (the upper triangle of its 8x8
 // grid of MFMA tiles shared out evenly + XTY), a further-Y-chunk item keeps one wave busy with 16;
