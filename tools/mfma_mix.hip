@@ -13,6 +13,11 @@
 //      4 + 1 LDS instructions per k-step instead of 9 (the same bytes)
 //   7  the diagonal tile's wave 0: 11 MFMAs per k-step fed by 8 + 1 + 1 b64 reads
 //   8  as 7 with b128 reads (4 + 1 + 1)
+//   9-11  variants 1-3 with inline-asm MFMAs on AccVGPR accumulators (the compiler pads each: 41-53 TFLOP/s)
+//   12/13  one LDS read / multiply pinned behind each MFMA, with / without the stage barrier (72.0: what
+//          wgram4_kernel does since round 2)
+//   14  as 12 in a function the compiler treats as an AccVGPR user: it then puts the accumulators
+//       into AccVGPRs itself -- 50.6 TFLOP/s: not the way on gfx950
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/mfma_mix.hip -o tools/mfma_mix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -136,7 +141,8 @@ template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in
       __syncthreads();
     }
     acc[11][0] = st_s[0] + st_q[0] + st_s[1] + st_q[1];
-  } else if (V == 12 || V == 13) {
+  } else if (V == 12 || V == 13 || V == 14) {
+    if (V == 14) { double dummy = in[0]; asm volatile("; agpr hint %0" : "+a"(dummy)); acc[0][0] += dummy; }
     // one LDS read (or one multiply) right behind each MFMA, the order pinned by a scheduling barrier
     // after every pair: the wave's other instructions issue while the matrix pipe is busy
     // (V == 13: without the stage barrier)
@@ -160,7 +166,7 @@ template <int V> __global__ __launch_bounds__(512, 2) void kern(const double* in
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (V == 12) __syncthreads();
+      if (V == 12 || V == 14) __syncthreads();
     }
   } else if (V == 4) {
     for (int s = 0; s < stages * 8; ++s) {
@@ -341,6 +347,7 @@ int main() {
   run<5>(din, dout, "same, reads and multiplies spread between the MFMAs");
   run<12>(din, dout, "one read / multiply behind each MFMA, order pinned, + barrier");
   run<13>(din, dout, "one read / multiply behind each MFMA, order pinned, no barrier");
+  run<14>(din, dout, "the same + barrier, function marked as an AccVGPR user");
   run<6>(din, dout, "as the barrier line, fragments by ds_read_b128");
   run<7>(din, dout, "diagonal tile wave 0: 11 MFMAs, 10 b64 reads per k-step", 44.0);
   run<8>(din, dout, "diagonal tile wave 0: 11 MFMAs, 6 reads (b128)", 44.0);
