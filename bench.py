@@ -265,6 +265,21 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="override the global N (debug / tests)")
     ap.add_argument("--device-data", action="store_true",
                     help="generate the inputs on the device (default for C4)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="run ONE rank's share of a G-GPU strong-scaling job on this GPU, without a process "
+                         "group: shard_folds(labels, G, rank), the exact per-rank step (sweep of the rank's own "
+                         "folds -> fit finalize -> exchange STUB -> per-fold finalize), and print the per-rank "
+                         "breakdown.  The stub adds the other ranks' (precomputed) share of [G|H|stats] in place "
+                         "-- the arithmetic of the all-reduce's last step -- and then holds the stream for --comm-us")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="which rank of --emulate-world (0 owns the most folds)")
+    ap.add_argument("--comm-us", type=float, default=0.0,
+                    help="--emulate-world: latency of the emulated collective, held on the stream after the add")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="supplementary pipelined figure: consecutive steps alternate over this many HIP streams "
+                         "(one model per stream, the same inputs), so that a step's finalize/exchange overlaps "
+                         "the next step's sweep; 1 = skip")
+    ap.add_argument("--with-breakdown", action="store_true",
+                    help="with --headline-only: still run the per-rank breakdown and the pipelined figure")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-measure roofline.traffic with rocprofv3 child runs (two short passes, "
                          "~1 min); the figure of profiles/hbm_traffic.json is reported instead")
@@ -276,6 +291,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    emu = args.emulate_world if args.emulate_world > 1 else 0
+    if emu and world > 1:
+        sys.exit("--emulate-world runs in ONE process (no torch.distributed.run)")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
@@ -303,14 +321,19 @@ def main():
     tdt = torch.float64 if dtype is np.float64 else torch.float32
     es = np.dtype(dtype).itemsize
     strong = args.scaling == "strong"
-    mode = args.mode if (strong and world > 1) else "row_sharded"
+    if emu and not strong:
+        sys.exit("--emulate-world emulates the strong-scaling layout")
+    # the LAYOUT (which folds and rows this process holds) is that of `lay_world` ranks; `world` is
+    # the number of processes that really exchange (1 under --emulate-world)
+    lay_world, lay_rank = (emu, args.emulate_rank) if emu else (world, rank)
+    mode = args.mode if (strong and lay_world > 1) else "row_sharded"
     device_data = args.device_data or args.workload == "C4"
 
     # ---- the problem, and this rank's share of it ------------------------------------------
     X = Y = w = None
     if strong:
         labels = np.arange(N) % P                      # the folds of the WHOLE problem
-        keys, rows, local_labels = shard_folds(labels, world, rank)
+        keys, rows, local_labels = shard_folds(labels, lay_world, lay_rank)
         if mode == "replicated":
             rows_held = np.arange(N)
             part = Partitioner(labels)
@@ -319,14 +342,22 @@ def main():
             rows_held = rows
             part = Partitioner(local_labels)
             fold_lists = [part.get_validation_indices(k) for k in keys]
+        Xf = Yf = wf = None                            # (--emulate-world: the WHOLE problem, for the stub)
         if device_data:
-            Xd, Yd, wd = synth_device_rows(torch, dev, torch.from_numpy(rows_held).to(dev), N, K, M, tdt, 42)
+            if emu:
+                Xf, Yf, wf = synth_device_rows(torch, dev, torch.arange(N, device=dev), N, K, M, tdt, 42)
+                sel_d = torch.from_numpy(rows_held).to(dev)
+                Xd, Yd, wd = Xf[sel_d].contiguous(), Yf[sel_d].contiguous(), wf[sel_d].contiguous()
+            else:
+                Xd, Yd, wd = synth_device_rows(torch, dev, torch.from_numpy(rows_held).to(dev), N, K, M, tdt, 42)
         else:
             X, Y, w = synth(N, K, M, dtype, 42)
             sel = slice(None) if rows_held.size == N else rows_held
             Xd = torch.from_numpy(X[sel]).to(dev)
             Yd = torch.from_numpy(Y[sel]).to(dev)
             wd = torch.from_numpy(w[sel]).to(dev)
+            if emu:
+                Xf, Yf, wf = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev), torch.from_numpy(w).to(dev)
         total_folds_per_step = P
     else:
         keys = list(range(P))
@@ -340,27 +371,78 @@ def main():
         fold_lists = [part.get_validation_indices(k) for k in keys]
         total_folds_per_step = P * world
     if not weighted:
-        wd = None
+        wd = wf = None
     n_mine = len(fold_lists)
+
+    # ---- --emulate-world: one rank of a `emu`-rank job, the exchange replaced by a stub ------
+    class EmulatedRank(ShardedCVMatrix):
+        """ShardedCVMatrix of rank `lay_rank` in a job of `lay_world` ranks, without a process group:
+        every code path of the real multi-GPU step (world > 1) runs; the one collective is replaced by
+        its last arithmetic step -- an in-place add (row-sharded) / copy (replicated) of a buffer of
+        the same size that holds the OTHER ranks' share, computed once up front, so the results
+        are the real job's (to rounding) -- followed by --comm-us of held stream."""
+        others = None          # [G | H | gstats] of the other ranks (row-sharded) / of rank 0 (replicated)
+        sleep_cycles = 0
+
+        @property
+        def world(self):
+            return lay_world
+
+        @property
+        def rank(self):
+            return lay_rank
+
+        def _exchange(self):
+            o = EmulatedRank.others
+            if self._globals is not None:
+                self._globals.add_(o[0]) if self.mode == "row_sharded" else self._globals.copy_(o[0])
+            else:
+                for t, u in zip((self._G, self._H, self._gs), o[1:]):
+                    if t is not None:
+                        t.add_(u) if self.mode == "row_sharded" else t.copy_(u)
+            if EmulatedRank.sleep_cycles:
+                torch.cuda._sleep(EmulatedRank.sleep_cycles)
+
+    Model = EmulatedRank if emu else ShardedCVMatrix
+    if emu:
+        # the other ranks' share of the full-data matrices: (whole problem) - (this rank's rows)
+        whole = CVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, lazy_fit=False)
+        whole.fit(Xf, Yf, wf)
+        mine = CVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, lazy_fit=False)
+        if mode == "row_sharded" and Xd.shape[0]:
+            mine.fit(Xd, Yd, wd)
+            parts = [(a - b) if a is not None else None for a, b in
+                     ((whole._globals, mine._globals), (whole._G, mine._G), (whole._H, mine._H), (whole._gs, mine._gs))]
+        else:
+            parts = [None if a is None else a.clone() for a in (whole._globals, whole._G, whole._H, whole._gs)]
+        EmulatedRank.others = parts
+        if args.comm_us > 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(1000000); torch.cuda.synchronize()
+            e0.record(); torch.cuda._sleep(10000000); e1.record(); torch.cuda.synchronize()
+            EmulatedRank.sleep_cycles = int(args.comm_us * 1e-3 / e0.elapsed_time(e1) * 10000000)
+        del whole, mine
 
     # `model`: lazy fit; fit() + a batched call whose folds partition the (local) rows is served
     # by ONE sweep of the Gram kernel (full-data matrices = sum of the folds' validation
     # matrices, all-reduced over the ranks).  `eager`: fit kernel, then fold update.
     # (copy=False: the inputs are already private device tensors of this process.)
-    model = ShardedCVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, mode=mode, lazy_fit=True)
-    eager = ShardedCVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, mode=mode, lazy_fit=False)
+    model = Model(*flags, ddof=1, dtype=dtype, copy=False, device=dev, mode=mode, lazy_fit=True)
+    eager = Model(*flags, ddof=1, dtype=dtype, copy=False, device=dev, mode=mode, lazy_fit=False)
     timed_model = model if args.path == "sweep" else eager
     model.fit(Xd, Yd, wd)
     eager.fit(Xd, Yd, wd)
     batch = model.prepare_folds(fold_lists) if n_mine else None
 
-    def step_of(m):
+    def step_of(m, b=None):
+        b = batch if b is None else b
+
         def step():
             m.fit(Xd, Yd, wd)
-            if batch is None:          # more ranks than folds: take part in the exchange only
-                m._ensure_fit()
+            if b is None:              # more ranks than folds: take part in the exchange only
+                m.ensure_fit()
                 return None
-            return m.training_XTX_XTY_batched(batch)
+            return m.training_XTX_XTY_batched(b)
         return step
 
     step = step_of(timed_model)
@@ -394,6 +476,118 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- per-rank breakdown of a step (outside the timed region) -----------------------------
+    # Isolated steps (device idle before each): events on the step's stream at its start, around the
+    # exchange (ShardedCVMatrix._probe) and at its end; the Gram launch by the library's own events.
+    # host_ms = wall time of issuing the step minus the time the host spends waiting for the
+    # device inside it (the all-reduced sample counts the validity checks need, multi-GPU only).
+    def breakdown(m, b, reps=20):
+        marks, waited = {}, [0.0]
+
+        def probe(label):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks[label] = e
+
+        orig_resolve = m._resolve_totals
+
+        def resolve():
+            a = time.perf_counter()
+            orig_resolve()
+            waited[0] += time.perf_counter() - a
+
+        m._probe, m._resolve_totals = probe, resolve
+        st = step_of(m, b)
+        acc = {"host_ms": [], "host_wait_ms": [], "latency_ms": [], "sweep_and_fit_finalize_ms": [],
+               "exchange_ms": [], "fold_finalize_ms": [], "device_ms": []}
+        lib.cvm_timing_enable(1)
+        try:
+            for _ in range(reps):
+                fence()
+                marks.clear(); waited[0] = 0.0
+                e0, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                a = time.perf_counter()
+                st()
+                bt = time.perf_counter()
+                e3.record()
+                torch.cuda.synchronize()
+                ct = time.perf_counter()
+                acc["host_ms"].append((bt - a - waited[0]) * 1e3)
+                acc["host_wait_ms"].append(waited[0] * 1e3)
+                acc["latency_ms"].append((ct - a) * 1e3)
+                acc["device_ms"].append(e0.elapsed_time(e3))
+                if "exchange_begin" in marks:
+                    acc["sweep_and_fit_finalize_ms"].append(e0.elapsed_time(marks["exchange_begin"]))
+                    acc["exchange_ms"].append(marks["exchange_begin"].elapsed_time(marks["exchange_end"]))
+                    acc["fold_finalize_ms"].append(marks["exchange_end"].elapsed_time(e3))
+        finally:
+            m._probe = None
+            m._resolve_totals = orig_resolve
+        g_ms, g_n, f_ms, f_n = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+        lib.cvm_timing_read(C.byref(g_ms), C.byref(g_n), C.byref(f_ms), C.byref(f_n))
+        lib.cvm_timing_enable(0)
+        out_ = {k: round(float(np.median(v)), 4) for k, v in acc.items() if v}
+        gl = (g_ms.value + f_ms.value) / max(g_n.value + f_n.value, 1)
+        out_["gram_ms"] = round(gl, 4)
+        if "sweep_and_fit_finalize_ms" in out_:
+            out_["fit_finalize_ms"] = round(out_["sweep_and_fit_finalize_ms"] - gl, 4)
+            out_["finalize_ms"] = round(out_["fit_finalize_ms"] + out_["fold_finalize_ms"], 4)
+        else:
+            out_["finalize_ms"] = round(out_["device_ms"] - gl, 4)
+        out_["what"] = (f"median of {reps} isolated steps of this rank (device idle before each); gram_ms: the library's "
+                        "events around the Gram launch; exchange_ms: events around the collective on the step's stream; "
+                        "host_ms: issuing the step, waits for the device excluded (host_wait_ms)")
+        if world > 1:
+            for k in list(out_):
+                if k.endswith("_ms"):
+                    tt = torch.tensor([out_[k]], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    out_[k] = round(float(tt.item()), 4)
+            out_["what"] += "; max over ranks"
+        return out_
+
+    # ---- pipelined steps: consecutive steps alternate over S streams (one model each) ----------
+    def pipelined(S, steps_, warm_):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        ms_ = [Model(*flags, ddof=1, dtype=dtype, copy=False, device=dev, mode=mode, lazy_fit=(args.path == "sweep"))
+               for _ in range(S)]
+        sts = []
+        for m_, s_ in zip(ms_, streams):
+            with torch.cuda.stream(s_):
+                m_.fit(Xd, Yd, wd)
+                b_ = m_.prepare_folds(fold_lists) if n_mine else None
+                sts.append(step_of(m_, b_))
+                if b_ is None:
+                    m_.ensure_fit()
+        keep = [None] * S
+        fence()
+        for i in range(warm_):
+            with torch.cuda.stream(streams[i % S]):
+                keep[i % S] = sts[i % S]()
+        fence()
+        a = time.perf_counter()
+        for i in range(steps_):
+            with torch.cuda.stream(streams[i % S]):
+                keep[i % S] = sts[i % S]()
+        fence()
+        el = time.perf_counter() - a
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        same = None
+        if out is not None and keep[0] is not None and args.path == "sweep":
+            (ax, ay), _ = out
+            (bx_, by_), _ = keep[0]
+            same = bool(torch.equal(ax, bx_) and torch.equal(ay, by_))
+        del keep, ms_
+        return {"streams": S, "steps": steps_, "ms_per_step": round(el / steps_ * 1e3, 4),
+                "folds_per_s": round(total_folds_per_step * steps_ / el, 2),
+                "identical_to_single_stream": same,
+                "what": f"the same step, consecutive steps alternating over {S} HIP streams (one model per stream, "
+                        "the same resident inputs): a step's finalize / exchange overlaps the next step's sweep"}
+
     # split timers (outside the timed region): fit alone, fold stage alone
     def timed(fn, reps=10):
         fence()
@@ -409,6 +603,62 @@ def main():
         return ms
 
     ho = args.headline_only
+    if emu:
+        # ---- one emulated rank: breakdown, pipelined figure, parity of THIS rank's folds, one line ----
+        bd = breakdown(timed_model, batch)
+        pipe = pipelined(args.streams, args.steps, args.warmup) if args.streams > 1 else None
+        notes, ok = [], True
+        if out is not None:
+            (bx, by), bst = out
+            if not args.rows and not device_data and args.workload in ("C2", "C3"):
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    import parity_cases as pc
+                    from conftest import load_npz
+
+                    z = load_npz("g6_digest.npz")
+                    for i, f in enumerate(keys):
+                        st = tuple(None if s_ is None else s_[i] for s_ in bst)
+                        pc.check_digest(z, args.workload.lower(), int(f), bx[i], by[i], st, 1e-10)
+                    notes.append(f"folds {[int(f) for f in keys]} of this rank within 1e-10 norm-wise of the reference digests")
+                except AssertionError as e:  # pragma: no cover
+                    ok = False
+                    notes.append(f"digest FAILED: {e}")
+            # this rank's last fold against a from-scratch float64 computation over the WHOLE problem
+            vglob = torch.from_numpy(np.asarray(rows_held)[np.asarray(fold_lists[-1])]).to(dev)
+            got = (bx[-1], by[-1], None if bst[0] is None else bst[0][-1], None if bst[1] is None else bst[1][-1])
+            errs = direct_fold_check(torch, dist, 1, Xf, Yf, wf, vglob, 0, 0, 1, flags, got, dev, yardstick=(es == 4))
+            bound = 1e-10 if es == 8 else max(2 * errs[4], 1e-5)
+            bound_y = 1e-10 if es == 8 else max(2 * errs[5], 1e-5)
+            good = errs[0] <= bound and errs[1] <= bound_y and all(e <= max(bound, 1e-10) for e in errs[2:4])
+            ok = ok and good
+            notes.append(f"fold {keys[-1]} vs a from-scratch float64 computation over all {N} rows: XTX {errs[0]:.1e}, "
+                         f"XTY {errs[1]:.1e}, mean {errs[2]:.1e}, std {errs[3]:.1e}{'' if good else ' FAILED'}")
+        n_val = np.diff(batch.host_offsets).astype(np.float64) if batch is not None else np.zeros(0)
+        f_tri = float((n_val * (K * (K + 1) + 2.0 * K * M)).sum())
+        gram_ms = ms_fold.value / max(n_fold.value, 1)
+        step_ms = elapsed / args.steps * 1e3
+        ceiling = P / math.ceil(P / emu)
+        line = {
+            "emulated": True, "emulate_world": emu, "emulate_rank": lay_rank, "mode": mode, "path": args.path,
+            "workload": args.workload, "folds_of_this_rank": [int(f) for f in keys], "rows_of_this_rank": int(Xd.shape[0]),
+            "comm_us_injected": args.comm_us,
+            "per_rank_step_ms": round(step_ms, 4),
+            "predicted_job_folds_per_s": round(P / (step_ms * 1e-3), 1),
+            "scaling_ceiling_vs_1gpu": round(ceiling, 3),
+            "gram_ms_in_timed_steps": round(gram_ms, 4),
+            "gram_frac_of_mfma_peak": round(f_tri / (gram_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4) if gram_ms > 0 else None,
+            "breakdown": bd, "pipelined": pipe,
+            "steps": args.steps, "warmup": args.warmup,
+            "parity": ("ok: " if ok else "FAILED: ") + "; ".join(notes),
+            "what": (f"rank {lay_rank} of a {emu}-GPU strong-scaling job on ONE GPU, no process group: the real per-rank "
+                     "step with the collective replaced by an in-place add of the other ranks' share (+ --comm-us of "
+                     "held stream); predicted_job_folds_per_s = P / per_rank_step (the slowest rank is rank 0: it owns "
+                     "ceil(P/G) folds)"),
+            "lib": lib.cvm_version().decode(),
+        }
+        print(json.dumps(line), flush=True)
+        return line
     other = eager if timed_model is model else model
     other_step = step_of(other)
     fit_ms = fold_ms = two_ms = float("nan")
@@ -447,6 +697,13 @@ def main():
         ls2()
         loop2_ms = timed(ls2, reps=5)
 
+    # per-rank breakdown of the timed step and the pipelined figure (every rank: both contain the exchange)
+    bd = pipe = None
+    if not ho or args.with_breakdown:
+        bd = breakdown(timed_model, batch)
+        if args.streams > 1:
+            pipe = pipelined(args.streams, args.steps, min(args.warmup, 20))
+
     # ---- parity gate in the same run ---------------------------------------------------------
     # C2/C3 (host-generated inputs = the reference benchmark's): this rank's folds against the
     # reference digests (tests/golden/g6_digest.npz); every workload: one fold recomputed from
@@ -467,7 +724,7 @@ def main():
                 for res, _name in results:
                     (bx, by), bst = res
                     for i, f in enumerate(keys):
-                        if f in (0, 4, 9) or world > 1:
+                        if f in (0, 4, 9) or lay_world > 1:
                             st = tuple(None if s is None else s[i] for s in bst)
                             pc.check_digest(z, args.workload.lower(), int(f), bx[i], by[i], st, 1e-10)
                             checked.append(int(f))
@@ -634,12 +891,20 @@ def main():
                 # what the memory system must move at least when the full-data matrices stay in
                 # cache (they are the same for every fold): the outputs + the rows, G and H once
                 bts_mem = nf_ * (sz * nv_ * (k_ + m_ + 1) + 8 * nv_ + sz * k_ * (k_ + m_)) + sz * k_ * (k_ + m_)
+                # `frac` counts the bytes the memory system has to move (the counters of
+                # profiles/r*/small_folds_pmc_summary.json agree with it to a few per cent); the
+                # per-fold formula of SURVEY 8(d) also bills a read of G and H per fold, which the
+                # caches serve -- its GB/s is reported for reference, without a fraction (it is not
+                # a roofline figure: it can exceed the peak)
                 supp[name] = {"folds": nf_, "ms": round(ms1, 4), "folds_per_s": round(nf_ / ms1 * 1e3, 1),
-                              "roofline": {"bound": "hbm", "achieved": round(bts / ms1 / 1e6, 1),
+                              "roofline": {"bound": "hbm", "achieved": round(bts_mem / ms1 / 1e6, 1),
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                           "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
-                                           "bytes_per_fold": "s*n*(K+M+1) + 8n + 2*s*K*(K+M)",
-                                           "frac_if_G_is_cache_resident": round(bts_mem / ms1 / 1e6 / PEAK_HBM_GBS, 4)}}
+                                           "frac": round(bts_mem / ms1 / 1e6 / PEAK_HBM_GBS, 4),
+                                           "bytes_per_launch": "folds*(s*n*(K+M+1) + 8n + s*K*(K+M)) + s*K*(K+M): outputs and rows "
+                                                               "once per fold, G and H once per launch",
+                                           "per_fold_formula_GBps": round(bts / ms1 / 1e6, 1),
+                                           "per_fold_formula": "s*n*(K+M+1) + 8n + 2*s*K*(K+M) per fold (bills a read of G,H per fold "
+                                                               "that the caches serve: not a roofline fraction)"}}
                 del Xs, Ys, ws_, ms_, bs_
         # statistics only (training_statistics): the column-statistics kernel
         # streams the validation rows once -> HBM-bound
@@ -771,6 +1036,7 @@ def main():
             "per_fold_call_identical_to_batched": per_fold_same,
             "per_fold_call_two_stage_folds_per_s": round(total_folds_per_step / (loop2_ms * 1e-3), 1),
             "reference_protocol": proto,
+            "step_breakdown": bd, "pipelined": pipe,
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu,
             "supplementary_hbm_regime": supp,
             "lib": lib.cvm_version().decode(),

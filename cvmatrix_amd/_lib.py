@@ -60,7 +60,7 @@ def load():
                     "and there is no hipcc to rebuild it")
             print(f"cvmatrix_amd: libcvmhip.so is stale (library {have}, sources {want}); rebuilding",
                   flush=True)
-            _build.build(force=True, verbose=False)
+            _build.build(force=False, verbose=False)   # (build() re-checks the hash under its lock: one builds, the others find it current)
     lib = C.CDLL(LIB_PATH)
     vp, i64, sz, u32, dbl = C.c_void_p, C.c_int64, C.c_size_t, C.c_uint, C.c_double
     lib.cvm_version.restype = C.c_char_p

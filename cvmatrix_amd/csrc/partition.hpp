@@ -123,7 +123,10 @@ __global__ void part_offsets_kernel(const int64_t *labels, const int64_t *seq, i
   if (i >= N) return;
   const int64_t cur = labels[seq[i]];
   const int64_t prev = i > 0 ? labels[seq[i - 1]] : -1;
-  if (cur < 0 || cur >= L || prev >= L) return;      // (bad labels: the error flag is already set)
+  // bad labels (the error flag is already set; they were sorted as digit 0, so one can sit right in
+  // front of a valid row): nothing may be written for them, and a negative `prev` must not start
+  // the loop below at a negative label
+  if (cur < 0 || cur >= L || prev >= L || (i > 0 && prev < 0)) return;
   for (int64_t l = prev + 1; l <= cur; ++l) { offsets[l] = i; first[l] = (l == cur) ? seq[i] : N; }
   if (i == N - 1)
     for (int64_t l = cur + 1; l <= L; ++l) { offsets[l] = N; if (l < L) first[l] = N; }

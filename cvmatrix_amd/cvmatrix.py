@@ -41,6 +41,37 @@ MSG_NO_Y = "Response variables `Y` are not provided."
 _TORCH_DT = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}
 
 
+class _WeightsToken:
+    """Identity of one validated set of weights.  A ``FoldBatch`` remembers the token its
+    non-zero-weight counts were computed for; tokens are never reused, so a batch carried to
+    another ``CVMatrix`` (or across a refit with other weights) is recounted."""
+    __slots__ = ()
+
+
+_NO_WEIGHTS = _WeightsToken()      # unweighted: the counts are the fold sizes, whoever asks
+
+
+def _same_objects(a: list, b: list) -> bool:
+    """Do two lists hold the very same objects, in order?  (List equality compares by identity
+    first; arrays that are not identical raise on the ambiguous truth value of ``==``.)"""
+    if len(a) != len(b):
+        return False
+    try:
+        return a == b and all(x is y for x, y in zip(a[:4], b[:4]))
+    except ValueError:
+        return False
+
+
+def _same_indices(v: np.ndarray, seg: np.ndarray) -> bool:
+    """Does the caller's index array hold exactly what the private copy ``seg`` holds?  (The exact
+    comparison behind every served loop: 7 us for 10 000 indices, 0.2 us for 100.)"""
+    if v.size != seg.size:
+        return False
+    if v.dtype == seg.dtype and v.ndim == 1 and v.flags.c_contiguous:
+        return v.tobytes() == seg.tobytes()
+    return bool(np.array_equal(v.reshape(-1), seg))
+
+
 def _resolve_backend(backend: str) -> str:
     """Counterpart of cvmatrix.py:58-96 for this package: the only backend is "hip"."""
     if backend == "hip":
@@ -115,7 +146,7 @@ class FoldBatch:
 class _ReadAhead:
     """State of a read-ahead over a Partitioner's folds (CVMatrix._ra_*)."""
     __slots__ = ("p", "arrs", "n", "batch", "key", "pos", "start", "count", "chunk", "max_chunk", "xtx", "xty",
-                 "stats", "need_stats", "need_std", "bad_zero", "bad_ddof", "sizes", "first", "last", "sums")
+                 "stats", "need_stats", "need_std", "bad_zero", "bad_ddof", "sizes", "first", "lo", "hidx")
 
 
 class CVMatrix:
@@ -137,6 +168,7 @@ class CVMatrix:
         device: Union[None, str, int, torch.device] = None,
         lazy_fit: Optional[bool] = None,
         output: str = "torch",
+        serve_loops: Optional[bool] = None,
     ) -> None:
         # ``lazy_fit=None`` (default): ``fit`` may defer its arithmetic to the first use only
         # when the object owns private copies of its inputs (``copy=True``, like the reference's
@@ -148,6 +180,16 @@ class CVMatrix:
             env = os.environ.get("CVM_LAZY_FIT")
             lazy_fit = bool(copy) if env is None else env != "0"
         self.lazy_fit = bool(lazy_fit)
+        # ``serve_loops`` (default on; CVM_SERVE_LOOPS=0/1 overrides the default): recognise the
+        # reference's one-call-per-fold loop over a ``Partitioner``'s own index arrays and serve it
+        # from one sweep / a read-ahead / the uploaded indices of an earlier pass.  Every such
+        # short cut compares the caller's array EXACTLY with the private copy the batch was built
+        # from before anything is handed out; ``serve_loops=False`` turns them all off: every call
+        # then gathers from whatever the array holds and launches its own kernels, like
+        # cvmatrix.py:924-941.
+        if serve_loops is None:
+            serve_loops = os.environ.get("CVM_SERVE_LOOPS", "1") != "0"
+        self.serve_loops = bool(serve_loops)
         # ``output="numpy"``: every result (matrices, statistics, the XTX/XTY/sum_* attributes)
         # is returned as a NumPy array like the reference's backend="numpy"; "torch" (default)
         # leaves results on the device, like the reference's backend="jax" returns jax.Array
@@ -193,14 +235,14 @@ class CVMatrix:
         self._sweep = None
         self._sweep_cache = None
         self._ra = None                                 # read-ahead of a per-fold loop (_ReadAhead)
-        self._pbatches = weakref.WeakKeyDictionary()   # Partitioner -> (FoldBatch, fingerprints)
+        self._pbatches = weakref.WeakKeyDictionary()   # Partitioner -> FoldBatch (uploaded indices)
         self._sweep_ws = None
         self._sweep_ids = None
         self._auto_sweep_tried = None
         self.sweep_folds = None
         self._w_checked = None
         self._w_checked_src = None
-        self._w_gen = 0          # bumped whenever the validated weights change
+        self._w_gen = _NO_WEIGHTS  # token of the validated weights (a new object whenever they change)
         self._np_cache = {}
         self._small_ws_key = None
         self._small_ws_bytes = 0
@@ -328,6 +370,11 @@ class CVMatrix:
     def _launch_fit(self, lib) -> None:
         """The fit-stage kernel over all rows (cvm_gram_fit)."""
         M = self._Md or 0
+        if self.N == 0:
+            # no rows (a rank of a multi-GPU job that owns none): the matrices of nothing are
+            # zeros -- no kernel, and the exchange that follows still takes place
+            self._zero_globals()
+            return
         neg = torch.empty(1, dtype=torch.int32, device=self.device)   # always written by fit_stats_kernel
         ws = self._workspace(lib.cvm_fit_workspace_bytes(self.N, self._Kd, M, self._cdt))
         rc = lib.cvm_gram_fit(
@@ -338,6 +385,12 @@ class CVMatrix:
         )
         _lib.check(rc, "cvm_gram_fit")
         self._neg = neg
+
+    def _zero_globals(self) -> None:
+        for t in ((self._globals,) if self._globals is not None else (self._G, self._H, self._gs)):
+            if t is not None:
+                t.zero_()
+        self._neg = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def _after_globals(self) -> None:
         """Hook: the full-data matrices of this process have just been launched (multi-GPU
@@ -354,7 +407,7 @@ class CVMatrix:
         # worth it when the folds are large: the sweep saves one pass of the Gram kernel over all
         # rows and costs a write + read of every fold's K x (K+M) partials (about 256 rows of
         # Gram work per fold at float64); small folds have their own direct route anyway
-        worth = (batch.n_folds > 0 and int(sizes.min()) > 32 and self.N >= 256 * batch.n_folds
+        worth = (batch.n_folds > 0 and self.N > 0 and int(sizes.min()) > 32 and self.N >= 256 * batch.n_folds
                  and lib.cvm_sweep_workspace_bytes(batch.n_folds, int(sizes.max()), self._Kd, self._Md or 0,
                                                    self._cdt) <= (4 << 30))
         return bool(worth and batch._n_rows == self.N and batch.is_partition)
@@ -481,7 +534,7 @@ class CVMatrix:
                     raise ValueError("weights must have shape (N,) or (N, 1)")
             else:
                 if self.weights is not None or self._w_host is not None:
-                    self._w_gen += 1
+                    self._w_gen = _NO_WEIGHTS
                 self.weights, self._w_host, self._w_checked, self._w_checked_src = None, None, None, None
             M = self._Md or 0
             self._alloc_globals(lib.cvm_gstats_len(self._Kd, M))
@@ -546,12 +599,14 @@ class CVMatrix:
         self._sweep_cache = None
         self.sweep_folds = batch
         # the folds of a Partitioner can later be asked for one at a time with the very arrays it
-        # holds (the reference's loop): remember them by identity + a cheap fingerprint
+        # holds (the reference's loop): remember them by identity; what such an array holds at the
+        # time of the call is compared exactly with the batch's private copy (_sweep_fold_of)
         src = batch._source
         self._sweep_ids = None
-        if src is not None and len(src._fold_arrays) == batch.n_folds:
+        if (self.serve_loops and src is not None and batch._host_idx is not None
+                and len(src._fold_arrays) == batch.n_folds):
             arrs = src._fold_arrays
-            self._sweep_ids = ({id(a): i for i, a in enumerate(arrs)}, [self._fingerprint(a) for a in arrs], arrs)
+            self._sweep_ids = ({id(a): i for i, a in enumerate(arrs)}, arrs)
 
     @staticmethod
     def _weights_key(w):
@@ -566,7 +621,7 @@ class CVMatrix:
         kept referenced so its address cannot be recycled by another tensor), is not read again."""
         if isinstance(weights, torch.Tensor) and weights.device.type != "cpu":
             key = self._weights_key(weights)
-            if (weights is self._w_checked_src and key == self._w_checked
+            if (self.serve_loops and weights is self._w_checked_src and key == self._w_checked
                     and self._w_host is not None):
                 return
             h = weights.detach().reshape(-1).cpu().numpy()
@@ -580,7 +635,7 @@ class CVMatrix:
             raise ValueError(MSG_NEG_W)
         self._w_host = np.array(h, dtype=self._npdt, copy=True)
         self._w_checked, self._w_checked_src = key, src
-        self._w_gen += 1
+        self._w_gen = _WeightsToken()
 
     def _publish_stats(self) -> None:
         """Host-side totals used by the per-fold validity checks.  ``_n_total`` /
@@ -591,7 +646,7 @@ class CVMatrix:
         if self.weights is None:
             self._nz_total = self.N
         else:
-            if self._nz_total_gen != self._w_gen:          # (once per set of weights, not per fit)
+            if self._nz_total_gen is not self._w_gen:      # (once per set of weights, not per fit)
                 self._nz_total_w, self._nz_total_gen = int(np.count_nonzero(self._w_host)), self._w_gen
             self._nz_total = self._nz_total_w
 
@@ -675,10 +730,11 @@ class CVMatrix:
             raise IndexError(f"validation index out of bounds for {self.N} samples")
         return np.where(v < 0, v + self.N, v) if v.min() < 0 else v
 
-    def prepare_folds(self, folds) -> FoldBatch:
+    def prepare_folds(self, folds, _trust_cached: bool = False) -> FoldBatch:
         """Upload validation indices of many folds once (CSR) and pre-compute the per-fold
         non-zero weight counts on the host.  ``folds``: a ``Partitioner``, or a sequence of
-        index arrays."""
+        index arrays.  (``_trust_cached``: internal -- the caller compares every fold's array
+        with the batch's private copy itself before it uses that fold.)"""
         if self.X is None:
             raise RuntimeError("call fit() first")
         if isinstance(folds, FoldBatch):
@@ -688,19 +744,21 @@ class CVMatrix:
                 raise ValueError(
                     f"this FoldBatch was prepared for {folds._n_rows} samples, the fitted "
                     f"data has {self.N}: prepare the folds again after fit()")
-            if folds._w_gen != self._w_gen:
+            if folds._w_gen is not self._w_gen:
                 folds.nz_val = self._nz_counts(folds)
                 folds._w_gen = self._w_gen
             return folds
         labels = None
         source = None
         if isinstance(folds, Partitioner):
-            cached = self._cached_partitioner_batch(folds)
+            cached = self._cached_partitioner_batch(folds, _trust_cached)
             if cached is not None:
                 return self.prepare_folds(cached)      # (row count / weights checks of a FoldBatch)
             source = folds
             labels = list(folds.folds_dict)
             folds = list(folds.folds_dict.values())
+            if not _same_objects(folds, source._fold_arrays):
+                source = None       # folds_dict was reassigned after construction: a plain list of arrays
         if not isinstance(folds, (list, tuple)):
             folds = list(folds)
         if folds and all(type(v) is np.ndarray and v.ndim == 1 and v.dtype.kind in "iu" for v in folds):
@@ -759,20 +817,33 @@ class CVMatrix:
         fb = FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N, w_gen=self._w_gen)
         fb._source = source
         fb._device = self.device
-        if source is not None and len(parts) <= 4096:
+        if self.serve_loops and source is not None and len(parts) <= 4096:
             # the same Partitioner again (a fit + per-fold loop repeated, another model on the same
-            # folds): the uploaded indices are reused while its arrays still hold what they held
-            self._pbatches[source] = (fb, [self._fingerprint(a) for a in source._fold_arrays])
+            # folds): the uploaded indices are reused while its arrays still hold EXACTLY what the
+            # private host copy of the batch holds (_cached_partitioner_batch)
+            self._pbatches[source] = fb
         return fb
 
-    def _cached_partitioner_batch(self, p) -> Optional[FoldBatch]:
-        ent = self._pbatches.get(p)
-        if ent is None:
+    def _cached_partitioner_batch(self, p, trust: bool = False) -> Optional[FoldBatch]:
+        """The uploaded batch of an earlier ``prepare_folds(p)``, if ``p``'s arrays still hold
+        what they held then -- an exact comparison with the batch's private host copy (one
+        comparison of the whole index matrix for equal folds, else fold by fold).  ``trust``: the
+        caller makes that comparison itself, per fold, at the time each fold is used."""
+        fb = self._pbatches.get(p) if self.serve_loops else None
+        if fb is None:
             return None
-        fb, prints = ent
         arrs = p._fold_arrays
-        if (fb._n_rows != self.N or fb._device != self.device or len(arrs) != len(prints)
-                or any(self._fingerprint(a) != q for a, q in zip(arrs, prints))):
+        ok = (fb._n_rows == self.N and fb._device == self.device and len(arrs) == fb.n_folds
+              and fb._host_idx is not None and _same_objects(list(p.folds_dict.values()), arrs))
+        if ok and not trust:
+            hidx, ho = fb._host_idx, fb.host_offsets
+            b = p._base
+            if (b is not None and p._starts is None and b.ndim == 2 and b.shape[0] == len(arrs)
+                    and b.flags.c_contiguous and b.size == hidx.size):
+                ok = _same_indices(b.reshape(-1), hidx)
+            else:
+                ok = all(_same_indices(a, hidx[ho[i]:ho[i + 1]]) for i, a in enumerate(arrs))
+        if not ok:
             del self._pbatches[p]
             return None
         return fb
@@ -823,7 +894,13 @@ class CVMatrix:
                                                             dtype=np.int64)).to(dev)
             if lab.numel() != self.N:
                 raise ValueError("one fold label per row is needed")
-            L = int(n_labels) if n_labels is not None else int(lab.max().item()) + 1
+            # one read-back for both ends: labels outside [0, L) are refused here, before any
+            # kernel sorts them (partition.hpp only flags them)
+            lo_hi = torch.stack(torch.aminmax(lab)).cpu() if self.N else torch.zeros(2, dtype=torch.int64)
+            lab_lo, lab_hi = int(lo_hi[0]), int(lo_hi[1])
+            L = int(n_labels) if n_labels is not None else lab_hi + 1
+            if lab_lo < 0 or lab_hi >= L:
+                raise ValueError(f"fold labels must be integers in [0, {L})")
             if 1 <= L <= self.N:
                 # the strided folds of the reference's benchmark (benchmarks/benchmark.py:232) and
                 # leave-one-out: row r is the (r // L)-th row of fold r % L -- no sort needed
@@ -1086,7 +1163,10 @@ class CVMatrix:
             p = partitioner_of(v)
             if p is not None and p is not self._auto_sweep_tried:
                 self._auto_sweep_tried = p          # (one attempt per fit and Partitioner)
-                batch = self.prepare_folds(p)
+                # (an uploaded batch of an earlier pass is taken as it is: whatever a fold's array
+                #  holds NOW is compared with the batch's private copy below, call by call; the
+                #  full-data matrices are the same for any partition of the rows)
+                batch = self.prepare_folds(p, _trust_cached=True)
                 lib = _lib.load()
                 K, M = self._Kd, self._Md or 0
                 if (not self._exchanges_globals() and batch.n_folds <= 16 and self._sweep_worth(lib, batch)
@@ -1107,20 +1187,13 @@ class CVMatrix:
         if ids is None or self._sweep is None:
             return None
         i = ids[0].get(id(v))
-        if i is None or ids[2][i] is not v:
+        if i is None or ids[1][i] is not v:
             return None
-        if self._fingerprint(v) != ids[1][i]:
-            return None                             # the array was changed since the sweep: recompute
+        batch = self._sweep[0]
+        ho = batch.host_offsets
+        if batch._host_idx is None or not _same_indices(v, batch._host_idx[ho[i]:ho[i + 1]]):
+            return None         # the array no longer holds what the sweep gathered: the ordinary route
         return i
-
-    @staticmethod
-    def _fingerprint(a: np.ndarray):
-        """Cheap witness that an index array still holds what it held when a sweep read it: size,
-        both ends and the sum of ~60 evenly spaced elements."""
-        n = a.size
-        if n == 0:
-            return (0, -1, -1, 0)
-        return (n, int(a[0]), int(a[-1]), int(a[::max(1, n // 61)].sum()))
 
     def _training_matrices(self, return_XTX: bool, return_XTY: bool, val_indices):
         """cvmatrix.py:754-896 for one fold."""
@@ -1130,6 +1203,13 @@ class CVMatrix:
             raise ValueError(MSG_NO_Y)
         if self.X is not None:
             v = val_indices
+            if not self.serve_loops:
+                # no loop serving: the small-fold short cut (a plain launch, nothing remembered) or
+                # the one-fold batched call
+                if (type(v) is np.ndarray and v.ndim == 1 and 0 < v.size <= 32 and v.dtype == np.int64
+                        and v.flags.c_contiguous):
+                    return self._one_small_fold(v, return_XTX, return_XTY)
+                return self._first(self._training_matrices_batched(return_XTX, return_XTY, [v]))
             ra = self._ra
             if ra is not None and ra.key == (return_XTX, return_XTY):
                 # a per-fold loop over a Partitioner with many folds is being read ahead
@@ -1173,7 +1253,9 @@ class CVMatrix:
             return False
         if rXTY and self.Y is None:
             return False
-        batch = self.prepare_folds(p)
+        batch = self.prepare_folds(p, _trust_cached=True)   # (every fold is compared exactly when served)
+        if batch._host_idx is None:
+            return False
         if self._sweep_worth(_lib.load(), batch) and not self._exchanges_globals():
             return False                            # (the sweep serves this loop)
         if self._sweep is not None and self._sweep[0] is batch:
@@ -1219,22 +1301,14 @@ class CVMatrix:
                 nz_train = self._n_total - full.sizes[a:b]
             if ra.need_std:
                 ra.bad_ddof = (nz_train <= self.ddof).tolist()
-        # witnesses of the index arrays as they were when the chunk was computed
-        hidx = full._host_idx
+        # what the chunk was computed from: this stretch of the batch's private copy of the indices
+        # (_ra_serve compares the caller's array with its fold's piece, exactly)
         o = ho[a:b + 1]
-        seg = hidx[o[0]:o[-1]]
-        sizes = np.diff(o)
-        ra.sizes = sizes.tolist()
-        nonempty = sizes > 0
-        first = np.zeros(b - a, dtype=np.int64)
-        last = np.zeros(b - a, dtype=np.int64)
-        sums = np.zeros(b - a, dtype=np.int64)
-        if seg.size:
-            rel = (o[:-1] - o[0])
-            first[nonempty] = seg[rel[nonempty]]
-            last[nonempty] = seg[(o[1:] - o[0] - 1)[nonempty]]
-            sums[nonempty] = np.add.reduceat(seg, rel[nonempty])
-        ra.first, ra.last, ra.sums = first.tolist(), last.tolist(), sums.tolist()
+        ra.lo = o.tolist()
+        ra.sizes = np.diff(o).tolist()
+        seg = full._host_idx[o[0]:o[-1]]
+        ra.first = seg[(o[:-1] - o[0]).clip(max=max(seg.size - 1, 0))].tolist() if seg.size else [0] * (b - a)
+        ra.hidx = full._host_idx
         ra.start, ra.count = a, b - a
         ra.chunk = min(ra.max_chunk, ra.chunk * 2)
 
@@ -1244,8 +1318,8 @@ class CVMatrix:
             self._ra_fill(ra)
             j = 0
         n = v.size
-        if n != ra.sizes[j] or (n and (int(v[0]) != ra.first[j] or int(v[-1]) != ra.last[j]
-                                       or (n > 2 and int(v.sum()) != ra.sums[j]))):
+        if n != ra.sizes[j] or (n == 1 and int(v[0]) != ra.first[j]) or (
+                n > 1 and not _same_indices(v, ra.hidx[ra.lo[j]:ra.lo[j + 1]])):
             return None                             # changed in place since the chunk was computed
         if ra.need_stats:
             if ra.bad_zero is not None and ra.bad_zero[j]:
@@ -1301,7 +1375,9 @@ class CVMatrix:
                  | (_lib.SCALE_X if sX else 0) | (_lib.SCALE_Y if sY else 0) | _lib.IDX_HOST)
         dev, dt = self.device, self._tdt
         if torch.cuda.current_device() != dev.index:
-            torch.cuda.set_device(dev)
+            # (a model on another GPU than the caller's current one: the caller's device is restored)
+            with torch.cuda.device(dev):
+                return self._one_small_fold(v, rXTX, rXTY)
         xtx = torch.empty((K, K), dtype=dt, device=dev) if rXTX else None
         xty = torch.empty((K, M), dtype=dt, device=dev) if rXTY else None
         stat = torch.empty(2 * K + 2 * M, dtype=dt, device=dev)
@@ -1370,7 +1446,8 @@ class CVMatrix:
                  | (_lib.SCALE_X if sX else 0) | (_lib.SCALE_Y if sY else 0))
         dev, dt = self.device, self._tdt
         if torch.cuda.current_device() != dev.index:
-            torch.cuda.set_device(dev)
+            with torch.cuda.device(dev):
+                return self._finish_sweep_fold(i, rXTX, rXTY)
         xtx = torch.empty((K, K), dtype=dt, device=dev) if rXTX else None
         xty = torch.empty((K, M), dtype=dt, device=dev) if rXTY else None
         stat = torch.empty(2 * K + 2 * M, dtype=dt, device=dev)

@@ -114,7 +114,20 @@ class ShardedCVMatrix(CVMatrix):
 
     mode="row_sharded": ``fit`` receives THIS RANK'S rows; fold indices passed to
     ``training_*`` are local row numbers of this rank.  mode="replicated": ``fit`` receives
-    all rows on every rank; use ``my_folds`` to pick this rank's share of the folds."""
+    all rows on every rank; use ``my_folds`` to pick this rank's share of the folds.
+
+    The path has ONE exchange per fit -- the all-reduce (row-sharded) or broadcast (replicated) of
+    ``[G | H | gstats]`` -- and every rank must enter it:
+
+    * default (``lazy_fit=False``): the exchange happens inside ``fit``; every rank calls ``fit``
+      (a rank that owns no rows passes zero-row arrays: it contributes zeros, runs no kernel and
+      still takes part);
+    * ``lazy_fit=True``: the exchange moves to the first call that needs the full-data matrices
+      (``training_*``, ``training_*_batched``, ``XTX`` ...).  EVERY rank must then make such a
+      call after every ``fit`` -- a rank without folds calls ``ensure_fit()`` -- or the others
+      wait in the collective for ever.  Nothing can detect a rank that does not call (that is what
+      a collective is); this mode is for loops like bench.py's, where all ranks run the same
+      program."""
 
     def __init__(self, *args, mode: str = "row_sharded", group=None, src: int = 0, lazy_fit: bool = False,
                  **kw):
@@ -126,6 +139,11 @@ class ShardedCVMatrix(CVMatrix):
         self.mode, self.group, self.src = mode, group, src
         self._tail_host = self._tail_event = None
         self._tail_pending = False
+        self._probe = None      # bench.py: callable(label) at "exchange_begin" / "exchange_end"
+
+    def ensure_fit(self) -> None:
+        """Take part in a pending lazy exchange (a rank that has no fold to ask for)."""
+        self._ensure_fit()
 
     @property
     def world(self) -> int:
@@ -161,8 +179,13 @@ class ShardedCVMatrix(CVMatrix):
         like (no collective may depend on rank-local state)."""
         if self.world == 1:
             return
+        probe = self._probe
+        if probe is not None:
+            probe("exchange_begin")
+        self._exchange()
+        if probe is not None:
+            probe("exchange_end")
         if self.mode == "row_sharded":
-            allreduce_globals(self._G, self._H, self._gs, self.group, flat=self._globals)
             # the global sample / non-zero-weight counts for the host-side validity checks
             # (cvmatrix.py:612-630, 1074-1078) ride in the all-reduced statistics vector
             # ([... | sw | nz]: sw = N when unweighted): fetch them without stalling ``fit`` --
@@ -175,6 +198,11 @@ class ShardedCVMatrix(CVMatrix):
                 self._tail_host.copy_(self._gs[2 * K + 2 * M: 2 * K + 2 * M + 2], non_blocking=True)
                 self._tail_event.record()
             self._tail_pending = True
+
+    def _exchange(self) -> None:
+        """The collective itself (on the current stream's NCCL/RCCL ordering)."""
+        if self.mode == "row_sharded":
+            allreduce_globals(self._G, self._H, self._gs, self.group, flat=self._globals)
         else:
             broadcast_globals(self._G, self._H, self._gs, self.src, self.group, flat=self._globals)
 

@@ -8,6 +8,7 @@ offsets, the layout ``cvm_fold_update`` (include/cvmhip.h) consumes."""
 
 from __future__ import annotations
 
+import threading
 import weakref
 from collections.abc import Hashable
 from typing import Iterable, Optional, Tuple
@@ -27,12 +28,16 @@ _REGISTER_MAX_FOLDS = 4096
 # labels: every fold is a row of a matrix or a slice of the sorted order): any number of folds at
 # one registry entry; the fold's position follows from its address.
 _BASE_OWNER: "weakref.WeakValueDictionary[int, Partitioner]" = weakref.WeakValueDictionary()
+# both registries are process-wide and Partitioners may be built and looked up from several threads
+# (one model per thread and stream): every access goes through this lock
+_REG_LOCK = threading.Lock()
 
 
 def partitioner_pos(indices):
     """(Partitioner, position of the fold in its ``folds_dict`` order) if ``indices`` is the very
     array object a live Partitioner holds for one of its folds, else (None, None)."""
-    p = _OWNER.get(id(indices))
+    with _REG_LOCK:
+        p = _OWNER.get(id(indices))
     if p is not None:
         pos = p._fold_pos.get(id(indices))
         if pos is not None and p._fold_arrays[pos] is indices:
@@ -41,7 +46,8 @@ def partitioner_pos(indices):
     b = getattr(indices, "base", None)
     if b is None:
         return None, None
-    p = _BASE_OWNER.get(id(b))
+    with _REG_LOCK:
+        p = _BASE_OWNER.get(id(b))
     if p is None or p._base is not b:
         return None, None
     pos = p._pos_from_address(indices)
@@ -79,17 +85,19 @@ class Partitioner:
             b = getattr(self._fold_arrays[0], "base", None)
             if b is not None and all(getattr(a, "base", None) is b for a in self._fold_arrays[:3]):
                 self._base = b
-                _BASE_OWNER[id(b)] = self
+                with _REG_LOCK:
+                    _BASE_OWNER[id(b)] = self
         if self._base is None and len(self._fold_arrays) <= _REGISTER_MAX_FOLDS:
             # folds that are arrays of their own (labels of any hashable kind): one entry each
-            for i, a in enumerate(self._fold_arrays):
-                self._fold_pos[id(a)] = i
-                _OWNER[id(a)] = self
+            with _REG_LOCK:
+                for i, a in enumerate(self._fold_arrays):
+                    self._fold_pos[id(a)] = i
+                    _OWNER[id(a)] = self
 
     def _pos_from_address(self, a) -> Optional[int]:
         b = self._base
         off = a.__array_interface__["data"][0] - b.__array_interface__["data"][0]
-        if self._addr_pos is None:      # (built on first use: start of every fold inside the base -> position)
+        if self._addr_pos is None:      # (built on first use; two threads may both build it: same dict)
             sizes = np.fromiter((f.size for f in self._fold_arrays), dtype=np.int64, count=len(self._fold_arrays))
             if self._starts is None:    # rows of a matrix, in order
                 st = np.zeros(sizes.size, dtype=np.int64)

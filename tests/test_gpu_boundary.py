@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_normwise, assert_stats
+from conftest import assert_normwise, assert_stats, to_np
 from oracle.cvmatrix_oracle import OracleCVMatrix, OraclePartitioner
 
 pytestmark = pytest.mark.gpu
@@ -223,8 +223,7 @@ def test_reference_loop_is_served_from_one_sweep(amd, hip_device):
     assert m._sweep_fold_of(v2) == 1
     other = int(p.get_validation_indices(keys[0])[5])
     v2[v2.size // 2] = other                          # a row of another fold, in the middle
-    if m._fingerprint(v2) != m._fingerprint(saved):   # (the witness samples ~60 positions)
-        assert m._sweep_fold_of(v2) is None
+    assert m._sweep_fold_of(v2) is None               # (exact comparison: any change is seen)
     v2[:] = saved
     # folds that do not partition the rows: no sweep, the fit kernel runs
     q = amd.Partitioner(np.arange(N) % 5)
@@ -323,3 +322,193 @@ def test_per_fold_loop_over_many_folds_is_read_ahead(amd, N, K, M, labels_kind, 
                     m2.training_XTX(v)
             else:
                 m2.training_XTX(v)
+
+
+def _oracle_fold(X, Y, w, v, dtype=np.float64):
+    from oracle.cvmatrix_oracle import OracleCVMatrix
+
+    o = OracleCVMatrix(dtype=dtype)
+    o.fit(X, Y, w)
+    return o.training_XTX_XTY(np.array(v, copy=True))
+
+
+@pytest.mark.parametrize("route", ["sweep_loop", "sweep_loop_second_pass", "cached_batch", "read_ahead"])
+@pytest.mark.parametrize("change", ["one_interior_index", "sum_preserving_pair"])
+def test_indices_changed_in_place_are_never_served_stale(amd, route, change):
+    """cvmatrix.py:924-941 gathers from whatever the index array holds at the time of the call.  The
+    loop-serving short cuts (one sweep for all folds of a Partitioner, the uploaded batch of an
+    earlier pass, the read-ahead over many folds) compare the caller's array EXACTLY with the
+    private copy their results were computed from: ONE interior index changed in place -- at a
+    position no sampled witness would look at -- or two indices changed so that size, both ends and
+    the sum stay what they were, and the call returns the oracle's matrices of the NEW indices."""
+    rng = np.random.default_rng(77)
+    if route == "read_ahead":
+        N, K, M, P = 4000, 40, 3, 40           # > 16 folds of 100 rows: the read-ahead serves the loop
+    else:
+        N, K, M, P = 6000, 64, 3, 6            # few large folds: one sweep serves the loop
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N) + 0.01
+    p = amd.Partitioner(np.arange(N) % P)
+    keys = list(p.folds_dict)
+    m = amd.CVMatrix()
+    m.fit(X, Y, w)
+    for k in keys[:2]:
+        m.training_XTX_XTY(p.get_validation_indices(k))       # the loop is being served
+    if route == "read_ahead":
+        assert m._ra is not None
+    else:
+        assert m._sweep is not None and m._sweep_ids is not None
+    if route in ("sweep_loop_second_pass", "cached_batch"):
+        for k in keys[2:]:
+            m.training_XTX_XTY(p.get_validation_indices(k))
+        m.fit(X, Y, w)                                       # a second pass: the uploaded batch is kept
+        assert p in m._pbatches
+    v = p.get_validation_indices(keys[2])
+    saved = v.copy()
+    n = v.size
+    j = n // 2 + 1                                           # (not a multiple of n // 61, not an end)
+    assert j % max(1, n // 61) != 0 or n < 122
+    if change == "one_interior_index":
+        v[j] = int(p.get_validation_indices(keys[3])[7])     # a row of another fold
+    else:
+        # two entries replaced by rows of the neighbouring folds: size, both ends and the sum unchanged
+        v[j], v[j + 2] = int(v[j]) + 1, int(v[j + 2]) - 1
+        assert int(v.sum()) == int(saved.sum()) and v[0] == saved[0] and v[-1] == saved[-1]
+    try:
+        if route == "cached_batch":
+            (bx, by), bst = m.training_XTX_XTY_batched(p)    # every fold of the Partitioner, as it is NOW
+            xtx, xty, st = bx[2], by[2], tuple(s[2] for s in bst)
+        else:
+            (xtx, xty), st = m.training_XTX_XTY(v)
+        (rx, ry), rst = _oracle_fold(X, Y, w, v)
+        assert_normwise(xtx, rx, 1e-10, f"{route}/{change} XTX")
+        assert_normwise(xty, ry, 1e-10, f"{route}/{change} XTY")
+        assert_stats(st, rst, 1e-10, f"{route}/{change}")
+        # and it is NOT the old fold's result
+        (ox, _), _ = _oracle_fold(X, Y, w, saved)
+        assert np.abs(to_np(xtx) - ox).max() > 1e-8 * np.abs(ox).max()
+    finally:
+        v[:] = saved
+    # restored: served again, the old result
+    (xtx, _), _ = m.training_XTX_XTY(v)
+    (ox, _), _ = _oracle_fold(X, Y, w, saved)
+    assert_normwise(xtx, ox, 1e-10, "restored")
+
+
+def test_serve_loops_off_recomputes_every_call(amd, monkeypatch):
+    """``CVMatrix(serve_loops=False)`` / CVM_SERVE_LOOPS=0: no sweep for the loop, no read-ahead, no
+    kept batches, no weights identity cache -- every call launches its own kernels on what it is
+    handed; same results to rounding."""
+    rng = np.random.default_rng(5)
+    N, K, M, P = 3000, 48, 2, 5
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N) + 0.01
+    p = amd.Partitioner(np.arange(N) % P)
+    monkeypatch.setenv("CVM_SERVE_LOOPS", "0")
+    assert amd.CVMatrix().serve_loops is False
+    monkeypatch.delenv("CVM_SERVE_LOOPS")
+    on, off = amd.CVMatrix(), amd.CVMatrix(serve_loops=False)
+    assert on.serve_loops is True
+    on.fit(X, Y, w); off.fit(X, Y, w)
+    for k in p.folds_dict:
+        v = p.get_validation_indices(k)
+        (a, b), sa = on.training_XTX_XTY(v)
+        (c, d), sc = off.training_XTX_XTY(v)
+        assert off._sweep is None and off._ra is None and off._sweep_ids is None and len(off._pbatches) == 0
+        assert_normwise(c, to_np(a), 1e-11, "serve_loops=False XTX")
+        assert_normwise(d, to_np(b), 1e-11, "serve_loops=False XTY")
+        (rx, ry), rst = _oracle_fold(X, Y, w, v)
+        assert_normwise(c, rx, 1e-10, "vs oracle")
+        assert_stats(sc, rst, 1e-10, "vs oracle")
+    off.training_XTX_XTY_batched(p)
+    assert len(off._pbatches) == 0
+    q = amd.Partitioner(np.arange(N) % 600)                  # many small folds: no read-ahead either
+    for k in list(q.folds_dict)[:20]:
+        off.training_XTX(q.get_validation_indices(k))
+        assert off._ra is None
+
+
+def test_partitioner_folds_dict_reassigned_after_construction(amd):
+    """A Partitioner whose ``folds_dict`` entries were replaced after construction is read as it is
+    (the index matrix it was built with is not consulted)."""
+    rng = np.random.default_rng(8)
+    N, K, P = 1200, 24, 4
+    X, w = rng.random((N, K)), rng.random(N) + 0.01
+    p = amd.Partitioner(np.arange(N) % P)
+    new0 = np.arange(0, 200)
+    p.folds_dict[0] = new0
+    m = amd.CVMatrix()
+    m.fit(X, None, w)
+    bx, _ = m.training_XTX_batched(p)
+    from oracle.cvmatrix_oracle import OracleCVMatrix
+
+    o = OracleCVMatrix()
+    o.fit(X, None, w)
+    assert_normwise(bx[0], o.training_XTX(new0)[0], 1e-10, "reassigned fold")
+    assert_normwise(bx[1], o.training_XTX(p.folds_dict[1])[0], 1e-10, "untouched fold")
+
+
+def test_fold_batch_carried_to_a_model_with_other_weights_is_recounted(amd):
+    """A prepared FoldBatch keeps the non-zero-weight counts of the weights it was prepared for; used
+    on ANOTHER model (other weights, same number of fits) the counts are made again, so the
+    reference's raises (cvmatrix.py:612-630) are decided on the right ones."""
+    rng = np.random.default_rng(9)
+    N, K = 400, 6
+    X = rng.random((N, K))
+    w1 = np.ones(N)
+    w2 = np.zeros(N); w2[:40] = 1.0                          # all weight inside fold 0
+    folds = [np.arange(0, 40), np.arange(40, 400)]
+    a, b = amd.CVMatrix(lazy_fit=False), amd.CVMatrix(lazy_fit=False)
+    a.fit(X, None, w1); b.fit(X, None, w2)
+    batch = a.prepare_folds(folds)
+    a.training_XTX_batched(batch)
+    with pytest.raises(ValueError, match="greater than zero"):
+        b.training_XTX_batched(batch)
+
+
+def test_two_threads_two_models_two_streams(amd, hip_device):
+    """Two threads, each with its own model, Partitioner and HIP stream, running the reference's
+    loop at the same time: the process-wide registries that recognise a Partitioner's arrays are
+    locked, the library's per-stream work queues keep the launches apart, results equal the
+    single-threaded ones bit for bit."""
+    import threading
+
+    import torch
+
+    rng = np.random.default_rng(21)
+    N, K, M = 5000, 64, 2
+    data = [(rng.random((N, K)), rng.random((N, M)), rng.random(N) + 0.01) for _ in range(2)]
+    Ps = [5, 8]
+
+    def run(i, stream, out):
+        X, Y, w = data[i]
+        res = []
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.device(hip_device):
+            for rep in range(6):
+                p = amd.Partitioner(np.arange(N) % Ps[i])
+                m = amd.CVMatrix()
+                m.fit(X, Y, w)
+                res = [m.training_XTX_XTY(p.get_validation_indices(k))[0] for k in p.folds_dict]
+            torch.cuda.current_stream().synchronize()
+        out[i] = [(a.clone(), b.clone()) for a, b in res]
+
+    want = [None, None]
+    for i in range(2):
+        run(i, None, want)
+    got = [None, None]
+    errs = []
+
+    def guarded(i, st):
+        try:
+            run(i, st, got)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=guarded, args=(i, torch.cuda.Stream(device=hip_device))) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert len(got[i]) == len(want[i])
+        for (a, b), (c, d) in zip(got[i], want[i]):
+            assert torch.equal(a, c) and torch.equal(b, d)

@@ -1062,6 +1062,92 @@ def test_device_partitioner_matches_host_partitioner(amd, N, L):
         m.prepare_folds_from_labels(bad, n_labels=L)
 
 
+@pytest.mark.parametrize("N,L,bad", [(6000, 5000, -5), (6000, 5000, -(2 ** 62)), (3000, 40, -1), (6000, 5000, 5000)])
+def test_device_partitioner_refuses_out_of_range_labels(amd, N, L, bad):
+    """A label outside [0, n_labels) -- negative ones included, on the many-label radix route too --
+    raises the ValueError, through the class (checked on the host before any kernel runs) and
+    through the C ABI alone (the error flag is set, nothing is written out of bounds, the call
+    returns)."""
+    import torch
+
+    from cvmatrix_amd import _lib
+
+    rng = np.random.default_rng(N + L)
+    labels = rng.integers(0, L, size=N)
+    labels[N // 2] = bad                      # (directly in front of / behind valid rows in the sorted order)
+    m = amd.CVMatrix()
+    m.fit(rng.random((N, 8)))
+    with pytest.raises(ValueError, match="fold labels"):
+        m.prepare_folds_from_labels(labels, n_labels=L)
+    lib = _lib.load()
+    dev = m.device
+    lab = torch.from_numpy(labels).to(dev)
+    guard = 4096                              # canaries around the outputs: nothing outside them is touched
+    idx = torch.full((N + 2 * guard,), -7, dtype=torch.int64, device=dev)
+    offs = torch.full((L + 1 + 2 * guard,), -7, dtype=torch.int64, device=dev)
+    first = torch.full((L + 2 * guard,), -7, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.cvm_partition_workspace_bytes(N, L)), dtype=torch.uint8, device=dev)
+    rc = lib.cvm_partition_labels(lab.data_ptr(), N, L, idx[guard:].data_ptr(), offs[guard:].data_ptr(),
+                                  first[guard:].data_ptr(), err.data_ptr(), ws.data_ptr(), ws.numel(), 0)
+    torch.cuda.synchronize()
+    assert rc == 0 and int(err.item()) != 0
+    for t, n in ((idx, N), (offs, L + 1), (first, L)):
+        assert bool((t[:guard] == -7).all()) and bool((t[guard + n:] == -7).all())
+
+
+def _empty_rank_worker(rank, world, port, tmp):
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cvmatrix_amd import CVMatrix
+        from cvmatrix_amd.distributed import ShardedCVMatrix
+
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(19)
+        N, K, M = 3000, 66, 2
+        X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N) + 0.01
+        full = CVMatrix(lazy_fit=False)
+        full.fit(X, Y, w)
+        rows = np.arange(N) if rank == 0 else np.zeros(0, dtype=np.int64)     # rank 1 owns nothing
+        for lazy in (False, True):
+            sh = ShardedCVMatrix(mode="row_sharded", lazy_fit=lazy)
+            sh.fit(X[rows], Y[rows], w[rows])
+            # every rank asks for the matrices (the lazy exchange is collective); rank 1 has no fold
+            assert torch.allclose(sh.XTX, full.XTX, rtol=1e-12, atol=1e-12)
+            assert torch.allclose(sh.XTY, full.XTY, rtol=1e-12, atol=1e-12)
+            if rank == 0:
+                folds = [np.arange(i, N, 3) for i in range(3)]
+                (a, b), sa = sh.training_XTX_XTY_batched(folds)
+                (c, d), sc = full.training_XTX_XTY_batched(folds)
+                assert torch.allclose(a, c, rtol=1e-10, atol=1e-10) and torch.allclose(b, d, rtol=1e-10, atol=1e-10)
+        open(os.path.join(tmp, f"ok_empty_{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_rows_takes_part_in_the_exchange(amd, tmp_path):
+    """More ranks than folds (strong scaling of 10 folds on 16 GPUs, or any rank whose shard is empty):
+    such a rank fits zero rows -- zeros, no kernel -- and still issues the one collective, so the
+    other ranks neither hang nor get a wrong sum."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    port = 29300 + (os.getpid() % 1500)
+    mp.spawn(_empty_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_empty_0").exists() and (tmp_path / "ok_empty_1").exists()
+
+
 def _sharded_worker(rank, world, port, tmp, mode):
     import os
     import sys
