@@ -375,53 +375,18 @@ def main():
     n_mine = len(fold_lists)
 
     # ---- --emulate-world: one rank of a `emu`-rank job, the exchange replaced by a stub ------
-    class EmulatedRank(ShardedCVMatrix):
-        """ShardedCVMatrix of rank `lay_rank` in a job of `lay_world` ranks, without a process group:
-        every code path of the real multi-GPU step (world > 1) runs; the one collective is replaced by
-        its last arithmetic step -- an in-place add (row-sharded) / copy (replicated) of a buffer of
-        the same size that holds the OTHER ranks' share, computed once up front, so the results
-        are the real job's (to rounding) -- followed by --comm-us of held stream."""
-        others = None          # [G | H | gstats] of the other ranks (row-sharded) / of rank 0 (replicated)
-        sleep_cycles = 0
-
-        @property
-        def world(self):
-            return lay_world
-
-        @property
-        def rank(self):
-            return lay_rank
-
-        def _exchange(self):
-            o = EmulatedRank.others
-            if self._globals is not None:
-                self._globals.add_(o[0]) if self.mode == "row_sharded" else self._globals.copy_(o[0])
-            else:
-                for t, u in zip((self._G, self._H, self._gs), o[1:]):
-                    if t is not None:
-                        t.add_(u) if self.mode == "row_sharded" else t.copy_(u)
-            if EmulatedRank.sleep_cycles:
-                torch.cuda._sleep(EmulatedRank.sleep_cycles)
-
-    Model = EmulatedRank if emu else ShardedCVMatrix
+    # (cvmatrix_amd/emulate.py: every code path of the real multi-GPU step runs; the collective is
+    #  an in-place add of the other ranks' precomputed share, then --comm-us of held stream)
     if emu:
-        # the other ranks' share of the full-data matrices: (whole problem) - (this rank's rows)
-        whole = CVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, lazy_fit=False)
-        whole.fit(Xf, Yf, wf)
-        mine = CVMatrix(*flags, ddof=1, dtype=dtype, copy=False, device=dev, lazy_fit=False)
-        if mode == "row_sharded" and Xd.shape[0]:
-            mine.fit(Xd, Yd, wd)
-            parts = [(a - b) if a is not None else None for a, b in
-                     ((whole._globals, mine._globals), (whole._G, mine._G), (whole._H, mine._H), (whole._gs, mine._gs))]
-        else:
-            parts = [None if a is None else a.clone() for a in (whole._globals, whole._G, whole._H, whole._gs)]
-        EmulatedRank.others = parts
-        if args.comm_us > 0:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda._sleep(1000000); torch.cuda.synchronize()
-            e0.record(); torch.cuda._sleep(10000000); e1.record(); torch.cuda.synchronize()
-            EmulatedRank.sleep_cycles = int(args.comm_us * 1e-3 / e0.elapsed_time(e1) * 10000000)
-        del whole, mine
+        import functools
+
+        from cvmatrix_amd.emulate import EmulatedRank, others_share, sleep_cycles_for
+
+        Model = functools.partial(EmulatedRank, emu_world=lay_world, emu_rank=lay_rank,
+                                  others=others_share(flags, dtype, dev, mode, (Xf, Yf, wf), (Xd, Yd, wd)),
+                                  sleep_cycles=sleep_cycles_for(args.comm_us))
+    else:
+        Model = ShardedCVMatrix
 
     # `model`: lazy fit; fit() + a batched call whose folds partition the (local) rows is served
     # by ONE sweep of the Gram kernel (full-data matrices = sum of the folds' validation

@@ -49,6 +49,10 @@ struct FinArgs {
   unsigned flags;
   int32_t *neg_flag;
   int gx, gy;           // apply_kernel<.., true>: sub-tiles + panels, folds of the launch
+  int compact;          // fit mode over several segments (the one-sweep path, float64): every segment's
+                        // subtotal -- the fold's raw update U_f = sum_sp partial, exactly the chain the fold
+                        // stage forms -- is written back to the segment's slot 0, so that the fold stage
+                        // reads ONE partial per fold and tile instead of s_off / s_diag (same bits: 0 + U_f)
 };
 __host__ __device__ inline size_t fstat_len(int K, int M) { return 2 * (size_t)K + 2 * (size_t)M + 4; }
 
@@ -94,18 +98,23 @@ __device__ __forceinline__ void fit_stats_columns(const FinArgs &a, double *gsta
     // the folds' own sums (one segment: the plain chain); sixteen loads in flight at a time
     double s = 0, us = 0;
     int p = 0, kk = 0;
+    long segc = 0;                         // segments closed so far
     const int np = a.n_sum * a.s_diag;     // (the column sums come from the diagonal items)
     UnitCursor cur(a.s_diag, a.splits);
+    auto close_seg = [&]() {
+      if (a.compact) unit_stats<T>((char *)a.ws, g, segc * a.splits)[src] = us;
+      s += us; us = 0; kk = 0; ++segc;
+    };
     for (; p + 16 <= np; p += 16) {
       double v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) v[u] = unit_stats<T>((char *)a.ws, g, cur.next())[src];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { us += v[u]; if (++kk == a.s_diag) { s += us; us = 0; kk = 0; } }
+      for (int u = 0; u < 16; ++u) { us += v[u]; if (++kk == a.s_diag) close_seg(); }
     }
     for (; p < np; ++p) {
       us += unit_stats<T>((char *)a.ws, g, cur.next())[src];
-      if (++kk == a.s_diag) { s += us; us = 0; kk = 0; }
+      if (++kk == a.s_diag) close_seg();
     }
     if (c < total - 1) gstats[c] = s;
     else if (a.neg_flag) *a.neg_flag = (s > 0) ? 1 : 0;
@@ -649,12 +658,23 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
 #pragma unroll
       for (int e = 0; e < VW; ++e) uu[j][e] = 0;
     int kk = 0;
+    long segc = 0;                                   // segments closed so far
     auto close_segment = [&]() {
+      if (a.compact) {                               // the fold's raw update goes back to its slot 0
+        const size_t so = (size_t)(segc * a.splits) * g.unit_bytes;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          vld_t uv;
+#pragma unroll
+          for (int e = 0; e < VW; ++e) uv[e] = (T)uu[j][e];
+          *reinterpret_cast<vld_t *>(const_cast<char *>(pp[j]) + so) = uv;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NQ; ++j)
 #pragma unroll
         for (int e = 0; e < VW; ++e) { v[j][e] += uu[j][e]; uu[j][e] = 0; }
-      kk = 0;
+      kk = 0; ++segc;
     };
     int p = 0;
     for (; p + UP <= np; p += UP) {
@@ -743,18 +763,23 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_apply_kernel(const FinArgs a)
       double s = 0, us = 0;
       const char *pp = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T);
       int p = 0, kk = 0;
+      long segc = 0;
       const int np = a.n_sum * a.s_diag;
       UnitCursor cur(a.s_diag, a.splits);
+      auto close_seg = [&]() {
+        if (a.compact) *reinterpret_cast<T *>(const_cast<char *>(pp) + (size_t)(segc * a.splits) * g.unit_bytes) = (T)us;
+        s += us; us = 0; kk = 0; ++segc;
+      };
       for (; p + 16 <= np; p += 16) {
         T t16[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) t16[u] = *reinterpret_cast<const T *>(pp + (size_t)cur.next() * g.unit_bytes);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { us += (double)t16[u]; if (++kk == a.s_diag) { s += us; us = 0; kk = 0; } }
+        for (int u = 0; u < 16; ++u) { us += (double)t16[u]; if (++kk == a.s_diag) close_seg(); }
       }
       for (; p < np; ++p) {
         us += (double)*reinterpret_cast<const T *>(pp + (size_t)cur.next() * g.unit_bytes);
-        if (++kk == a.s_diag) { s += us; us = 0; kk = 0; }
+        if (++kk == a.s_diag) close_seg();
       }
       out[(size_t)ga * M + m] = (T)s;
     }

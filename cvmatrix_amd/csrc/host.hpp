@@ -416,8 +416,10 @@ bool rows_aligned(const void *X, int K, int esize) {
 
 // full-data matrices and column statistics from the partials: one launch of the many-workgroup
 // kernel when rows are 16-byte aligned, else the statistics kernel and the general apply kernel
-template <typename T> void launch_fit_apply(FinArgs f, const Geom &g, double *gstats, hipStream_t st) {
+// (returns whether the kernel that can compact the folds' partials ran: FinArgs::compact)
+template <typename T> bool launch_fit_apply(FinArgs f, const Geom &g, double *gstats, hipStream_t st) {
   const bool aligned = ((size_t)g.K * sizeof(T)) % 16 == 0 && ((uintptr_t)f.out_XTX % 16 == 0);
+  if (!aligned) f.compact = 0;
   if (aligned) {
     f.gstats = gstats;
     hipLaunchKernelGGL((fit_apply_kernel<T>), dim3(g.nTiles * APPLY_SUB * fit_rc<T>() + g.P * FIT_PCH + FIT_STAT_WGS),
@@ -426,6 +428,7 @@ template <typename T> void launch_fit_apply(FinArgs f, const Geom &g, double *gs
     hipLaunchKernelGGL((fit_stats_kernel<T>), dim3(32), dim3(64), 0, st, f, gstats);
     hipLaunchKernelGGL((apply_kernel<T, false>), dim3(g.nTiles * APPLY_SUB + g.P, 1), dim3(APPLY_THREADS_FIT), 0, st, f);
   }
+  return f.compact != 0;
 }
 
 template <typename T>
@@ -733,9 +736,16 @@ int sweep_fit_impl(const void *X, const void *Y, const void *w, const int64_t *i
   f.g = p.g; set_fin_splits(f, p, (int)n_folds);      // every unit of every fold, fold-major
   f.n_seg = 1; f.seg0 = 0; f.ws = (const char *)ws;
   f.w = w; f.out_XTX = G; f.out_XTY = (Y && M > 0) ? H : nullptr; f.neg_flag = neg_flag;
-  launch_fit_apply<T>(f, p.g, gstats, st);
+  // float64 with more than one row split: the fit finalize leaves every fold's raw update in the
+  // fold's slot 0 (FinArgs::compact), and cvm_sweep_folds / cvm_sweep_fold_range then read one
+  // partial per fold and tile (the multi-GPU step: this call, the exchange, that call -- with 1-2
+  // folds per GPU the fold stage read 11-28 partials per tile: 21 us -> 6 us at C3 on 8 GPUs)
+  static const bool no_compact = getenv("CVM_NO_COMPACT") != nullptr;       // tests: the uncompacted route
+  f.compact = (sizeof(T) == 8 && !no_compact && (p.s_off > 1 || p.s_diag > 1)) ? 1 : 0;
+  const bool compacted = launch_fit_apply<T>(f, p.g, gstats, st);
   HIP_OK(hipGetLastError());
-  if (splits_out) *splits_out = (int64_t)p.s_off | ((int64_t)p.s_diag << 20);   // plan token for cvm_sweep_folds
+  // plan token for cvm_sweep_folds: s_off | s_diag << 20 | compacted << 40
+  if (splits_out) *splits_out = (int64_t)p.s_off | ((int64_t)p.s_diag << 20) | ((int64_t)(compacted ? 1 : 0) << 40);
   return CVM_OK;
 }
 
@@ -750,7 +760,8 @@ int sweep_folds_impl(const int64_t *offsets, int64_t n_total, int64_t fold0, int
   const Geom g = make_geom(K, M, sizeof(T), 0);
   Plan p;
   p.g = g;
-  set_plan_splits(p, (int)(splits & 0xfffff), (int)(splits >> 20));
+  set_plan_splits(p, (int)(splits & 0xfffff), (int)((splits >> 20) & 0xfffff));
+  const bool compacted = (splits >> 40) & 1;      // every fold's slot 0 holds the sum of its partials
   if (p.s_off < 1 || p.s_diag < 1) return fail(CVM_EINVAL, "cvm_sweep_folds: not a plan token of cvm_sweep_fit%s");
   const size_t units = (size_t)n_total * (size_t)p.splits * g.unit_bytes;
   if (units + (size_t)n_total * fstat_len(K, M) * 8 > ws_bytes)
@@ -758,6 +769,7 @@ int sweep_folds_impl(const int64_t *offsets, int64_t n_total, int64_t fold0, int
   FinArgs f;
   memset(&f, 0, sizeof(f));
   f.g = g; set_fin_splits(f, p, 1); f.n_seg = (int)n_folds; f.seg0 = 0;
+  if (compacted) f.s_off = f.s_diag = 1;          // (f.splits stays the slot stride)
   f.ws = (const char *)ws + (size_t)fold0 * (size_t)p.splits * g.unit_bytes;
   f.fstats = (double *)((char *)ws + units) + (size_t)fold0 * fstat_len(K, M);
   f.offs = offsets + fold0; f.w = weighted ? (const void *)G : nullptr;   // non-null = weighted

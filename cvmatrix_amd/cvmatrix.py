@@ -655,8 +655,26 @@ class CVMatrix:
         all-reduced counts here)."""
 
     def _totals_in_flight(self) -> bool:
-        """Hook: True while those counts are still being fetched from the device."""
+        """Hook: True while those counts are still on the device (a multi-GPU exchange)."""
         return False
+
+    def _request_totals(self) -> None:
+        """Hook: start fetching those counts (asynchronously; ``_resolve_totals`` waits)."""
+
+    def _passes_on_local_counts(self, batch, need_stats: bool, need_std: bool, only: Optional[int] = None) -> bool:
+        """While the global counts are still in flight, this process's own counts (``_publish_stats``)
+        are LOWER bounds of them: if even they leave every fold's training set more non-zero
+        weights than ``ddof`` (and than zero), neither of the reference's raises
+        (cvmatrix.py:612-630, 1074-1078) can fire whatever the other ranks hold, and the check
+        needs no read-back at all."""
+        if not need_stats:
+            return True
+        sel = slice(None) if only is None else slice(only, only + 1)
+        if self.weights is not None:
+            lb = self._nz_total - batch.nz_val[sel]
+        else:
+            lb = self._n_total - batch.sizes[sel]
+        return bool(lb.size == 0 or int(lb.min()) > max(int(np.ceil(self.ddof)) if need_std else 0, 0))
 
     def _gslice(self, lo: int, hi: int, cond: bool):
         if not cond or self._gstats is None:
@@ -985,6 +1003,8 @@ class CVMatrix:
         ``only``: check fold ``only`` of the batch alone."""
         if not need_stats:
             return
+        if self._totals_in_flight() and self._passes_on_local_counts(batch, need_stats, need_std, only):
+            return
         self._resolve_totals()
         sel = slice(None) if only is None else slice(only, only + 1)
         if self.weights is not None:
@@ -1113,12 +1133,17 @@ class CVMatrix:
         # need are still on their way from the other GPUs (multi-GPU, _totals_in_flight): then the
         # kernels are queued first (they never fault on such data) and the check, which has to
         # wait for the exchange anyway, follows; the results are only handed out after it
+        need_stats, need_std = r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY
         late = self._totals_in_flight()
+        if late and self._passes_on_local_counts(batch, need_stats, need_std, only=sweep_fold):
+            late = need_stats = False           # (decided on this process's own counts: nothing to wait for)
+        elif late:
+            self._request_totals()              # (queued behind the exchange; awaited after the launch below)
         if not late:
-            self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
+            self._validate(batch, need_stats, need_std, only=sweep_fold)
         xtx, xty, (muX, sdX, muY, sdY), _ = self._run(batch, rXTX, rXTY, sweep_fold=sweep_fold, sweep_all=sweep_all)
         if late:
-            self._validate(batch, r_muX or r_muY or r_sdX or r_sdY, r_sdX or r_sdY, only=sweep_fold)
+            self._validate(batch, need_stats, need_std, only=sweep_fold)
         o, oXX, oXY, oX, oY = self._out, self._oXX, self._oXY, self._oX, self._oY
         stats = (oX(muX) if r_muX else None, oX(sdX) if r_sdX else None,
                  oY(muY) if r_muY else None, oY(sdY) if r_sdY else None)

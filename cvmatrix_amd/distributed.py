@@ -138,7 +138,7 @@ class ShardedCVMatrix(CVMatrix):
             raise ValueError("mode must be 'row_sharded' or 'replicated'")
         self.mode, self.group, self.src = mode, group, src
         self._tail_host = self._tail_event = None
-        self._tail_pending = False
+        self._tail_pending = self._tail_requested = False
         self._probe = None      # bench.py: callable(label) at "exchange_begin" / "exchange_end"
 
     def ensure_fit(self) -> None:
@@ -188,16 +188,23 @@ class ShardedCVMatrix(CVMatrix):
         if self.mode == "row_sharded":
             # the global sample / non-zero-weight counts for the host-side validity checks
             # (cvmatrix.py:612-630, 1074-1078) ride in the all-reduced statistics vector
-            # ([... | sw | nz]: sw = N when unweighted): fetch them without stalling ``fit`` --
-            # an asynchronous copy into pinned memory, awaited by the first check that needs them
-            K, M = self._Kd, self._Md or 0
-            if self._tail_host is None:
-                self._tail_host = torch.empty(2, dtype=torch.float64, pin_memory=True)
-                self._tail_event = torch.cuda.Event()
-            with torch.cuda.device(self.device):
-                self._tail_host.copy_(self._gs[2 * K + 2 * M: 2 * K + 2 * M + 2], non_blocking=True)
-                self._tail_event.record()
-            self._tail_pending = True
+            # ([... | sw | nz]: sw = N when unweighted).  They stay on the device until a check
+            # cannot be decided on this rank's own counts (CVMatrix._passes_on_local_counts):
+            # then ``_request_totals`` copies them into pinned memory asynchronously and the check
+            # awaits that copy -- a step whose folds leave this rank enough rows never waits
+            self._tail_pending, self._tail_requested = True, False
+
+    def _request_totals(self) -> None:
+        if not self._tail_pending or self._tail_requested:
+            return
+        K, M = self._Kd, self._Md or 0
+        if self._tail_host is None:
+            self._tail_host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+            self._tail_event = torch.cuda.Event()
+        with torch.cuda.device(self.device):
+            self._tail_host.copy_(self._gs[2 * K + 2 * M: 2 * K + 2 * M + 2], non_blocking=True)
+            self._tail_event.record()
+        self._tail_requested = True
 
     def _exchange(self) -> None:
         """The collective itself (on the current stream's NCCL/RCCL ordering)."""
@@ -215,6 +222,7 @@ class ShardedCVMatrix(CVMatrix):
     def _resolve_totals(self) -> None:
         if not self._tail_pending:
             return
+        self._request_totals()
         self._tail_pending = False
         self._tail_event.synchronize()
         sw, nz = float(self._tail_host[0]), float(self._tail_host[1])
