@@ -312,7 +312,7 @@ __device__ __forceinline__ void finish_store_tile(TS (*Ts)[ST + 1], bool diag, i
         for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = (TS)vals[e];
       }
     }
-    __syncthreads();
+    lds_barrier();     // (LDS only: the stores above need not be acknowledged before the mirrored pass)
   }
 }
 
@@ -915,7 +915,7 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
       }
       uh[fl][el] = u;
     }
-    __syncthreads();
+    lds_barrier();
     double h = 0;
     for (int f = 0; f < P; ++f) h += uh[f][el];
     const T hT = (T)h;
@@ -1010,7 +1010,7 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
   // are stored transposed as rows b0 + c / columns a0 + r (strictly below the diagonal).
   const int mc = tid / (SWF_R / VW), mr = (tid - mc * (SWF_R / VW)) * VW;
   const int n_out = a.out_XTX ? P + 1 : 1;
-  __syncthreads();                                   // (stl)
+  lds_barrier();                                   // (stl)
   for (int o0 = 0; o0 < n_out; o0 += SWF_GROUP) {
 #pragma unroll
     for (int k = 0; k < SWF_GROUP; ++k) {
@@ -1059,7 +1059,7 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
         for (int e = 0; e < VW; ++e) tm[k][lr][lc + e] = vals[e];
       }
     }
-    __syncthreads();
+    lds_barrier();
     const int orow = b0 + mc, ocol = a0 + mr;
     if (orow < K) {
 #pragma unroll
@@ -1080,6 +1080,6 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }

@@ -122,6 +122,17 @@ template <typename T> __device__ __forceinline__ double *unit_stats(char *ws, co
                     ((g.h_elems * sizeof(T) + 255) / 256 * 256));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release +
+// acquire: the compiler puts s_waitcnt vmcnt(0) in front of the barrier, so every global store the
+// wave has issued must be ACKNOWLEDGED by the memory system first -- with output stores streaming
+// to HBM that is several microseconds per barrier (tools/exp_small_apply.py: the K = 4096 small-fold
+// kernel spent ~7 of its ~9.5 us per fold and tile in two such waits).  The kernels below only
+// hand LDS contents from wave to wave at these points; global results are never read back by
+// another wave of the launch.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ long long uni64(long long v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));

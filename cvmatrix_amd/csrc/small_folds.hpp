@@ -107,7 +107,25 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   }
 }
 
-template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_apply_kernel(const SmallArgs a) {
+// small_apply_kernel, round 3.  What the round-2 kernel spent its time on (tools/exp_small_apply.py,
+// K = 4096, 16-row folds): with NO rows at all (only G - 0, finish, stores) it moved 4.7 TB/s of
+// float32 outputs and 5.5 TB/s of float64 -- every fold of a workgroup's group started with two
+// dependent global latencies (offsets, then the statistics), and under a memory system saturated
+// with writes a read takes several microseconds -- and the rank-n update itself, 16 mul + 16 add per
+// row and thread with four LDS reads, cost another 0.2 ms per 16 rows (3.5 / 4.0 TB/s), serial with
+// the stores.  Now:
+//   * the update runs on the matrix cores: wave w owns row tile w of the 64 x 64 tile, 4 MFMA
+//     16x16x4 tiles, one A and four B fragment reads per 4 rows (LDS row pitch 80: conflict-free);
+//   * the indices, weights and row counts of ALL folds of the workgroup's group are read once, up
+//     front; the next fold's rows and statistics are requested before the current fold's
+//     arithmetic and stores and arrive in registers while those run: no global latency is left
+//     inside the per-fold chain.
+constexpr int SA_PITCH = 80;            // LDS row pitch of As / Bs in elements (f32: 320 B, f64: 640 B)
+constexpr int SA_FPB = 8;               // folds per workgroup at most (host: fpb <= 8)
+#ifndef CVM_SMALL_WPE
+#define CVM_SMALL_WPE 1
+#endif
+template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL_WPE) void small_apply_kernel(const SmallArgs a) {
   // Workgroups go to the 8 XCDs round-robin by their linear number; neighbouring tiles of one
   // output matrix share cache lines when its rows are not whole lines, and only one L2 can merge
   // the two halves before they go to HBM: give every XCD a contiguous range of (fold group, tile).
@@ -123,102 +141,196 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
   const bool inl = a.inl_n >= 0;
-  // As: w * x, columns of the tile's rows; Bs: x (or y), columns of the tile's columns;
-  // Ts: the finished tile for the transposed store -- it reuses the As/Bs space (33 KB per
-  // workgroup instead of 66: four workgroups per CU keep more loads and stores in flight)
-  // (float32 problems stage and accumulate the at most 32-term updates in float32: half the LDS,
-  //  twice the workgroups per CU -- their tiles carry half the bytes for the same latencies)
-  typedef typename std::conditional<sizeof(T) == 8, double, float>::type TS;
-  __shared__ __attribute__((aligned(16))) TS sm[ST * (ST + 1)];
-  TS (*As)[ST] = reinterpret_cast<TS (*)[ST]>(sm);
-  TS (*Bs)[ST] = reinterpret_cast<TS (*)[ST]>(sm + SMALL_ROWS * ST);
+  // As: w * x, columns of the tile's rows; Bs: x (or y), columns of the tile's columns (SMALL_ROWS
+  // rows of SA_PITCH each); Ts: the tile for the finish and the transposed store -- it reuses the
+  // As / Bs space.  Elements are T: float32 problems stage and accumulate in float32.
+  typedef T TS;
+  constexpr int SM_ELEMS = 2 * SMALL_ROWS * SA_PITCH > ST * (ST + 1) ? 2 * SMALL_ROWS * SA_PITCH : ST * (ST + 1);
+  __shared__ __attribute__((aligned(16))) TS sm[SM_ELEMS];
+  TS *As = sm, *Bs = sm + SMALL_ROWS * SA_PITCH;
   TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm);
-  __shared__ int64_t rows[SMALL_ROWS];
-  __shared__ double wl[SMALL_ROWS];
-  __shared__ double st_lds[4 * ST];              // this fold's means / stds of the tile's rows and columns
+  __shared__ int64_t rows_all[SA_FPB][SMALL_ROWS];
+  __shared__ T wl_all[SA_FPB][SMALL_ROWS];
+  __shared__ int n_all[SA_FPB];
+  __shared__ double st_lds[2][4 * ST];           // the folds' means / stds of the tile's rows and columns
   const bool xtx_part = x < a.nT64;
   if (xtx_part ? !a.out_XTX : (!a.out_XTY || M == 0)) return;
-  // a workgroup takes its tile for `fpb` consecutive folds: the tile of G (the same for every
-  // fold) is fetched once and stays in registers, and the fixed latencies of a workgroup are
-  // paid once per group of folds -- with leave-one-out style batches the kernel is otherwise
-  // bound by them, not by the bytes it writes
   int ti = 0, tj = 0;
   if (xtx_part) decode_tile(x, a.P64, ti, tj);
   const int a0 = (xtx_part ? ti : x - a.nT64) * ST, b0 = tj * ST;
-  constexpr int NQG = ST * (ST / (16 / (int)sizeof(T))) / 256;
-  T gpre[NQG][16 / sizeof(T)];
-  if (xtx_part)
-    finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, (const T *)a.out_XTX, tid, 256);
-  for (int ff = 0; ff < a.fpb; ++ff) {
-    const int f = by * a.fpb + ff;
-    if (f >= a.nb) break;
-    const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
-    const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
-    const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-    const double swt = fs[2 * K + 2 * M];
-    const size_t fo = (size_t)(a.seg0 + f);
-    if (ff) __syncthreads();                   // the previous fold is done with rows / wl / sm
-    if (tid < n) {
-      const int64_t r = inl ? a.inl[tid] : a.idx[o0 + tid];
-      rows[tid] = r;
-      wl[tid] = WEIGHTED ? (double)W[r] : 1.0;
+  const int f_first = by * a.fpb;
+  const int nf = (a.nb - f_first < a.fpb) ? a.nb - f_first : a.fpb;      // folds of this workgroup
+  // ---- every fold's row numbers, weights and row count, once ----------------------------------
+  {
+    const int ff = tid >> 5, j = tid & 31;       // 8 folds x 32 row slots = 256 threads
+    int n = 0;
+    if (ff < nf) {
+      const int f = f_first + ff;
+      const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
+      n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
+      int64_t r = 0;
+      T wv = (T)0;
+      if (j < n) {
+        r = inl ? a.inl[j] : a.idx[o0 + j];
+        wv = WEIGHTED ? W[r] : (T)1;
+      }
+      rows_all[ff][j] = r;
+      wl_all[ff][j] = wv;
+      if (j == 0) n_all[ff] = n;
     }
-    if (xtx_part) stage_tile_stats(st_lds, fs, a0, b0, K, tid);
-    __syncthreads();
-    if (xtx_part) {
+  }
+  lds_barrier();
+  if (xtx_part) {
+    constexpr int VWG = 16 / (int)sizeof(T);
+    constexpr int NQG = ST * (ST / VWG) / 256;
+    T gpre[NQG][VWG];
+    finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, (const T *)a.out_XTX, tid, 256);
+    // staging element j of this thread: row sr[j] = (tid + 256 j) / 64 of the fold, column sc of the
+    // tile; up to SMALL_ROWS * 64 / 256 = 8 elements, each an A-side and a B-side value
+    constexpr int NE = SMALL_ROWS * ST / 256;
+    const int sc = tid & (ST - 1), sr0 = tid >> 6;           // element j: row sr0 + 4 j
+    const bool ca_ok = a0 + sc < K, cb_ok = b0 + sc < K;
+    T pa[NE], pb[NE];
+    double pst = 0;
+    auto request = [&](int ff) {                 // rows and statistics of fold ff -> registers
+      const int n = n_all[ff];
+      const int n4 = (n + 3) & ~3;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int r = sr0 + 4 * j;
+        pa[j] = (T)0; pb[j] = (T)0;
+        if (r < n4 && r < n) {
+          const int64_t row = rows_all[ff][r];
+          if (ca_ok) pa[j] = X[row * (int64_t)K + a0 + sc];
+          if (cb_ok) pb[j] = X[row * (int64_t)K + b0 + sc];
+        }
+      }
+      const double *fs = a.fstats + (size_t)(f_first + ff) * fstat_len(K, M);
+      const int part = tid / ST, l = tid - part * ST;        // stage_tile_stats, one value per thread
+      const int col = ((part < 2) ? a0 : b0) + l;
+      pst = (col < K) ? fs[((part & 1) ? K : 0) + col] : ((part & 1) ? 1.0 : 0.0);
+    };
+    request(0);
+    const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
+    // Fast finish of a tile that lies wholly inside the matrix, off the diagonal, with 16-byte
+    // accessible rows (all but the edge and diagonal tiles of a large K): piece j of this thread is
+    // row fr0 + FSTEP j, columns fc .. fc + VWG - 1 of the tile; its two output offsets are computed
+    // once per workgroup, the per-fold work is arithmetic, LDS and stores only (finish_store_tile
+    // re-derives rows, columns, bounds and addresses per piece and fold: most of its instructions)
+    constexpr int LPRF = ST / VWG, FSTEP = 256 / LPRF;
+    const int fr0 = tid / LPRF, fc = (tid - fr0 * LPRF) * VWG;
+    const bool fast = ti != tj && a0 + ST <= K && b0 + ST <= K && ((size_t)K * sizeof(T)) % 16 == 0 &&
+                      ((uintptr_t)a.out_XTX % 16 == 0) && ((uintptr_t)a.G % 16 == 0);
+    const size_t off_d0 = (size_t)(a0 + fr0) * K + b0 + fc, off_m0 = (size_t)(b0 + fr0) * K + a0 + fc;
+    const size_t off_step = (size_t)FSTEP * K;
+    typedef T vst_t __attribute__((ext_vector_type(VWG)));
+    typedef typename MF<T>::acc_t acc_t;
+    for (int ff = 0; ff < nf; ++ff) {
+      const int f = f_first + ff;
+      const int n = n_all[ff], n4 = (n + 3) & ~3;
+      const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+      const double swt = fs[2 * K + 2 * M];
+      const size_t fo = (size_t)(a.seg0 + f);
+      // the fold's rows (A side weighted, zero rows up to a multiple of 4) and statistics -> LDS
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int r = sr0 + 4 * j;
+        if (r < n4) {
+          As[r * SA_PITCH + sc] = WEIGHTED ? (T)(wl_all[ff][r] * pa[j]) : pa[j];
+          Bs[r * SA_PITCH + sc] = pb[j];
+        }
+      }
+      st_lds[ff & 1][tid] = pst;
+      lds_barrier();
+      if (ff + 1 < nf) request(ff + 1);          // in flight during the arithmetic and the stores below
+      // rank-n update of the 64 x 64 tile on the matrix cores: wave w -> row tile w, 4 column tiles
+      acc_t acc[4];
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) acc[nn] = (acc_t){0, 0, 0, 0};
+      for (int k0 = 0; k0 < n4; k0 += 4) {
+        const T af = As[(k0 + lk) * SA_PITCH + 16 * wave + lc];
+        T bf[4];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) bf[nn] = Bs[(k0 + lk) * SA_PITCH + 16 * nn + lc];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) acc[nn] = MF<T>::mfma(af, bf[nn], acc[nn]);
+      }
+      lds_barrier();   // every wave is done with As/Bs: Ts may overwrite them
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ts[16 * wave + MF<T>::drow(lane, r)][16 * nn + lc] = acc[nn][r];
+      lds_barrier();
       T *out = (T *)a.out_XTX + fo * (size_t)K * K;
-      const int ty = tid >> 4, tx = tid & 15;      // rows 4ty.., columns 4tx..
-      for (int e = tid; e < n * ST; e += 256) {
-        const int r = e / ST, c = e - r * ST;
-        const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
-        const T xb = (b0 + c < K) ? X[rows[r] * (int64_t)K + b0 + c] : (T)0;
-        As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
-        Bs[r][c] = (TS)xb;
+      if (fast) {
+        const double *st = st_lds[ff & 1];
+        double muc[VWG], sdc[VWG];
+#pragma unroll
+        for (int e = 0; e < VWG; ++e) { muc[e] = st[2 * ST + fc + e]; sdc[e] = st[3 * ST + fc + e]; }
+        T *od = out + off_d0;
+#pragma unroll
+        for (int j = 0; j < NQG; ++j) {
+          const int lr = fr0 + FSTEP * j;
+          const double mur = st[lr], sdr = st[ST + lr];
+          vst_t vv;
+#pragma unroll
+          for (int e = 0; e < VWG; ++e) {
+            double v = (double)gpre[j][e] - (double)Ts[lr][fc + e];
+            if (cX) v -= swt * (mur * muc[e]);
+            if (sX) v = v * (sdr * sdc[e]);
+            vv[e] = (T)v;
+          }
+          out_store(reinterpret_cast<vst_t *>(od), vv);
+          od += off_step;
+#pragma unroll
+          for (int e = 0; e < VWG; ++e) Ts[lr][fc + e] = vv[e];       // parked for the mirrored pass
+        }
+        lds_barrier();
+        T *om = out + off_m0;
+#pragma unroll
+        for (int j = 0; j < NQG; ++j) {
+          const int lr = fr0 + FSTEP * j;
+          vst_t vv;
+#pragma unroll
+          for (int e = 0; e < VWG; ++e) vv[e] = Ts[fc + e][lr];          // finished, transposed
+          out_store(reinterpret_cast<vst_t *>(om), vv);
+          om += off_step;
+        }
+        lds_barrier();
+      } else {
+        finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, st_lds[ff & 1], swt, cX, sX, tid, 256, gpre);
       }
-      __syncthreads();
-      TS acc[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
-      for (int r = 0; r < n; ++r) {
-        TS av[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { av[i] = As[r][4 * ty + i]; bv[i] = Bs[r][4 * tx + i]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
-      }
-      __syncthreads();   // every thread is done with As/Bs: Ts may overwrite them
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Ts[4 * ty + i][4 * tx + j] = acc[i][j];
-      __syncthreads();
-      finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, st_lds, swt, cX, sX, tid, 256, gpre);
-    } else {
+      // (both ways end with a barrier: As / Bs are free for the next fold)
+    }
+  } else {
+    for (int ff = 0; ff < nf; ++ff) {
+      const int f = f_first + ff;
+      const int n = n_all[ff];
+      const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+      const double swt = fs[2 * K + 2 * M];
+      const size_t fo = (size_t)(a.seg0 + f);
       const T *Ht = (const T *)a.H;
       T *out = (T *)a.out_XTY + fo * (size_t)K * M;
+      if (ff) lds_barrier();                   // the previous fold is done with As / Bs
       for (int e = tid; e < n * ST; e += 256) {
         const int r = e / ST, c = e - r * ST;
-        const T xa = (a0 + c < K) ? X[rows[r] * (int64_t)K + a0 + c] : (T)0;
-        As[r][c] = (TS)(WEIGHTED ? (T)((T)wl[r] * xa) : xa);
+        const T xa = (a0 + c < K) ? X[rows_all[ff][r] * (int64_t)K + a0 + c] : (T)0;
+        As[r * SA_PITCH + c] = WEIGHTED ? (T)(wl_all[ff][r] * xa) : xa;
       }
       for (int m0 = 0; m0 < M; m0 += ST) {
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < n * ST; e += 256) {
           const int r = e / ST, c = e - r * ST;
-          Bs[r][c] = (m0 + c < M) ? (TS)Y[rows[r] * (int64_t)M + m0 + c] : (TS)0;
+          Bs[r * SA_PITCH + c] = (m0 + c < M) ? Y[rows_all[ff][r] * (int64_t)M + m0 + c] : (T)0;
         }
-        __syncthreads();
+        lds_barrier();
         const int mw = (M - m0 < ST) ? M - m0 : ST;
         for (int e = tid; e < ST * mw; e += 256) {
           const int la = e / mw, lm = e - la * mw;
           const int ga = a0 + la, gm = m0 + lm;
           if (ga >= K) continue;
           TS acc = 0;
-          for (int r = 0; r < n; ++r) acc += As[r][la] * Bs[r][lm];
+          for (int r = 0; r < n; ++r) acc += As[r * SA_PITCH + la] * Bs[r * SA_PITCH + lm];
           double v = (double)Ht[(size_t)ga * M + gm] - (double)acc;
           if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + gm]);
           if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + gm]);

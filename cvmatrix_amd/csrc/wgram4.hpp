@@ -316,9 +316,9 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         T (*Td)[TP] = reinterpret_cast<T (*)[TP]>(smem_raw);
         double *rs0 = reinterpret_cast<double *>(smem_raw + diag_tile_bytes<T>());
         T *outp = (T *)a.out_XTX + (size_t)(a.seg0 + seg) * (size_t)K * K;
-        __syncthreads();   // B_dump
+        lds_barrier();     // B_dump
         diag_tile_finish<T, TP>(Td, rs0, wave_all, 0, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
-        __syncthreads();   // B_parked
+        lds_barrier();     // B_parked (LDS only: the direct stores need not be acknowledged first)
         diag_tile_finish<T, TP>(Td, rs0, wave_all, 1, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
       }
       if (do_g && !diag) {
@@ -335,10 +335,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         T (*Ts)[65] = reinterpret_cast<T (*)[65]>(slice);
         const double *rs = reinterpret_cast<const double *>(slice + wave_tile_bytes<T>());
         T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
-        __syncthreads();   // B_dump
+        lds_barrier();     // B_dump
         if (active)
           fused_finish_direct<T, 65>(Ts, rs, false, a0, b0, K, (const T *)a.G, outp, swt, cX, sX, lane, 32, 64);
-        __syncthreads();   // B_parked
+        lds_barrier();     // B_parked (LDS only: the direct stores need not be acknowledged first)
         if (active) fused_finish_mirror<T, 65>(Ts, a0, b0, K, outp, lane, 32, 64);
       }
     }
@@ -586,7 +586,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
 #ifdef CVM_STAMPS
       STAMP(f1);
 #endif
-      __syncthreads();   // B_dump
+      lds_barrier();     // B_dump
 #ifdef CVM_STAMPS
       STAMP(f2);
 #endif
@@ -595,7 +595,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
 #ifdef CVM_STAMPS
       STAMP(f3);
 #endif
-      __syncthreads();   // B_parked
+      lds_barrier();     // B_parked (LDS only: the direct stores need not be acknowledged first)
 #ifdef CVM_STAMPS
       STAMP(f4);
 #endif
@@ -873,10 +873,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
         rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
         rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
       }
-      __syncthreads();   // B_dump: the tile and the statistics are in LDS (all eight waves)
+      lds_barrier();     // B_dump: the tile and the statistics are in LDS (all eight waves)
       T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
       diag_tile_finish<T, TP>(Td, rs0, W, 0, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
-      __syncthreads();   // B_parked
+      lds_barrier();     // B_parked (LDS only: the direct stores need not be acknowledged first)
       diag_tile_finish<T, TP>(Td, rs0, W, 1, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
     }
     ROLE_EXIT();

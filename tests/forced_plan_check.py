@@ -54,6 +54,32 @@ def main():
                         cx, _ = m.training_XTX(v.copy())
                     worst = max(worst, err(bx[f], rx), err(cx, rx))
                     assert bool((bx[f] == bx[f].T).all())
+    # mid-size folds (the fused single-split epilogue, or the two-stage route under CVM_NO_FUSED) and
+    # folds of a few rows (tile kernel / whole-rows kernel, CVM_NO_DIRECT): tools/route_matrix.sh's switches
+    for (N, K, M, nv, seed) in ((6000, 132, 2, 150, 5), (3000, 70, 3, 8, 6), (2400, 70, 0, 1, 7), (4000, 260, 2, 25, 8)):
+        rng = np.random.default_rng(seed)
+        X = rng.random((N, K)) + 0.1
+        Y = rng.random((N, M)) if M else None
+        w = rng.random(N) + 0.01
+        perm = rng.permutation(N)
+        folds = [np.sort(perm[i:i + nv]) for i in range(0, N, nv)]
+        o = OracleCVMatrix()
+        o.fit(X, Y, w)
+        for lazy in (False, True):
+            m = amd.CVMatrix(lazy_fit=lazy)
+            m.fit(X, Y, w)
+            if M:
+                (bx, by), _ = m.training_XTX_XTY_batched(folds)
+            else:
+                bx, _ = m.training_XTX_batched(folds)
+            for f in (0, len(folds) // 2, len(folds) - 1):
+                if M:
+                    (rx, ry), _ = o.training_XTX_XTY(folds[f])
+                    worst = max(worst, err(by[f], ry))
+                else:
+                    rx, _ = o.training_XTX(folds[f])
+                worst = max(worst, err(bx[f], rx))
+                assert bool((bx[f] == bx[f].T).all())
     print("plan", os.environ.get("CVM_FORCE_SPLITS"), "worst norm-wise error %.3e" % worst)
     assert worst <= 1e-10, worst
 

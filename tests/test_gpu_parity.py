@@ -97,6 +97,9 @@ def assert_fp32_like_reference(got, ref64, ref32, what, floor=2e-6):
     scale = max(np.abs(ref64).max(), np.finfo(np.float64).tiny)
     err = np.abs(got - ref64).max() / scale
     yard = np.abs(ref32 - ref64).max() / scale
+    if os.environ.get("CVM_FP32_REPORT"):         # (calibration runs: every comparison's two errors)
+        with open(os.environ["CVM_FP32_REPORT"], "a") as fh:
+            fh.write(f"{what}\t{err:.3e}\t{yard:.3e}\t{floor:.1e}\n")
     assert err <= 2 * yard + floor, f"{what}: error {err:.3e} > 2 x reference float32 error {yard:.3e} + {floor}"
 
 
@@ -1441,7 +1444,37 @@ def test_forced_split_plans(plan):
     assert "worst norm-wise error" in r.stdout
 
 
-@pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["60", "101"]), ("fuzz_small.py", ["120", "102"])])
+@pytest.mark.parametrize("switch", ["CVM_NO_FUSED=1", "CVM_FORCE_FALLBACK=1", "CVM_NO_SWEEP_MERGE=1", "CVM_NO_DIRECT=1",
+                                    "CVM_NO_COMPACT=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0"])
+def test_route_forcing_switches(switch):
+    """One pass of tools/route_matrix.sh inside the suite: every route-forcing switch of the library
+    (read once per process, hence a subprocess each) over tests/forced_plan_check.py -- two-stage
+    path, sweep, per-fold calls, mid-size folds (fused epilogue / two-stage), folds of a few rows
+    (tile kernel / whole-rows kernel) -- against the oracle at 1e-10."""
+    import subprocess
+
+    k, v = switch.split("=")
+    env = dict(os.environ, **{k: v})
+    env.pop("CVM_FORCE_SPLITS", None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "forced_plan_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_wide_matrices_k8192_k16384():
+    """K = 8192 and 16384 (G of 0.27 / 1 GB in float32, 2 GB in float64), few folds, and an odd
+    K = 8191 with 40 folds: the fold stage against a from-scratch float64 computation of the centred /
+    scaled training-set matrices on the device (tools/big_k_check.py; float64 1e-10, float32 1e-3)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "big_k_check.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("XTX err") == 4, r.stdout
+
+
+@pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["400", "101"]), ("fuzz_small.py", ["600", "102"])])
 def test_randomised_routes_against_the_oracle(tool, args):
     """tools/fuzz_all.py / fuzz_small.py: random shapes, fold structures, element types, flags,
     weights, ddof, lazy or eager fit and call styles through every route of the fold stage,

@@ -32,5 +32,7 @@ for (N, K, M, P, dt) in ((20000, 8192, 3, 5, torch.float32), (6000, 16384, 2, 2,
     es = float((st[1][f, 0].double() - sdx).abs().max() / sdx.abs().max())
     sym = bool((bx[f] == bx[f].T).all())
     print(f"N={N} K={K} M={M} P={P} {dt}: XTX err {ex:.2e} XTY err {ey:.2e} std err {es:.2e} symmetric {sym}", flush=True)
+    bound = 1e-10 if dt == torch.float64 else 1e-3
+    assert sym and ex <= bound and ey <= bound and es <= (1e-10 if dt == torch.float64 else 1e-4), (ex, ey, es, sym)
     del X, Y, w, m, bx, by, rx, ry, Xs, Ys, Xc, Yc, Xt
     torch.cuda.empty_cache()
