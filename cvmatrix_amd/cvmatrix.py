@@ -73,12 +73,16 @@ def _same_indices(v: np.ndarray, seg: np.ndarray) -> bool:
 
 
 def _resolve_backend(backend: str) -> str:
-    """Counterpart of cvmatrix.py:58-96 for this package: the only backend is "hip"."""
-    if backend == "hip":
+    """Counterpart of cvmatrix.py:58-96 for this package.  ``"hip"``: results stay on the device
+    (torch tensors, like the reference's ``backend="jax"`` returns ``jax.Array``).  ``"numpy"``:
+    the reference's NumPy contract at the seam -- ndarray in, ndarray out, the reference's
+    attribute types -- so that a caller written for ``CVMatrix(backend="numpy")`` runs unchanged;
+    the arithmetic is still the HIP library's (there is no CPU path in this package)."""
+    if backend in ("hip", "numpy"):
         return backend
     # same form as cvmatrix.py:96 ("Invalid backend: 'x'. Must be 'numpy' or 'jax'."); the
-    # reference's own backends live in the reference package
-    raise ValueError(f"Invalid backend: {backend!r}. Must be 'hip'.")
+    # reference's JAX backend lives in the reference package
+    raise ValueError(f"Invalid backend: {backend!r}. Must be 'hip' or 'numpy'.")
 
 
 class FoldBatch:
@@ -195,6 +199,8 @@ class CVMatrix:
         # leaves results on the device, like the reference's backend="jax" returns jax.Array
         if output not in ("torch", "numpy"):
             raise ValueError(f"Invalid output: {output!r}. Must be 'torch' or 'numpy'.")
+        if backend == "numpy":
+            output = "numpy"
         self.output = output
         self._pending = False
         self.center_X, self.center_Y = center_X, center_Y
@@ -209,11 +215,22 @@ class CVMatrix:
             npdt = np.dtype(self.dtype)
         except TypeError as e:
             raise TypeError(f"dtype {dtype!r} is not a floating-point type") from e
+        if npdt.kind != "f":
+            raise TypeError(f"dtype {dtype!r} is not a floating-point type")
+        # The reference's dtype surface (tests/test_cvmatrix.py:1147-1205 runs float16, float32,
+        # float64 and float128).  The kernels compute in float32 or float64: float16 problems are
+        # rounded to float16 like the reference rounds its inputs (cvmatrix.py:1146), computed in
+        # float32 and returned as float16; wider types (np.longdouble) are computed in float64 and
+        # returned as NumPy arrays of the requested type (torch has no such dtype) -- 1e-16
+        # instead of 1e-19 relative, well inside the 1e-10 parity bar.
+        self._res_npdt = npdt                          # what results are handed out as
+        self._out_cast = None
         if npdt not in _TORCH_DT:
-            raise TypeError(
-                f"backend='hip' computes in float64 or float32, not {npdt.name}; "
-                "use the reference package for other dtypes."
-            )
+            if npdt.itemsize < 4:
+                self._out_cast, npdt = "half", np.dtype(np.float32)
+            else:
+                self._out_cast, npdt = "wide", np.dtype(np.float64)
+                self.output = "numpy"
         self._npdt, self._tdt = npdt, _TORCH_DT[npdt]
         self._cdt = _lib.CVM_F64 if npdt == np.float64 else _lib.CVM_F32
         self.resolution = np.finfo(self.dtype).resolution * 10  # cvmatrix.py:187
@@ -256,13 +273,21 @@ class CVMatrix:
     def _out(self, t, key=None):
         """A result in the form ``output`` asks for: the device tensor, or its NumPy copy
         (attributes are copied once per fit: ``key``)."""
-        if t is None or self.output != "numpy":
+        if t is None:
+            return t
+        if self._out_cast == "half" and self.output != "numpy":
+            return t.to(torch.float16)
+        if self.output != "numpy":
             return t
         if key is None:
-            return t.cpu().numpy()
+            return self._np_result(t)
         if key not in self._np_cache:
-            self._np_cache[key] = t.cpu().numpy()
+            self._np_cache[key] = self._np_result(t)
         return self._np_cache[key]
+
+    def _np_result(self, t):
+        a = t.cpu().numpy()
+        return a if self._out_cast is None else a.astype(self._res_npdt)
 
     # Results whose last dimensions are the DEVICE dims (the columns of the private device copies
     # may be padded, see ``fit``): cut back to the caller's K, M.  ``key``: an attribute (the cut
@@ -453,6 +478,8 @@ class CVMatrix:
         """cvmatrix.py:1131-1151 on the device: cast, copy iff needed, 1-D -> (N,1).
         ``pad_cols`` > columns: the private copy gets that many columns (zeros behind the data) and
         the returned tensor is the view of its first columns (same address, row stride pad_cols)."""
+        if self._out_cast == "half":                  # (the reference rounds its inputs to float16 first)
+            mat = (mat.to(torch.float16) if isinstance(mat, torch.Tensor) else np.asarray(mat, dtype=np.float16))
         if isinstance(mat, torch.Tensor):
             t = mat
             fresh = False
@@ -631,6 +658,8 @@ class CVMatrix:
                 weights = weights.detach().numpy()
             h = np.asarray(weights).reshape(-1)
             key = src = None
+        if self._out_cast == "half":
+            h = np.asarray(h).astype(np.float16)      # (non-zero counts are taken after the rounding, like the reference's)
         if bool(np.any(h < 0)):
             raise ValueError(MSG_NEG_W)
         self._w_host = np.array(h, dtype=self._npdt, copy=True)
@@ -1425,7 +1454,7 @@ class CVMatrix:
             0, ws.data_ptr(), ws.numel(), self._stream(),
         )
         _lib.check(rc, "cvm_fold_update")
-        if self.output == "numpy" or K != self._Ku or M != (self._Mu or 0):
+        if self.output == "numpy" or self._out_cast or K != self._Ku or M != (self._Mu or 0):
             o, oXX, oXY, oX, oY = self._out, self._oXX, self._oXY, self._oX, self._oY
             stats = (oX(stat[:K].view(1, K)) if r_muX else None, oX(stat[K:2 * K].view(1, K)) if r_sdX else None,
                      oY(stat[2 * K:2 * K + M].view(1, M)) if r_muY else None,

@@ -512,3 +512,70 @@ def test_two_threads_two_models_two_streams(amd, hip_device):
         assert len(got[i]) == len(want[i])
         for (a, b), (c, d) in zip(got[i], want[i]):
             assert torch.equal(a, c) and torch.equal(b, d)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.longdouble])
+def test_reference_dtype_surface_float16_and_float128(amd, dtype):
+    """The reference runs float16, float32, float64 and float128 (tests/test_cvmatrix.py:1147-1205).
+    float16: inputs rounded to float16 like cvmatrix.py:1146, arithmetic in float32, float16 results
+    -- at least as close to the float64 truth as the reference's own float16 arithmetic (the
+    oracle run in float16 is the yardstick).  np.longdouble: arithmetic in float64, NumPy results of
+    the requested type, 1e-10 norm-wise against the oracle run in long double."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    N, K, M, P = 240, 20, 3, 4
+    X, Y = rng.random((N, K)) + 0.5, rng.random((N, M))
+    w = rng.random(N) + 0.1
+    folds = [np.arange(f, N, P) for f in range(P)]
+    m = amd.CVMatrix(dtype=dtype)
+    m.fit(X, Y, w)
+    (bx, by), bst = m.training_XTX_XTY_batched(folds)
+    (lx, ly), lst = m.training_XTX_XTY(folds[1])
+    if dtype is np.float16:
+        assert bx.dtype == torch.float16 and lx.dtype == torch.float16 and m.XTX.dtype == torch.float16
+        X16, Y16, w16 = (a.astype(np.float16) for a in (X, Y, w))
+        truth = OracleCVMatrix(dtype=np.float64)
+        truth.fit(X16.astype(np.float64), Y16.astype(np.float64), w16.astype(np.float64))
+        ref16 = OracleCVMatrix(dtype=np.float16)
+        ref16.fit(X16, Y16, w16)
+        eps16 = float(np.finfo(np.float16).eps)
+        for f in (1, 3):
+            (tx, ty), tst = truth.training_XTX_XTY(folds[f])
+            with np.errstate(all="ignore"):
+                (rx, ry), _ = ref16.training_XTX_XTY(folds[f])
+            for got, t, r in ((bx[f], tx, rx), (by[f], ty, ry)):
+                scale = np.abs(t).max()
+                err = np.abs(to_np(got).astype(np.float64) - t).max() / scale
+                yard = np.nanmax(np.abs(np.asarray(r, dtype=np.float64) - t)) / scale
+                assert np.isfinite(err) and err <= 2 * (yard if np.isfinite(yard) else 1.0) + 4 * eps16, (err, yard)
+        assert_normwise(lx.float(), to_np(bx[1]).astype(np.float64), 1e-3, "per-fold call")
+    else:
+        assert isinstance(bx, np.ndarray) and bx.dtype == np.longdouble and isinstance(m.XTX, np.ndarray)
+        assert m.XTX.dtype == np.longdouble and lst[0].dtype == np.longdouble
+        ref = OracleCVMatrix(dtype=np.longdouble)
+        ref.fit(X.astype(np.longdouble), Y.astype(np.longdouble), w.astype(np.longdouble))
+        assert_normwise(m.XTX, np.asarray(ref.XTX, dtype=np.float64), 1e-10, "XTX")
+        for f in (0, 2):
+            (rx, ry), rst = ref.training_XTX_XTY(folds[f])
+            assert_normwise(bx[f], np.asarray(rx, dtype=np.float64), 1e-10, "XTX fold")
+            assert_normwise(by[f], np.asarray(ry, dtype=np.float64), 1e-10, "XTY fold")
+            assert_stats(tuple(s[f] for s in bst), tuple(np.asarray(s, dtype=np.float64) for s in rst), 1e-10, "stats")
+
+
+def test_backend_numpy_literal_runs_the_reference_call_sequence(amd):
+    """``CVMatrix(backend="numpy")`` -- the reference's default literal -- is accepted: ndarray in,
+    ndarray out (the arithmetic is the HIP library's)."""
+    rng = np.random.default_rng(3)
+    X, Y = rng.random((100, 12)), rng.random((100, 2))
+    m = amd.CVMatrix(backend="numpy")
+    m.fit(X, Y)
+    p = amd.Partitioner(np.arange(100) % 5)
+    o = OracleCVMatrix()
+    o.fit(X, Y)
+    for k in p.folds_dict:
+        (a, b), st = m.training_XTX_XTY(p.get_validation_indices(k))
+        assert isinstance(a, np.ndarray) and isinstance(st[0], np.ndarray)
+        (ra, rb), rst = o.training_XTX_XTY(p.get_validation_indices(k))
+        assert_normwise(a, ra, 1e-10, "XTX"); assert_normwise(b, rb, 1e-10, "XTY")
+    assert isinstance(m.XTX, np.ndarray)

@@ -84,13 +84,27 @@ def test_g3_leave_one_out_sweep(amd, chunk):
         pc.run_g3loo_case(name, make_factory(amd), TOL, batched=True)
 
 
-FP32_FLOOR = 2e-5   # a few hundred float32 roundings of the scale: sums of thousands of rows
+# BASELINE.md section 4 for float32: "error must not exceed 2x NumPy-fp32's own error".  The only
+# allowance on top is FOUR float32 roundings of the scale (4.8e-7): result and yardstick are both
+# float32 arrays, and where the yardstick itself is one or two roundings (uncentred sums, where
+# NumPy's blocked sgemm happens to be exact to a rounding) "twice" is below the resolution of the
+# comparison.  Calibration (round 3, CVM_FP32_REPORT): over the 1904 float32 comparisons of this
+# file 18 exceed twice the yardstick, by at most 0.6 roundings; of the 400 + 600 randomised cases
+# (tools/fuzz_all.py, fuzz_small.py) the first to fail a ONE-rounding allowance exceeded it by 1.1
+# (error 4.1 roundings against a yardstick of 1.0), with four all of them pass.  The 2e-5 / 2e-6
+# floors of rounds 1-2 were never needed.
+FP32_EPS = float(np.finfo(np.float32).eps)
+# float32 statistics against the float64 oracle on the same float32 inputs: the product sums in
+# float64 and rounds once, so means agree to a rounding; a standard deviation is the root of a
+# difference of sums and may lose a few more
+F32_STAT_RTOL = 2e-6
+FP32_FLOOR = 4 * FP32_EPS
 
 
-def assert_fp32_like_reference(got, ref64, ref32, what, floor=2e-6):
+def assert_fp32_like_reference(got, ref64, ref32, what, floor=FP32_FLOOR):
     """BASELINE.md section 4 for float32: the error against the float64 reference is at most
     twice the error of the reference's own float32 arithmetic (`ref32`: the oracle run in
-    float32 on the same float32 inputs), plus a floor of a few float32 roundings of the scale."""
+    float32 on the same float32 inputs), plus four float32 roundings of the scale."""
     got = to_np(got).astype(np.float64)
     ref64 = np.asarray(ref64, dtype=np.float64)
     ref32 = np.asarray(ref32, dtype=np.float64)
@@ -154,7 +168,7 @@ def test_leave_one_out_flag_sweep_rows_kernel(amd, K, weighted, dtype):
                         for a_, b_ in zip(tuple(None if s is None else s[f] for s in bst), rst):
                             assert (a_ is None) == (b_ is None)
                             if b_ is not None:
-                                np.testing.assert_allclose(to_np(a_).astype(np.float64), b_, rtol=3e-5)
+                                np.testing.assert_allclose(to_np(a_).astype(np.float64), b_, rtol=F32_STAT_RTOL)
                     else:
                         assert_normwise(bx[f], rx, TOL, what + " XTX")
                         assert_stats(tuple(None if s is None else s[f] for s in bst), rst, TOL, what)
@@ -199,7 +213,7 @@ def test_g6_digest_fp64(amd, name):
 
 def test_g6_digest_fp32_c5_scaled(amd):
     """C5 shape (K=4096, M=1, fp32), N scaled to 8000: fp32 result vs the fp64 reference
-    must be no worse than 2x the reference's own fp32 error (min 1e-5 slack)."""
+    must be no worse than 2x the reference's own fp32 error (+ four float32 roundings of the scale)."""
     name = "c5s"
     z = load_npz("g6_digest.npz")
     meta = load_json("g6_digest_meta.json")[name]
@@ -217,8 +231,8 @@ def test_g6_digest_fp32_c5_scaled(amd):
         k = f"{name}/fold{f}"
         x64 = to_np(bx[i]).astype(np.float64)
         y64 = to_np(by[i]).astype(np.float64)
-        bound_x = max(2 * float(z[f"{k}/ref32_XTX_relfro"]), 1e-5)
-        bound_y = max(2 * float(z[f"{k}/ref32_XTY_relfro"]), 1e-5)
+        bound_x = 2 * float(z[f"{k}/ref32_XTX_relfro"]) + FP32_FLOOR
+        bound_y = 2 * float(z[f"{k}/ref32_XTY_relfro"]) + FP32_FLOOR
         # sampled entries everywhere; whole rows of XTX and the whole XTY where the fixtures hold
         # them (folds 0 and 19): the norm of the difference against BASELINE.md section 4's bound,
         # twice NumPy's own float32 error -- no extra slack
@@ -427,7 +441,7 @@ def test_dtype_preserved_and_copy_semantics(amd, hip_device):
     m.fit(Xd)
     assert m.X.data_ptr() != Xd.data_ptr()
     with pytest.raises(TypeError):
-        amd.CVMatrix(dtype=np.float16)
+        amd.CVMatrix(dtype=np.int32)
     with pytest.raises(ValueError, match="Invalid backend"):
         amd.CVMatrix(backend="tpu")
 
@@ -704,7 +718,7 @@ def test_training_statistics_streaming_kernel(amd, K, M, dtype):
     w[rng.choice(N, 100, replace=False)] = 0
     perm = rng.permutation(N)
     folds = [perm[:900], perm[900:933], np.zeros(0, dtype=int), perm[933:1500], perm[1500:]]
-    tol = TOL if dtype == np.float64 else 2e-5
+    tol = TOL if dtype == np.float64 else F32_STAT_RTOL
     for flags in [(True,) * 4, (True, False, False, False), (False, False, True, True),
                   (False, True, False, True)]:
         for weights in (w, None):
@@ -847,7 +861,7 @@ def test_fused_single_split_epilogue_float32(amd, K, M):
                 for a_, b_ in zip(bst, rst):
                     assert (a_ is None) == (b_ is None)
                     if b_ is not None:
-                        np.testing.assert_allclose(to_np(a_[i]).astype(np.float64), b_, rtol=3e-5, atol=1e-6)
+                        np.testing.assert_allclose(to_np(a_[i]).astype(np.float64), b_, rtol=F32_STAT_RTOL, atol=1e-7)
             t = bx[check[1] + 1]
             assert bool((t == t.T).all())
 
@@ -1316,7 +1330,7 @@ def test_float32_shape_sweep(amd, K, M, route):
             for a_, b_ in zip(bst, rst):
                 assert (a_ is None) == (b_ is None)
                 if b_ is not None:
-                    np.testing.assert_allclose(to_np(a_[f]).astype(np.float64), b_, rtol=3e-5)
+                    np.testing.assert_allclose(to_np(a_[f]).astype(np.float64), b_, rtol=F32_STAT_RTOL)
             t = bx[f]
             assert bool((t == t.T).all())
 

@@ -71,11 +71,19 @@ def test_constructor_surface_and_errors():
     assert CVMatrix(dtype=np.dtype("float64")).dtype is np.float64
     assert CVMatrix().resolution == np.finfo(np.float64).resolution * 10  # ~1e-14
     assert m.X is None and m.XTX is None and m.sum_X is None and m.sum_w is None
-    for bad in ("numpy", "jax", "tpu"):
+    for bad in ("jax", "tpu"):
         # same form as the reference's message (cvmatrix.py:96)
         with pytest.raises(ValueError) as ei:
             CVMatrix(backend=bad)
-        assert str(ei.value) == f"Invalid backend: {bad!r}. Must be 'hip'."
+        assert str(ei.value) == f"Invalid backend: {bad!r}. Must be 'hip' or 'numpy'."
+    # the reference's default literal is accepted: the NumPy contract at the seam (ndarray results)
+    mn = CVMatrix(backend="numpy")
+    assert mn.backend == "numpy" and mn.output == "numpy"
+    # the reference's dtype surface (tests/test_cvmatrix.py:1147-1205): float16 computes in float32,
+    # wider than float64 in float64 (results as NumPy arrays of the requested type)
+    mh, mw = CVMatrix(dtype=np.float16), CVMatrix(dtype=np.longdouble)
+    assert mh.dtype is np.float16 and mh._npdt == np.float32 and mh.resolution == np.finfo(np.float16).resolution * 10
+    assert mw.dtype is np.longdouble and mw._npdt == np.float64 and mw.output == "numpy"
     with pytest.raises(ValueError, match="Invalid output"):
         CVMatrix(output="jax")
     assert CVMatrix(output="numpy").output == "numpy" and CVMatrix().output == "torch"
@@ -108,7 +116,7 @@ def test_library_carries_the_hash_of_its_sources():
     want = build.source_hash()
     assert lib.cvm_source_hash().decode() == want == build._embedded_hash_without_loading()
     assert want in lib.cvm_version().decode() and len(want) == 16
-    for bad in (np.float16, np.longdouble, np.int32):
+    for bad in (np.int32, np.complex128):
         with pytest.raises(TypeError):
             CVMatrix(dtype=bad)
 
