@@ -273,6 +273,10 @@ int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info)
   if (!make_pls_plan(n_folds, K, M, A, dtype == CVM_F64 ? 8 : 4, pls_cu_count(), p))
     return fail(CVM_EINVAL, "cvm_pls_plan: K too large for the LDS plan%s");
   info[0] = p.S; info[1] = p.rows; info[2] = p.folds_per_launch; info[3] = p.xres; info[4] = (int64_t)p.lds;
+  PlsRepPlan r;
+  if (make_pls_rep_plan(n_folds, K, M, A, dtype == CVM_F64 ? 8 : 4, pls_cu_count(), r)) {      // few folds: the one-barrier kernel
+    info[0] = r.S; info[1] = r.rows; info[2] = r.folds_per_launch; info[3] = 2; info[4] = (int64_t)r.lds;
+  }
   return CVM_OK;
 }
 

@@ -34,6 +34,10 @@ struct PlsArgs {
   void *B, *W, *P, *Q, *R;          // outputs ([F][A][K][M]; [F][K][A] x3 and [F][M][A], optional)
   int *n_fit;                       // [F]
   double eps;
+  // pls_rep_kernel (replicated small state): folds of this launch, folds per XCD, each slice's private
+  // copies of P^T and R^T ([fold][slice][2][A][K]), the folds' u exchange buffers ([fold][2][K])
+  int nf, per_x;
+  double *prw, *xu;
 };
 
 __host__ __device__ inline size_t pls_xch_len(int K, int M, int A, int S) {
@@ -584,6 +588,243 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
   if (s == 0 && tid == 0) a.n_fit[f] = fit;
 }
 
+// ----------------------------------------------------------------------------------
+// pls_rep_kernel (round 3): ONE per-fold barrier per component instead of four.
+// Everything of a component except u = XTX r is O(K (M + A)) work on small data -- the deflated
+// XTY (K x M), P, R, w, r -- and pls_kernel spends most of its 47 us per component (C3) waiting
+// for the other slices of its fold four times so that each may own only its rows of them.  Here
+// every slice of a fold keeps the WHOLE deflated XTY in LDS and whole P^T, R^T of its own in a
+// private global buffer (L2), and computes w, P^T w, r, q and the deflation redundantly -- the same
+// instructions on the same numbers, so all slices agree bit for bit -- while XTX alone stays cut
+// in row slices: a slice forms its rows of u, publishes them, and the one barrier of the component
+// is the all-gather of u.  The slices of a fold are placed on ONE XCD (block b runs on XCD b % 8:
+// tools/dispatch_probe.hip), where a device-coherent round trip costs 0.5-0.75 us instead of
+// 1.15-1.2 us across XCDs (tools/xcd_pingpong.hip); placement is a matter of speed only, the
+// accesses stay device-coherent.
+// ----------------------------------------------------------------------------------
+size_t pls_rep_lds_bytes(int K, int M, int A, int rows) {
+  const size_t yst = (size_t)(M | 1);
+  size_t d = 3 * (size_t)((K + 1) & ~1) + 3 * (size_t)M * M + PLS_NW * 256 + (PLS_MAXM + 2) + ((A + 2) & ~1) +
+             PLS_NW + 2 + (((size_t)K * yst + 1) & ~(size_t)1) + (((size_t)rows * M + 1) & ~(size_t)1);
+  return d * 8;
+}
+
+template <typename T>
+__global__ __launch_bounds__(PLS_THREADS) void pls_rep_kernel(const PlsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pls_smem[];
+  const int K = a.K, M = a.M, A = a.A, S = a.S;
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int f = (bi / S) * 8 + xcd, s = bi - (bi / S) * S;      // fold g of the launch lives on XCD g % 8
+  if (f >= a.nf) return;                                       // padding blocks of the XCD-affine grid
+  const int rows = a.rows;
+  const int k0 = s * rows;
+  const int n = (k0 + rows <= K) ? rows : (K - k0 > 0 ? K - k0 : 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int MM = M * M;
+  const int Kp = (K + 1) & ~1;
+  const int yst = M | 1;
+
+  double *rl = reinterpret_cast<double *>(pls_smem);           // r, w, u: all K rows
+  double *wl = rl + Kp;
+  double *ul = wl + Kp;
+  double *S0 = ul + Kp;
+  double *Ba = S0 + MM;
+  double *Bb = Ba + MM;
+  double *ms = Bb + MM;
+  double *qx = ms + PLS_NW * 256;
+  double *cx = qx + PLS_MAXM + 2;
+  double *red = cx + ((A + 2) & ~1);
+  int *lflag = reinterpret_cast<int *>(red + PLS_NW);
+  double *Yl = red + PLS_NW + 2;                               // the whole deflated XTY, pitch yst
+  double *Bl = Yl + (((size_t)K * yst + 1) & ~(size_t)1);      // running B of the slice's rows
+  double *qv = qx + 1, *cj = cx + 1;
+
+  const T *XTX = (const T *)a.XTX + (size_t)f * K * K;
+  const T *XTY = (const T *)a.XTY + (size_t)f * K * M;
+  double *Pp = a.prw + ((size_t)f * S + s) * 2 * (size_t)A * K;   // [A][K], this slice's own copy
+  double *Rp = Pp + (size_t)A * K;
+  double *xu = a.xu + (size_t)f * 2 * K;
+  unsigned *cnt = a.cnt + f;
+  unsigned target = 0;
+  const bool vec_ok = (K % (16 / (int)sizeof(T))) == 0;
+
+  for (int e = tid; e < K * M; e += PLS_THREADS) {
+    const int k = e / M, j = e - k * M;
+    Yl[(size_t)k * yst + j] = (double)XTY[e];
+  }
+  for (int e = tid; e < n * M; e += PLS_THREADS) Bl[e] = 0.0;
+  __syncthreads();
+
+  int fit = 0;
+  for (int c = 0; c < A; ++c) {
+    if (M > 1) {
+      // ---- XTY^T XTY over all rows, its dominant eigenvector q (as in pls_kernel, nothing traded)
+      if (M <= 16) pls_gram_phase<1, false>(Yl, yst, K, M, ms, S0, tid);
+      else pls_gram_phase<2, false>(Yl, yst, K, M, ms, S0, tid);
+      __syncthreads();
+      double tr = 0.0;
+      for (int i = 0; i < M; ++i) tr += S0[(size_t)i * M + i];
+      double *fin = Ba;
+      if (tr > 0.0) {
+        if (wave == 0) {
+          if (M <= 16) pls_eig_phase<1>(S0, tr, M, fin, lane);
+          else pls_eig_phase<2>(S0, tr, M, fin, lane);
+        }
+        __syncthreads();
+        double *scr = Bb;
+        int best = 0;
+        for (int i = 1; i < M; ++i) if (fin[(size_t)i * M + i] > fin[(size_t)best * M + best]) best = i;
+        if (tid < M) qv[tid] = fin[(size_t)tid * M + best];
+        __syncthreads();
+        for (int polish = 0; polish < 2; ++polish) {
+          double v = 0.0;
+          if (tid < M) for (int k = 0; k < M; ++k) v += S0[(size_t)tid * M + k] * qv[k];
+          if (tid < M) scr[tid] = v;
+          __syncthreads();
+          double nn = 0.0;
+          for (int k = 0; k < M; ++k) nn += scr[k] * scr[k];
+          nn = sqrt(nn);
+          if (tid < M) qv[tid] = nn > 0.0 ? v / nn : 0.0;
+          __syncthreads();
+        }
+      } else {
+        if (tid < M) qv[tid] = 0.0;
+        __syncthreads();
+      }
+    }
+    // ---- w (all rows), its norm, P^T w ---------------------------------------------------------
+    double nrm2 = 0.0;
+    for (int k = tid; k < K; k += PLS_THREADS) {
+      double v;
+      if (M == 1) v = Yl[k];
+      else {
+        v = 0.0;
+        for (int j = 0; j < M; ++j) v += Yl[(size_t)k * yst + j] * qv[j];
+      }
+      wl[k] = v;
+      nrm2 += v * v;
+    }
+    nrm2 = block_sum(nrm2, red);                               // (ends behind a barrier: wl is visible)
+    const double nrm = sqrt(nrm2);
+    if (!(nrm > a.eps)) break;                                 // every slice sees the same number
+    for (int j0 = wave * 4; j0 < c; j0 += 4 * PLS_NW) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = lane; k < K; k += 256) {
+        double pv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            pv[u][q] = (k + 64 * u < K && j0 + q < c) ? Pp[(size_t)(j0 + q) * K + k + 64 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double wv = (k + 64 * u < K) ? wl[k + 64 * u] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += pv[u][q] * wv;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0 && j0 + q < c) cj[j0 + q] = v / nrm;
+      }
+    }
+    __syncthreads();
+    // ---- r = w / |w| - R (P^T w) -----------------------------------------------------------------
+    for (int k = tid; k < K; k += PLS_THREADS) {
+      const double w = wl[k] / nrm;
+      double corr = 0.0;
+      for (int j0 = 0; j0 < c; j0 += 8) {
+        double rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rv[u] = (j0 + u < c) ? Rp[(size_t)(j0 + u) * K + k] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (j0 + u < c) corr += rv[u] * cj[j0 + u];
+      }
+      const double r = w - corr;
+      rl[k] = r;
+      Rp[(size_t)c * K + k] = r;
+      if (k >= k0 && k < k0 + n) {
+        if (a.W) ((T *)a.W)[((size_t)f * K + k) * A + c] = (T)w;
+        if (a.R) ((T *)a.R)[((size_t)f * K + k) * A + c] = (T)r;
+      }
+    }
+    __syncthreads();
+    // ---- the slice's rows of u = XTX r, published ----------------------------------------------
+    double *xuc = xu + (size_t)(c & 1) * K;
+    {
+      const T *xb = XTX + (size_t)k0 * K;
+      int done = 0;
+      if (vec_ok) {
+        done = n & ~3;
+        for (int i0 = wave * 4; i0 < done; i0 += 4 * PLS_NW) {
+          double acc[4] = {0.0, 0.0, 0.0, 0.0};
+          matvec_rows<T, 4>(xb + (size_t)i0 * K, (size_t)K, K, rl, lane, acc);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double v = wave_sum(acc[q]);
+            if (lane == 0) xput<true>(&xuc[k0 + i0 + q], v);
+          }
+        }
+      }
+      for (int i = done + wave; i < n; i += PLS_NW) {
+        double acc = 0.0;
+        for (int k = lane; k < K; k += 64) acc += (double)xb[(size_t)i * K + k] * rl[k];
+        acc = wave_sum(acc);
+        if (lane == 0) xput<true>(&xuc[k0 + i], acc);
+      }
+    }
+    if (!fold_barrier<true>(cnt, target, S, a.status, lflag)) return;
+    for (int k = tid; k < K; k += PLS_THREADS) ul[k] = xget<true>(&xuc[k]);
+    __syncthreads();
+    // ---- t^T t, q, p, deflation (all rows), B (the slice's rows) -------------------------------
+    double tt = 0.0;
+    for (int k = tid; k < K; k += PLS_THREADS) tt += rl[k] * ul[k];
+    tt = block_sum(tt, red);
+    for (int j = wave; j < M; j += PLS_NW) {
+      double acc = 0.0;
+      for (int k = lane; k < K; k += 64) acc += Yl[(size_t)k * yst + j] * rl[k];
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        const double qm = acc / tt;
+        qv[j] = qm;
+        if (a.Q && s == 0) ((T *)a.Q)[((size_t)f * M + j) * A + c] = (T)qm;
+      }
+    }
+    for (int k = tid; k < K; k += PLS_THREADS) {
+      const double p = ul[k] / tt;
+      ul[k] = p;
+      Pp[(size_t)c * K + k] = p;
+      if (a.P && k >= k0 && k < k0 + n) ((T *)a.P)[((size_t)f * K + k) * A + c] = (T)p;
+    }
+    __syncthreads();
+    for (int e = tid; e < K * M; e += PLS_THREADS) {
+      const int k = e / M, j = e - k * M;
+      Yl[(size_t)k * yst + j] = Yl[(size_t)k * yst + j] - (ul[k] * qv[j]) * tt;
+    }
+    T *Bout = (T *)a.B + (((size_t)f * A + c) * K + k0) * M;
+    for (int e = tid; e < n * M; e += PLS_THREADS) {
+      const int k = e / M, j = e - k * M;
+      const double b = Bl[e] + rl[k0 + k] * qv[j];
+      Bl[e] = b;
+      Bout[e] = (T)b;
+    }
+    __syncthreads();
+    fit = c + 1;
+  }
+  for (int c = fit; c < A; ++c) {
+    T *Bout = (T *)a.B + (((size_t)f * A + c) * K + k0) * M;
+    for (int e = tid; e < n * M; e += PLS_THREADS) Bout[e] = (T)0;
+    for (int k = tid; k < n; k += PLS_THREADS) {
+      if (a.W) ((T *)a.W)[((size_t)f * K + k0 + k) * A + c] = (T)0;
+      if (a.R) ((T *)a.R)[((size_t)f * K + k0 + k) * A + c] = (T)0;
+      if (a.P) ((T *)a.P)[((size_t)f * K + k0 + k) * A + c] = (T)0;
+    }
+    if (a.Q && s == 0 && tid < M) ((T *)a.Q)[((size_t)f * M + tid) * A + c] = (T)0;
+  }
+  if (s == 0 && tid == 0) a.n_fit[f] = fit;
+}
+
 // Before the launches of a call: the folds' barrier counters and the status word
 __global__ void pls_zero_kernel(unsigned *cnt, int64_t n, int32_t *status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -674,11 +915,39 @@ int pls_cu_count() {
   return cus;
 }
 
+// pls_rep_kernel's cut: few folds (at most 8 per XCD with at least 4 slices each), the whole deflated
+// XTY in LDS.  The slices of a fold sit on one XCD: per_x folds per XCD, S <= CUs-per-XCD / per_x.
+struct PlsRepPlan { int S, rows, per_x, folds_per_launch; size_t lds; };
+bool make_pls_rep_plan(int64_t F, int K, int M, int A, int esize, int cus, PlsRepPlan &p) {
+  static const bool off = getenv("CVM_PLS_NO_REP") != nullptr;      // tests / comparisons: the four-barrier kernel
+  const int per_xcd = cus / 8;
+  // for the problems whose components are bound by the barriers, not by streaming XTX: at most 64
+  // folds (one launch) and an XTX of at most 8 MB per fold (it stays in the L2 of the fold's XCD)
+  if (off || F < 1 || F > 64 || per_xcd < 8 || (size_t)K * K * esize > ((size_t)8 << 20)) return false;
+  const int64_t Fl = F;                                             // folds per launch
+  const int per_x = (int)((Fl + 7) / 8);
+  int S = per_xcd / per_x;
+  if (S > (K + 7) / 8) S = (K + 7) / 8;                             // >= 8 rows per slice
+  if (S < 4) return false;                                          // many folds: one slice per fold is the better cut
+  const int rows = (K + S - 1) / S;
+  S = (K + rows - 1) / rows;
+  const size_t lds = pls_rep_lds_bytes(K, M, A, rows);
+  if (lds > PLS_LDS_BUDGET) return false;
+  p.S = S; p.rows = rows; p.per_x = per_x; p.folds_per_launch = 8 * per_x; p.lds = lds;
+  return true;
+}
+
 size_t pls_workspace_bytes(int64_t F, int K, int M, int A, int esize, int cus) {
   PlsPlan p;
   if (!make_pls_plan(F, K, M, A, esize, cus, p)) return 0;
   const size_t per_fold = (2 * (size_t)K * M + 2 * (size_t)K * A + pls_xch_len(K, M, A, p.S)) * 8 + 16;
-  return (size_t)F * per_fold + 256;
+  size_t need = (size_t)F * per_fold + 256;
+  PlsRepPlan r;
+  if (make_pls_rep_plan(F, K, M, A, esize, cus, r)) {
+    const size_t rep = (size_t)F * ((size_t)r.S * 2 * A * K + 2 * (size_t)K) * 8 + (size_t)F * 16 + 256;
+    if (rep > need) need = rep;
+  }
+  return need;
 }
 
 template <typename T>
@@ -689,8 +958,52 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
   if (!make_pls_plan(F, K, M, A, sizeof(T), cus, p)) return fail(CVM_EINVAL, "cvm_pls_fit: K too large for the LDS plan%s");
   if (ws_bytes < pls_workspace_bytes(F, K, M, A, sizeof(T), cus)) return fail(CVM_EWORKSPACE, "cvm_pls_fit: workspace too small%s");
   if (F == 0) return CVM_OK;
+  PlsRepPlan rp;
+  if (make_pls_rep_plan(F, K, M, A, (int)sizeof(T), cus, rp)) {
+    // few folds: replicated small state, one barrier per component (pls_rep_kernel)
+    double *d = reinterpret_cast<double *>(ws);
+    PlsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.K = K; a.M = M; a.A = A; a.S = rp.S; a.rows = rp.rows; a.per_x = rp.per_x;
+    a.prw = d; d += (size_t)F * rp.S * 2 * A * K;
+    a.xu = d; d += (size_t)F * 2 * K;
+    a.cnt = reinterpret_cast<unsigned *>(d);
+    a.status = status;
+    a.eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+    hipLaunchKernelGGL(pls_zero_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, a.cnt, F, status);
+    void (*kern)(const PlsArgs) = pls_rep_kernel<T>;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp.lds));
+    int per_cu = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), PLS_THREADS, rp.lds));
+    if (per_cu < 1) return fail(CVM_ELAUNCH, "cvm_pls_fit: the replicated-state launch would not be resident on this device%s");
+    for (int64_t f0 = 0; f0 < F; f0 += rp.folds_per_launch) {
+      const int64_t nf = F - f0 < rp.folds_per_launch ? F - f0 : rp.folds_per_launch;
+      PlsArgs b = a;
+      b.nf = (int)nf;
+      b.XTX = (const T *)XTX + (size_t)f0 * K * K;
+      b.XTY = (const T *)XTY + (size_t)f0 * K * M;
+      b.prw = a.prw + (size_t)f0 * rp.S * 2 * A * K;
+      b.xu = a.xu + (size_t)f0 * 2 * K;
+      b.cnt = a.cnt + f0;
+      b.B = (T *)B + (size_t)f0 * A * K * M;
+      b.W = W ? (T *)W + (size_t)f0 * K * A : nullptr;
+      b.P = P ? (T *)P + (size_t)f0 * K * A : nullptr;
+      b.R = R ? (T *)R + (size_t)f0 * K * A : nullptr;
+      b.Q = Q ? (T *)Q + (size_t)f0 * M * A : nullptr;
+      b.n_fit = n_fit + f0;
+      // (fold g of the launch -> XCD g % 8)
+      hipLaunchKernelGGL(kern, dim3((unsigned)(8 * rp.per_x * rp.S)), dim3(PLS_THREADS), rp.lds, st, b);
+      HIP_OK(hipGetLastError());
+    }
+    hipLaunchKernelGGL((pls_poison_kernel<T>), dim3(256), dim3(256), 0, st, (const int *)status, (T *)B,
+                       (size_t)F * A * K * M, (T *)W, (T *)P, (T *)R, (size_t)F * K * A, (T *)Q, (size_t)F * M * A,
+                       (int *)n_fit, F);
+    HIP_OK(hipGetLastError());
+    return CVM_OK;
+  }
   double *d = reinterpret_cast<double *>(ws);
   PlsArgs a;
+  memset(&a, 0, sizeof(a));
   a.K = K; a.M = M; a.A = A; a.S = p.S; a.rows = p.rows; a.y_in_lds = p.y_in_lds; a.pr_in_lds = p.pr_in_lds;
   a.Yw = d; d += (size_t)F * K * M;
   a.Bw = d; d += (size_t)F * K * M;

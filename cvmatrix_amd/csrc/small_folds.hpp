@@ -410,7 +410,20 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
     dvec_t muc, sdc;     // mean, std of this thread's columns
     T sx, sw;            // staged by thread r * 8 + i: x[row r][a0 + i], w[row r]
     double sst;          // staged by threads 0..15: mean / std of panel row
+    double swt;          // the fold's training weight sum
+    // XTY element (row i, column m) of thread i * M + m (8 M <= 256): y of the validation rows,
+    // the four statistics it needs
+    T yv[NV];
+    double ya, yb, yc, yd;
   };
+  // (every per-fold load sits in `fetch`, one fold ahead: a load issued and consumed inside an
+  //  iteration would make the wave wait for everything older in the in-order memory counter --
+  //  the next fold's prefetch and the previous stores -- and serialise the folds)
+  const bool xty_fast = a.out_XTY && M > 0 && SR_ROWS * M <= 256;
+  const int yi = tid / (M > 0 ? M : 1), ym = tid - yi * (M > 0 ? M : 1);
+  const bool y_mine = xty_fast && cc == 0 && tid < SR_ROWS * M && a0 + yi < K;
+  T y_h = (T)0;
+  if (y_mine) y_h = ((const T *)a.H)[(size_t)(a0 + yi) * M + ym];
   const int f_lo = by * a.fpb;
   const int f_hi = (f_lo + a.fpb < a.nb) ? f_lo + a.fpb : a.nb;
   auto fetch = [&](int f, Pre &p) {
@@ -445,6 +458,21 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
       }
       p.sst = v;
     }
+    p.swt = fs[2 * K + 2 * M];
+    p.ya = p.yb = p.yc = p.yd = 0.0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) p.yv[u] = (T)0;
+    if (y_mine) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+        if (u < p.n) {
+          const int64_t ridx = inl ? a.inl[u] : a.idx[o0 + u];
+          p.yv[u] = Y[ridx * (int64_t)M + ym];
+        }
+      if (cX || cY) { p.ya = fs[a0 + yi]; p.yb = fs[2 * K + ym]; }
+      if (sX) p.yc = fs[K + a0 + yi];
+      if (sY) p.yd = fs[2 * K + M + ym];
+    }
   };
   Pre cur, nxt;
   if (f_lo < f_hi) fetch(f_lo, cur);
@@ -459,10 +487,10 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
       if (i == 0) wl[b][r] = (double)cur.sw;
     }
     if (tid < 2 * SR_ROWS) str[b][tid / SR_ROWS][tid % SR_ROWS] = cur.sst;
-    __syncthreads();
+    lds_barrier();                                // (LDS only: the previous fold's stores need no acknowledgement)
     if (f + 1 < f_hi) fetch(f + 1, nxt);          // in flight during the arithmetic and the stores below
     const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-    const double swt = fs[2 * K + 2 * M];
+    const double swt = cur.swt;
     const size_t fo = (size_t)(a.seg0 + f);
     if (do_xx) {
       TS acc[NP][VW];
@@ -499,7 +527,20 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
       }
     }
     // the panel's rows of XTY (first column chunk only)
-    if (a.out_XTY && M > 0 && cc == 0) {
+    if (xty_fast) {
+      if (y_mine) {
+        TS sacc = 0;
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+          if (u < n) sacc += wxr[b][u][yi] * (TS)cur.yv[u];
+        double v = (double)y_h - (double)sacc;
+        if (cX || cY) v -= swt * (cur.ya * cur.yb);
+        if (sX && sY) v = v * (cur.yc * cur.yd);
+        else if (sX) v = v * cur.yc;
+        else if (sY) v = v * cur.yd;
+        ((T *)a.out_XTY)[fo * (size_t)K * M + (size_t)(a0 + yi) * M + ym] = (T)v;
+      }
+    } else if (a.out_XTY && M > 0 && cc == 0) {
       const T *Ht = (const T *)a.H;
       T *out = (T *)a.out_XTY + fo * (size_t)K * M;
       const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];

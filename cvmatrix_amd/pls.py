@@ -39,7 +39,9 @@ def pls_plan(n_folds: int, K: int, M: int, A: int, dtype=np.float64) -> dict:
     code = _lib.CVM_F64 if np.dtype(dtype) == np.float64 else _lib.CVM_F32
     _lib.check(lib.cvm_pls_plan(n_folds, K, M, A, code, info.ctypes.data), "cvm_pls_plan")
     return {"slices": int(info[0]), "rows": int(info[1]), "folds_per_launch": int(info[2]),
-            "xtx_in_lds": bool(info[3]), "lds_bytes": int(info[4])}
+            "xtx_in_lds": int(info[3]) == 1, "lds_bytes": int(info[4]),
+            "kernel": "replicated small state, one barrier per component" if int(info[3]) == 2
+            else ("row slices, four barriers per component" if int(info[0]) > 1 else "one workgroup per fold")}
 
 
 def pls_fit_batched(XTX: torch.Tensor, XTY: torch.Tensor, A: int, *, return_factors: bool = False,

@@ -197,7 +197,9 @@ int cvm_pls_fit(const void *XTX, const void *XTY, int64_t n_folds, int K, int M,
                 void *B, void *W, void *P, void *Q, void *R, int32_t *n_fit, int32_t *status,
                 void *ws, size_t ws_bytes, void *stream);
 /* info[0]=row slices per fold, [1]=rows per slice, [2]=folds per launch, [3]=1 if the slice of XTX
- * stays in LDS, [4]=LDS bytes per workgroup */
+ * stays in LDS, 0 if it is streamed, 2: few folds -- the kernel that keeps the small state of a fold
+ * (deflated XTY, P, R) whole in every slice and passes ONE per-fold barrier per component, XTX
+ * streamed from L2, the slices of a fold on one XCD; [4]=LDS bytes per workgroup */
 int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info);
 
 /* Benchmark support: when enabled, a hipEvent pair is recorded on the launch stream around

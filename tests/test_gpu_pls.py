@@ -238,3 +238,17 @@ def test_tiny_shapes(pls, K, M, A, F):
     XTY = np.stack([rng.standard_normal((K, M)) for _ in range(F)])
     fit = pls.pls_fit_batched(torch.from_numpy(XTX).cuda(), torch.from_numpy(XTY).cuda(), A, return_factors=True)
     check_against_oracle(fit, XTX, XTY, A, 1e-8)
+
+
+def test_four_barrier_kernel_still_agrees(pls):
+    """CVM_PLS_NO_REP=1 (read once per process): the row-sliced kernel with four barriers per component,
+    which problems with 65-255 folds and wide response blocks still take, over this file's oracle and
+    repeatability tests."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, CVM_PLS_NO_REP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x",
+                        "-k", "not four_barrier and not example"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

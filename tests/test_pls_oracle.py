@@ -66,9 +66,11 @@ def test_oracle_stops_when_xty_is_exhausted():
 
 def test_device_pls_plan_is_host_logic():
     from cvmatrix_amd.pls import pls_plan
-    p = pls_plan(10, 512, 16, 20)                       # few folds: slices, XTX slice resident in LDS
-    assert p["slices"] * p["rows"] >= 512 and p["slices"] * 10 <= 256 and p["xtx_in_lds"]
-    assert p["lds_bytes"] <= 150 * 1024
+    p = pls_plan(10, 512, 16, 20)                       # few folds: the one-barrier kernel, a fold's slices on one XCD
+    assert p["slices"] * p["rows"] >= 512 and p["slices"] * 2 <= 32 and "one barrier" in p["kernel"]
+    assert p["lds_bytes"] <= 150 * 1024 and p["folds_per_launch"] >= 10
+    p = pls_plan(64, 1024, 32, 20)                      # the whole deflated XTY does not fit in LDS: row slices, four barriers
+    assert p["slices"] > 1 and p["slices"] * p["folds_per_launch"] <= 256 and "four barriers" in p["kernel"]
     p = pls_plan(1000, 500, 10, 30)                     # many folds: one workgroup per fold
     assert p["slices"] == 1 and p["rows"] == 500 and not p["xtx_in_lds"]
     p = pls_plan(20, 4096, 1, 20, np.float32)           # wide K: sliced, streamed
