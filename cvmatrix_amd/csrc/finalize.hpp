@@ -49,6 +49,10 @@ struct FinArgs {
   unsigned flags;
   int32_t *neg_flag;
   int gx, gy;           // apply_kernel<.., true>: sub-tiles + panels, folds of the launch
+  int inline_stats;     // apply_kernel<.., true>: no fold_stats_kernel ran -- every workgroup derives the
+                        // fold statistics its tile needs from the partials' column sums itself (same
+                        // chains, same bits) and designated workgroups write the statistics outputs: one
+                        // launch and one launch gap less per call of cvm_sweep_folds / cvm_sweep_fold_range
   int compact;          // fit mode over several segments (the one-sweep path, float64): every segment's
                         // subtotal -- the fold's raw update U_f = sum_sp partial, exactly the chain the fold
                         // stage forms -- is written back to the segment's slot 0, so that the fold stage
@@ -155,6 +159,56 @@ __device__ __forceinline__ void fold_column_finish(const FinArgs &a, int f, bool
   const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
   if (omu) omu[o] = (T)mu;
   if (osd && want_sd) osd[o] = (T)sd;
+}
+
+// The same arithmetic for workgroups that derive the statistics they need themselves
+// (FinArgs::inline_stats): the fold's weight sum / non-zero count (every thread, the same loads),
+template <typename T>
+__device__ __forceinline__ void inline_fold_totals(const FinArgs &a, int f, double &swv, double &nzv, double &swt,
+                                                   double &nzt, double &divisor) {
+  const Geom &g = a.g;
+  const int K = g.K, M = g.M;
+  const long u0 = (long)f * a.splits;
+  swv = 0; nzv = 0;
+  if (a.w != nullptr) {
+    for (int p = 0; p < a.s_diag; ++p) {               // split order, like fold_stats_kernel's lane sums
+      const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
+      swv += st[2 * g.Kp + 2 * g.Mp + 0]; nzv += st[2 * g.Kp + 2 * g.Mp + 1];
+    }
+  } else {
+    swv = nzv = (double)(a.offs[a.seg0 + f + 1] - a.offs[a.seg0 + f]);
+  }
+  const double gsw = a.gstats[2 * K + 2 * M], gnz = a.gstats[2 * K + 2 * M + 1];
+  swt = gsw - swv; nzt = gnz - nzv;
+  divisor = (nzt - a.ddof) * swt / nzt;
+}
+// and one column: mean and RECIPROCAL std (std itself in `sd`), fold_column_finish's formulas
+template <typename T>
+__device__ __forceinline__ void inline_column_stat(const FinArgs &a, int f, bool isX, int cc, double swt, double divisor,
+                                                   bool want_sd, double &mu, double &isd, double &sd) {
+  const Geom &g = a.g;
+  const int K = g.K, M = g.M;
+  const long u0 = (long)f * a.splits;
+  const int s_src = isX ? cc : 2 * g.Kp + cc;
+  const int q_src = isX ? g.Kp + cc : 2 * g.Kp + g.Mp + cc;
+  double sv = 0, qv = 0;
+  for (int p = 0; p < a.s_diag; ++p) {
+    const double *st = unit_stats<T>((char *)a.ws, g, u0 + p);
+    sv += st[s_src]; qv += st[q_src];
+  }
+  const double gs = isX ? a.gstats[cc] : a.gstats[2 * K + cc];
+  const double gq = isX ? a.gstats[K + cc] : a.gstats[2 * K + M + cc];
+  const double st_ = gs - sv;          // cvmatrix.py:1020
+  mu = st_ / swt;                      // cvmatrix.py:1043
+  sd = 1.0;
+  if (want_sd) {
+    const double qt = gq - qv;
+    double var = (-2 * mu * st_ + swt * (mu * mu) + qt) / divisor;   // 1119-1123
+    var = (var < 0) ? 0.0 : var;
+    sd = sqrt(var);
+    if (sd <= a.resolution) sd = 1.0;  // 1128
+  }
+  isd = 1.0 / sd;
 }
 
 // fold: training-set mean / std of every column; reference operation order
@@ -442,6 +496,7 @@ __device__ __forceinline__ void fused_finish_block(T (*Ts)[TP], const double *rs
 constexpr int APPLY_THREADS = 256;        // fold mode: one workgroup per (fold, sub-tile), plenty of them
 constexpr int APPLY_THREADS_FIT = 1024;   // fit mode: 44 workgroups at K = 512 -- more threads each
 constexpr int APPLY_SUB = 4;   // 64x64 sub-tiles per 128x128 tile
+constexpr int APPLY_INLINE_MAXM = 512;   // responses up to which a workgroup keeps the Y statistics itself (inline_stats)
 template <typename T, bool FOLD>
 __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void apply_kernel(const FinArgs a) {
   constexpr int NTHR = FOLD ? APPLY_THREADS : APPLY_THREADS_FIT;
@@ -464,12 +519,26 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
   }
   const int K = g.K, M = g.M;
   const long u0 = (long)f * a.splits;
-  const double *fs = FOLD ? a.fstats + (size_t)f * fstat_len(K, M) : nullptr;
-  const double swt = FOLD ? fs[2 * K + 2 * M] : 0.0;
+  const bool inl = FOLD && a.inline_stats;
+  const double *fs = (FOLD && !inl) ? a.fstats + (size_t)f * fstat_len(K, M) : nullptr;
+  double swt = (FOLD && !inl) ? fs[2 * K + 2 * M] : 0.0;
+  double divisor = 0, swv = 0, nzv = 0, nzt = 0;
+  if (inl) inline_fold_totals<T>(a, f, swv, nzv, swt, nzt, divisor);
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const bool rXTY = a.flags & CVM_RET_XTY;
+  const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
+  const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
+  // who writes the statistics outputs (inline_stats): the X statistics of a 128-column panel by the
+  // panel's XTY workgroup when XTY is produced, else (XTX only) by the diagonal 64 x 64 sub-tiles;
+  // the Y statistics and the per-fold diagnostics by the first XTY workgroup / sub-tile 0
+  const bool xty_wgs = a.out_XTY && M > 0;
   const size_t fo = (size_t)(a.seg0 + f);
   const char *ws0 = a.ws + (size_t)u0 * g.unit_bytes;
+  if (inl && x == 0 && threadIdx.x == 0 && a.out_fold) {
+    double *o = a.out_fold + 4 * (a.seg0 + f);
+    o[0] = swt; o[1] = nzt; o[2] = swv; o[3] = nzv;
+  }
   if (x < g.nTiles * APPLY_SUB) {
     if (!a.out_XTX) return;
     const int t = x / APPLY_SUB, sub = x - t * APPLY_SUB;
@@ -486,7 +555,23 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     constexpr int LPR = ST / VW;
     typedef T vld_t __attribute__((ext_vector_type(VW)));
     const int tid = threadIdx.x;
-    if (FOLD) stage_tile_stats(st_lds, fs, a0, b0, K, tid);   // (visible after the barrier below)
+    if (FOLD && !inl) stage_tile_stats(st_lds, fs, a0, b0, K, tid);   // (visible after the barrier below)
+    if (inl && tid < 4 * ST) {
+      const int part = tid / ST, l = tid - part * ST;
+      const int col = ((part < 2) ? a0 : b0) + l;
+      double v = (part & 1) ? 1.0 : 0.0;
+      if (col < K && want_muX) {
+        double mu, isd, sd;
+        inline_column_stat<T>(a, f, true, col, swt, divisor, want_sdX, mu, isd, sd);
+        v = (part & 1) ? isd : mu;
+        if (!xty_wgs && ti == tj && si == sj && part < 2) {            // this sub-tile owns columns a0 .. a0 + 63
+          const size_t o = fo * K + col;
+          if (part == 0 && a.out_muX) ((T *)a.out_muX)[o] = (T)mu;
+          if (part == 1 && a.out_sdX && want_sdX) ((T *)a.out_sdX)[o] = (T)sd;
+        }
+      }
+      st_lds[tid] = v;
+    }
     // every thread owns NQ 16-byte pieces of the sub-tile; the splits are summed in order, the
     // pieces of one split loaded together (NQ independent loads in flight: a fit with 25 splits
     // is otherwise one long chain of dependent latencies on 44 workgroups)
@@ -571,6 +656,42 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     T *out = (T *)a.out_XTY + (FOLD ? fo * (size_t)K * M : 0);
     const T *Ht = (const T *)a.H;
     const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
+    // inline_stats: this workgroup derives (and writes out) the X statistics of its 128 rows and, panel
+    // 0, the Y statistics; M <= APPLY_INLINE_MAXM (the host checks)
+    __shared__ double xs_l[2 * TILE];
+    __shared__ double ys_l[2 * APPLY_INLINE_MAXM];
+    if (inl) {
+      const int tid = threadIdx.x;
+      for (int q = tid; q < 2 * TILE; q += NTHR) {
+        const int part = q / TILE, l = q - part * TILE, col = ti * TILE + l;
+        double v = part ? 1.0 : 0.0;
+        if (col < K && want_muX) {
+          double mu, isd, sd;
+          inline_column_stat<T>(a, f, true, col, swt, divisor, want_sdX, mu, isd, sd);
+          v = part ? isd : mu;
+          const size_t o = fo * K + col;
+          if (part == 0 && a.out_muX) ((T *)a.out_muX)[o] = (T)mu;
+          if (part == 1 && a.out_sdX && want_sdX) ((T *)a.out_sdX)[o] = (T)sd;
+        }
+        xs_l[q] = v;
+      }
+      for (int q = tid; q < 2 * M; q += NTHR) {
+        const int part = q / M, m = q - part * M;
+        double v = part ? 1.0 : 0.0;
+        if (want_muY) {
+          double mu, isd, sd;
+          inline_column_stat<T>(a, f, false, m, swt, divisor, want_sdY, mu, isd, sd);
+          v = part ? isd : mu;
+          if (ti == 0) {
+            const size_t o = fo * M + m;
+            if (part == 0 && a.out_muY) ((T *)a.out_muY)[o] = (T)mu;
+            if (part == 1 && a.out_sdY && want_sdY) ((T *)a.out_sdY)[o] = (T)sd;
+          }
+        }
+        ys_l[part * APPLY_INLINE_MAXM + m] = v;
+      }
+      __syncthreads();
+    }
     for (int e = threadIdx.x; e < TILE * M; e += NTHR) {
       const int ra = e / M, m = e - ra * M;
       const int ga = ti * TILE + ra;
@@ -586,11 +707,13 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
         if (++kk == a.s_diag) { v += us; us = 0; kk = 0; }     // (segment sums, then their sum)
       }
       if (FOLD) {
+        const double mx = inl ? xs_l[ra] : fs[ga], ix = inl ? xs_l[TILE + ra] : fs[K + ga];
+        const double my = inl ? ys_l[m] : fs[2 * K + m], iy = inl ? ys_l[APPLY_INLINE_MAXM + m] : fs[2 * K + M + m];
         v = (double)Ht[(size_t)ga * M + m] - v;
-        if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
-        if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + m]);
-        else if (sX) v = v * fs[K + ga];
-        else if (sY) v = v * fs[2 * K + M + m];
+        if (cX || cY) v -= swt * (mx * my);
+        if (sX && sY) v = v * (ix * iy);
+        else if (sX) v = v * ix;
+        else if (sY) v = v * iy;
       }
       out[(size_t)ga * M + m] = (T)v;
     }

@@ -778,8 +778,16 @@ int sweep_folds_impl(const int64_t *offsets, int64_t n_total, int64_t fold0, int
   f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
   f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
   f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
-  hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)n_folds, (unsigned)fold_stats_chunks(K, M, n_folds)), dim3(256), 0, st, f);
-  if (f.out_XTX || f.out_XTY) {
+  // Matrices wanted and few partials per fold (compacted: one): every workgroup of apply_kernel derives
+  // the fold statistics of its tile itself and the statistics kernel is not launched at all -- one
+  // launch and one launch gap less per call (the per-rank step of the multi-GPU path, the reference's
+  // per-fold loop).  CVM_NO_INLINE_STATS: the two-launch route (tests).
+  static const bool no_inline = getenv("CVM_NO_INLINE_STATS") != nullptr;
+  const bool mats = f.out_XTX || f.out_XTY;
+  f.inline_stats = (mats && !no_inline && f.s_diag <= 4 && M <= APPLY_INLINE_MAXM) ? 1 : 0;
+  if (!f.inline_stats)
+    hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)n_folds, (unsigned)fold_stats_chunks(K, M, n_folds)), dim3(256), 0, st, f);
+  if (mats) {
     f.gx = g.nTiles * APPLY_SUB + g.P; f.gy = (int)n_folds;
     hipLaunchKernelGGL((apply_kernel<T, true>), dim3((unsigned)(8 * (((size_t)f.gx * f.gy + 7) / 8))),
                        dim3(APPLY_THREADS), 0, st, f);

@@ -1046,7 +1046,10 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
       fetch(fx, fq, probe);
       s_next[(n + 1) & 1][0] = fx; s_next[(n + 1) & 1][1] = fq;
     }
-    __syncthreads();                             // the item is finished with the LDS ring; s_next is visible
+    // the item is finished with the LDS ring; s_next is visible.  LDS only: the item's output / partial
+    // stores need not be acknowledged before the next item's loaders start (a __syncthreads() here
+    // made every wave wait for them -- several microseconds per item with stores streaming to HBM)
+    lds_barrier();
   }
   // the queue block is the library's (host.hpp: queue pool) and must be all zero again for its
   // next launch: the last workgroup to leave -- every other one has made its last fetch -- clears it

@@ -1459,7 +1459,7 @@ def test_forced_split_plans(plan):
 
 
 @pytest.mark.parametrize("switch", ["CVM_NO_FUSED=1", "CVM_FORCE_FALLBACK=1", "CVM_NO_SWEEP_MERGE=1", "CVM_NO_DIRECT=1",
-                                    "CVM_NO_COMPACT=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0"])
+                                    "CVM_NO_COMPACT=1", "CVM_NO_INLINE_STATS=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0"])
 def test_route_forcing_switches(switch):
     """One pass of tools/route_matrix.sh inside the suite: every route-forcing switch of the library
     (read once per process, hence a subprocess each) over tests/forced_plan_check.py -- two-stage
