@@ -29,6 +29,7 @@ EXPORTS = (
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds", "cvm_sweep_fold_range", "cvm_sweep_all",
     "cvm_partition_workspace_bytes", "cvm_partition_labels",
     "cvm_pls_workspace_bytes", "cvm_pls_fit", "cvm_pls_plan",
+    "cvm_pls_sse_workspace_bytes", "cvm_pls_validation_sse",
 )
 
 _lib = None
@@ -104,6 +105,11 @@ def load():
                                 vp, vp, vp, sz, vp]
     lib.cvm_pls_plan.restype = C.c_int
     lib.cvm_pls_plan.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.cvm_pls_sse_workspace_bytes.restype = sz
+    lib.cvm_pls_sse_workspace_bytes.argtypes = [i64, i64, C.c_int, C.c_int]
+    lib.cvm_pls_validation_sse.restype = C.c_int
+    lib.cvm_pls_validation_sse.argtypes = [vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.cvm_timing_enable.restype = C.c_int
     lib.cvm_timing_enable.argtypes = [C.c_int]
     lib.cvm_timing_read.restype = C.c_int

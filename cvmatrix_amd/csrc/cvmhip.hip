@@ -266,6 +266,27 @@ int cvm_pls_fit(const void *XTX, const void *XTY, int64_t n_folds, int K, int M,
   return fail(CVM_EINVAL, "cvm_pls_fit: dtype must be CVM_F32 or CVM_F64%s");
 }
 
+size_t cvm_pls_sse_workspace_bytes(int64_t n_folds, int64_t max_fold_rows, int M, int A) {
+  if (n_folds < 0 || max_fold_rows < 0 || M <= 0 || A <= 0) return 0;
+  return pls_sse_workspace_bytes(n_folds, max_fold_rows, M, A);
+}
+
+int cvm_pls_validation_sse(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
+                           int64_t n_folds, int64_t max_fold_rows, int K, int M, int A, int dtype, const void *muX,
+                           const void *sdX, const void *muY, const void *sdY, const void *B, double *sse,
+                           double *wsum, void *ws, size_t ws_bytes, void *stream) {
+  if (!X || !Y || !offsets || !B || !sse || !wsum || !ws) return fail(CVM_EINVAL, "cvm_pls_validation_sse: null pointer%s");
+  if (n_folds < 0 || max_fold_rows < 0 || K <= 0 || M <= 0 || A <= 0 || (!idx && max_fold_rows > 0))
+    return fail(CVM_EINVAL, "cvm_pls_validation_sse: bad shape%s");
+  if (dtype == CVM_F64)
+    return pls_sse_impl<double>(X, Y, w, idx, offsets, n_folds, max_fold_rows, K, M, A, muX, sdX, muY, sdY, B, sse, wsum, ws,
+                                ws_bytes, (hipStream_t)stream);
+  if (dtype == CVM_F32)
+    return pls_sse_impl<float>(X, Y, w, idx, offsets, n_folds, max_fold_rows, K, M, A, muX, sdX, muY, sdY, B, sse, wsum, ws,
+                               ws_bytes, (hipStream_t)stream);
+  return fail(CVM_EINVAL, "cvm_pls_validation_sse: dtype must be CVM_F32 or CVM_F64%s");
+}
+
 int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info) {
   if (!info || n_folds < 0 || K <= 0 || M <= 0 || M > PLS_MAXM || A <= 0 || A > PLS_MAXA)
     return fail(CVM_EINVAL, "cvm_pls_plan: bad argument%s");

@@ -1057,3 +1057,177 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
   }
   return CVM_OK;
 }
+
+// ----------------------------------------------------------------------------------
+// Validation errors of the folds' PLS models (round 3): the last step of a cross-validation on the
+// device.  For fold f, model with a + 1 components, response m:
+//   sse[f][a][m] = sum over the fold's validation rows i of
+//                  w_i ( ((x_i - muX_f) / sdX_f) . B[f][a][:, m] * sdY_f[m] + muY_f[m] - y_im )^2
+//   wsum[f]      = sum w_i
+// (centre / scale vectors are the fold stage's statistics outputs; a NULL one means 0 / 1).
+// One workgroup = 64 validation rows x 64 of the A M columns (a, m): the standardised rows and the
+// coefficient columns go through LDS 16 k at a time, wave w owns row tile w and four MFMA column
+// tiles; the squared errors are summed over the rows in a fixed order (registers -> lanes ->
+// waves -> a second small kernel over the row chunks: no float atomics).
+// ----------------------------------------------------------------------------------
+constexpr int SSE_ROWS = 64, SSE_COLS = 64, SSE_KS = 16, SSE_ZP = 80, SSE_BP = 80;   // pitches: conflict-free MFMA operand reads
+struct SseArgs {
+  const void *X, *Y, *w, *muX, *sdX, *muY, *sdY, *B;
+  const int64_t *idx, *offs;
+  int K, M, A, n_chunks;        // n_chunks: row chunks of the longest fold
+  double *part;                 // [F][n_chunks][A M] partial sums, [F][n_chunks] weight sums behind them
+  double *sse, *wsum;
+  int64_t F;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
+  const int K = a.K, M = a.M, C = a.A * M;
+  const int chunk = blockIdx.x, cb = blockIdx.y, f = blockIdx.z;
+  const int64_t o0 = a.offs[f];
+  const int n = (int)(a.offs[f + 1] - o0);
+  const int r0 = chunk * SSE_ROWS;
+  double *part = a.part + ((size_t)f * a.n_chunks + chunk) * C;
+  double *wpart = a.part + (size_t)a.F * a.n_chunks * C + (size_t)f * a.n_chunks + chunk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lk = lane >> 4, lc = lane & 15;
+  const int c0 = cb * SSE_COLS;
+  if (r0 >= n) {                                              // past this fold's rows: zeros
+    for (int c = tid; c < SSE_COLS; c += 256) if (c0 + c < C) part[c0 + c] = 0.0;
+    if (cb == 0 && tid == 0) *wpart = 0.0;
+    return;
+  }
+  __shared__ T Zs[SSE_KS][SSE_ZP];                            // [k][row]: the A operand's lanes run over rows
+  __shared__ T Bs[SSE_KS][SSE_BP];                            // [k][column]
+  __shared__ int64_t rows[SSE_ROWS];
+  __shared__ double wl[SSE_ROWS];
+  __shared__ double red[4][SSE_COLS];
+  const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
+  const T *muX = a.muX ? (const T *)a.muX + (size_t)f * K : nullptr;
+  const T *sdX = a.sdX ? (const T *)a.sdX + (size_t)f * K : nullptr;
+  const T *Bf = (const T *)a.B + (size_t)f * a.A * K * M;
+  if (tid < SSE_ROWS) {
+    const bool ok = r0 + tid < n;
+    const int64_t r = ok ? a.idx[o0 + r0 + tid] : 0;
+    rows[tid] = r;
+    wl[tid] = ok ? (W ? (double)W[r] : 1.0) : 0.0;
+  }
+  __syncthreads();
+  typedef typename MF<T>::acc_t acc_t;
+  acc_t acc[4];
+#pragma unroll
+  for (int nn = 0; nn < 4; ++nn) acc[nn] = (acc_t){0, 0, 0, 0};
+  // staging maps: Z element (row zr, k zk + 4 j), j < 4; B element (k bk + 4 j, column bc)
+  const int zr = tid & 63, zk = tid >> 6;
+  const int bc = tid & 63, bk = tid >> 6;
+  const int gcol = c0 + bc;
+  const int ba = gcol < C ? gcol / M : 0, bm = gcol < C ? gcol - ba * M : 0;
+  const bool zok = r0 + zr < n;
+  const T *xrow = X + rows[zr] * (int64_t)K;
+  for (int k0 = 0; k0 < K; k0 += SSE_KS) {
+    T zv[4], bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + zk + 4 * j;
+      T z = (T)0;
+      if (zok && k < K) {
+        z = xrow[k];
+        if (muX) z = z - muX[k];
+        if (sdX) z = z / sdX[k];
+      }
+      zv[j] = z;
+      const int kb = k0 + bk + 4 * j;
+      bv[j] = (gcol < C && kb < K) ? Bf[((size_t)ba * K + kb) * M + bm] : (T)0;
+    }
+    __syncthreads();                                          // the previous stage's fragments have been read
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { Zs[zk + 4 * j][zr] = zv[j]; Bs[bk + 4 * j][bc] = bv[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < SSE_KS; ks += 4) {
+      const T af = Zs[ks + lk][16 * wave + lc];
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) acc[nn] = MF<T>::mfma(af, Bs[ks + lk][16 * nn + lc], acc[nn]);
+    }
+  }
+  // squared errors: register r of tile nn is (row 16 wave + drow(lane, r), column 16 nn + lc)
+  const T *muY = a.muY ? (const T *)a.muY + (size_t)f * M : nullptr;
+  const T *sdY = a.sdY ? (const T *)a.sdY + (size_t)f * M : nullptr;
+#pragma unroll
+  for (int nn = 0; nn < 4; ++nn) {
+    const int col = c0 + 16 * nn + lc;
+    const int m = col < C ? col % M : 0;
+    const double sy = sdY ? (double)sdY[m] : 1.0, my = muY ? (double)muY[m] : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * wave + MF<T>::drow(lane, r);
+      if (col < C && r0 + lr < n) {
+        const double e = (double)acc[nn][r] * sy + my - (double)Y[rows[lr] * (int64_t)M + m];
+        s += wl[lr] * (e * e);
+      }
+    }
+    // over the four lane groups of the wave (rows), in order
+    const double s1 = __shfl(s, lc + 16), s2 = __shfl(s, lc + 32), s3 = __shfl(s, lc + 48);
+    const double sw = ((__shfl(s, lc) + s1) + s2) + s3;
+    if (lk == 0) red[wave][16 * nn + lc] = sw;
+  }
+  __syncthreads();
+  if (tid < SSE_COLS && c0 + tid < C) part[c0 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  if (cb == 0 && tid == 0) {
+    double t = 0.0;
+    for (int i = 0; i < SSE_ROWS; ++i) t += wl[i];
+    *wpart = t;
+  }
+}
+
+// sums over a fold's row chunks, in chunk order
+__global__ void pls_sse_reduce_kernel(const SseArgs a) {
+  const int C = a.A * a.M;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < a.F * C) {
+    const int64_t f = e / C;
+    const int c = (int)(e - f * C);
+    const int64_t n = a.offs[f + 1] - a.offs[f];
+    const int used = (int)((n + SSE_ROWS - 1) / SSE_ROWS);
+    double s = 0.0;
+    for (int ch = 0; ch < used; ++ch) s += a.part[((size_t)f * a.n_chunks + ch) * C + c];
+    a.sse[e] = s;
+  }
+  if (e < a.F) {
+    const int64_t n = a.offs[e + 1] - a.offs[e];
+    const int used = (int)((n + SSE_ROWS - 1) / SSE_ROWS);
+    double s = 0.0;
+    for (int ch = 0; ch < used; ++ch) s += a.part[(size_t)a.F * a.n_chunks * C + (size_t)e * a.n_chunks + ch];
+    a.wsum[e] = s;
+  }
+}
+
+size_t pls_sse_workspace_bytes(int64_t F, int64_t max_rows, int M, int A) {
+  const int64_t chunks = (max_rows + SSE_ROWS - 1) / SSE_ROWS;
+  return (size_t)F * (chunks > 0 ? chunks : 1) * ((size_t)A * M + 1) * 8 + 256;
+}
+
+template <typename T>
+int pls_sse_impl(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
+                 int64_t F, int64_t max_rows, int K, int M, int A, const void *muX, const void *sdX, const void *muY,
+                 const void *sdY, const void *B, double *sse, double *wsum, void *ws, size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < pls_sse_workspace_bytes(F, max_rows, M, A)) return fail(CVM_EWORKSPACE, "cvm_pls_validation_sse: workspace too small%s");
+  if (F == 0) return CVM_OK;
+  SseArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = X; a.Y = Y; a.w = w; a.muX = muX; a.sdX = sdX; a.muY = muY; a.sdY = sdY; a.B = B;
+  a.idx = idx; a.offs = offsets; a.K = K; a.M = M; a.A = A; a.F = F;
+  int64_t chunks = (max_rows + SSE_ROWS - 1) / SSE_ROWS;
+  if (chunks < 1) chunks = 1;
+  a.n_chunks = (int)chunks;
+  a.part = reinterpret_cast<double *>(ws);
+  a.sse = sse; a.wsum = wsum;
+  const int C = A * M;
+  if (F > 65535) return fail(CVM_EINVAL, "cvm_pls_validation_sse: at most 65535 folds per call%s");
+  hipLaunchKernelGGL((pls_sse_kernel<T>), dim3((unsigned)chunks, (unsigned)((C + SSE_COLS - 1) / SSE_COLS), (unsigned)F),
+                     dim3(256), 0, st, a);
+  const int64_t ne = F * C > F ? F * C : F;
+  hipLaunchKernelGGL(pls_sse_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a);
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}

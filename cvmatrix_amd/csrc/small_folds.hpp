@@ -144,15 +144,20 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
   // As: w * x, columns of the tile's rows; Bs: x (or y), columns of the tile's columns (SMALL_ROWS
   // rows of SA_PITCH each); Ts: the tile for the finish and the transposed store -- it reuses the
   // As / Bs space.  Elements are T: float32 problems stage and accumulate in float32.
+  // NF folds go through a pass together.  NF = 2 for float32 was measured (the tile kernel is bound by
+  // instructions per byte -- float32 moves half the bytes of float64 for the same instruction count,
+  // 4.5 against 5.8 TB/s with no rows at all -- and a pass pays barriers, loop control and output
+  // offsets once): SLOWER, 16-row folds 0.761 -> 0.831 ms, 32-row folds 0.884 -> 1.065 ms -- three
+  // workgroups per CU instead of five, more registers.  NF stays 1; the code keeps the parameter.
   typedef T TS;
-  constexpr int SM_ELEMS = 2 * SMALL_ROWS * SA_PITCH > ST * (ST + 1) ? 2 * SMALL_ROWS * SA_PITCH : ST * (ST + 1);
-  __shared__ __attribute__((aligned(16))) TS sm[SM_ELEMS];
-  TS *As = sm, *Bs = sm + SMALL_ROWS * SA_PITCH;
-  TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm);
+  constexpr int NF = 1;
+  constexpr int AB_ELEMS = 2 * SMALL_ROWS * SA_PITCH, TS_ELEMS = ST * (ST + 1);
+  constexpr int SLOT = AB_ELEMS > TS_ELEMS ? AB_ELEMS : TS_ELEMS;
+  __shared__ __attribute__((aligned(16))) TS sm[NF * SLOT];
   __shared__ int64_t rows_all[SA_FPB][SMALL_ROWS];
   __shared__ T wl_all[SA_FPB][SMALL_ROWS];
   __shared__ int n_all[SA_FPB];
-  __shared__ double st_lds[2][4 * ST];           // the folds' means / stds of the tile's rows and columns
+  __shared__ double st_lds[2][NF][4 * ST];       // the folds' means / stds of the tile's rows and columns
   const bool xtx_part = x < a.nT64;
   if (xtx_part ? !a.out_XTX : (!a.out_XTY || M == 0)) return;
   int ti = 0, tj = 0;
@@ -185,30 +190,37 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
     constexpr int NQG = ST * (ST / VWG) / 256;
     T gpre[NQG][VWG];
     finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, (const T *)a.out_XTX, tid, 256);
-    // staging element j of this thread: row sr[j] = (tid + 256 j) / 64 of the fold, column sc of the
-    // tile; up to SMALL_ROWS * 64 / 256 = 8 elements, each an A-side and a B-side value
+    // staging element j of this thread: row sr0 + 4 j of the fold, column sc of the tile; up to
+    // SMALL_ROWS * 64 / 256 = 8 elements, each an A-side and a B-side value
     constexpr int NE = SMALL_ROWS * ST / 256;
-    const int sc = tid & (ST - 1), sr0 = tid >> 6;           // element j: row sr0 + 4 j
+    const int sc = tid & (ST - 1), sr0 = tid >> 6;
     const bool ca_ok = a0 + sc < K, cb_ok = b0 + sc < K;
-    T pa[NE], pb[NE];
-    double pst = 0;
-    auto request = [&](int ff) {                 // rows and statistics of fold ff -> registers
-      const int n = n_all[ff];
-      const int n4 = (n + 3) & ~3;
+    T pa[NF][NE], pb[NF][NE];
+    double pst[NF], pswt[NF];
+    auto request = [&](int ff0) {                // rows and statistics of folds ff0 .. ff0 + NF - 1 -> registers
 #pragma unroll
-      for (int j = 0; j < NE; ++j) {
-        const int r = sr0 + 4 * j;
-        pa[j] = (T)0; pb[j] = (T)0;
-        if (r < n4 && r < n) {
-          const int64_t row = rows_all[ff][r];
-          if (ca_ok) pa[j] = X[row * (int64_t)K + a0 + sc];
-          if (cb_ok) pb[j] = X[row * (int64_t)K + b0 + sc];
+      for (int g = 0; g < NF; ++g) {
+        const int ff = ff0 + g;
+        const int n = ff < nf ? n_all[ff] : 0;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int r = sr0 + 4 * j;
+          pa[g][j] = (T)0; pb[g][j] = (T)0;
+          if (r < n) {
+            const int64_t row = rows_all[ff][r];
+            if (ca_ok) pa[g][j] = X[row * (int64_t)K + a0 + sc];
+            if (cb_ok) pb[g][j] = X[row * (int64_t)K + b0 + sc];
+          }
+        }
+        pst[g] = 0.0; pswt[g] = 0.0;
+        if (ff < nf) {
+          const double *fs = a.fstats + (size_t)(f_first + ff) * fstat_len(K, M);
+          pswt[g] = fs[2 * K + 2 * M];
+          const int part = tid / ST, l = tid - part * ST;      // stage_tile_stats, one value per thread
+          const int col = ((part < 2) ? a0 : b0) + l;
+          pst[g] = (col < K) ? fs[((part & 1) ? K : 0) + col] : ((part & 1) ? 1.0 : 0.0);
         }
       }
-      const double *fs = a.fstats + (size_t)(f_first + ff) * fstat_len(K, M);
-      const int part = tid / ST, l = tid - part * ST;        // stage_tile_stats, one value per thread
-      const int col = ((part < 2) ? a0 : b0) + l;
-      pst = (col < K) ? fs[((part & 1) ? K : 0) + col] : ((part & 1) ? 1.0 : 0.0);
     };
     request(0);
     const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
@@ -225,84 +237,113 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
     const size_t off_step = (size_t)FSTEP * K;
     typedef T vst_t __attribute__((ext_vector_type(VWG)));
     typedef typename MF<T>::acc_t acc_t;
-    for (int ff = 0; ff < nf; ++ff) {
-      const int f = f_first + ff;
-      const int n = n_all[ff], n4 = (n + 3) & ~3;
-      const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-      const double swt = fs[2 * K + 2 * M];
-      const size_t fo = (size_t)(a.seg0 + f);
-      // the fold's rows (A side weighted, zero rows up to a multiple of 4) and statistics -> LDS
+    int pass = 0;
+    for (int ff0 = 0; ff0 < nf; ff0 += NF, ++pass) {
+      const int ng = nf - ff0 < NF ? nf - ff0 : NF;            // folds of this pass
+      double swt[NF];
+      int n4[NF];
+      // the folds' rows (A side weighted, zero rows up to a multiple of 4) and statistics -> LDS
 #pragma unroll
-      for (int j = 0; j < NE; ++j) {
-        const int r = sr0 + 4 * j;
-        if (r < n4) {
-          As[r * SA_PITCH + sc] = WEIGHTED ? (T)(wl_all[ff][r] * pa[j]) : pa[j];
-          Bs[r * SA_PITCH + sc] = pb[j];
+      for (int g = 0; g < NF; ++g) {
+        const int ff = ff0 + g;
+        n4[g] = g < ng ? (n_all[ff] + 3) & ~3 : 0;
+        swt[g] = pswt[g];
+        TS *As = sm + g * SLOT, *Bs = As + SMALL_ROWS * SA_PITCH;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int r = sr0 + 4 * j;
+          if (r < n4[g]) {
+            As[r * SA_PITCH + sc] = WEIGHTED ? (T)(wl_all[ff][r] * pa[g][j]) : pa[g][j];
+            Bs[r * SA_PITCH + sc] = pb[g][j];
+          }
+        }
+        st_lds[pass & 1][g][tid] = pst[g];
+      }
+      lds_barrier();
+      if (ff0 + NF < nf) request(ff0 + NF);      // in flight during the arithmetic and the stores below
+      // rank-n updates of the 64 x 64 tile on the matrix cores: wave w -> row tile w, 4 column tiles
+      acc_t acc[NF][4];
+#pragma unroll
+      for (int g = 0; g < NF; ++g) {
+        const TS *As = sm + g * SLOT, *Bs = As + SMALL_ROWS * SA_PITCH;
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) acc[g][nn] = (acc_t){0, 0, 0, 0};
+        for (int k0 = 0; k0 < n4[g]; k0 += 4) {
+          const T af = As[(k0 + lk) * SA_PITCH + 16 * wave + lc];
+          T bf[4];
+#pragma unroll
+          for (int nn = 0; nn < 4; ++nn) bf[nn] = Bs[(k0 + lk) * SA_PITCH + 16 * nn + lc];
+#pragma unroll
+          for (int nn = 0; nn < 4; ++nn) acc[g][nn] = MF<T>::mfma(af, bf[nn], acc[g][nn]);
         }
       }
-      st_lds[ff & 1][tid] = pst;
-      lds_barrier();
-      if (ff + 1 < nf) request(ff + 1);          // in flight during the arithmetic and the stores below
-      // rank-n update of the 64 x 64 tile on the matrix cores: wave w -> row tile w, 4 column tiles
-      acc_t acc[4];
+      lds_barrier();     // every wave is done with As/Bs: Ts may overwrite them
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) acc[nn] = (acc_t){0, 0, 0, 0};
-      for (int k0 = 0; k0 < n4; k0 += 4) {
-        const T af = As[(k0 + lk) * SA_PITCH + 16 * wave + lc];
-        T bf[4];
+      for (int g = 0; g < NF; ++g) {
+        TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) bf[nn] = Bs[(k0 + lk) * SA_PITCH + 16 * nn + lc];
+        for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) acc[nn] = MF<T>::mfma(af, bf[nn], acc[nn]);
+          for (int r = 0; r < 4; ++r) Ts[16 * wave + MF<T>::drow(lane, r)][16 * nn + lc] = acc[g][nn][r];
       }
-      lds_barrier();   // every wave is done with As/Bs: Ts may overwrite them
-#pragma unroll
-      for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ts[16 * wave + MF<T>::drow(lane, r)][16 * nn + lc] = acc[nn][r];
       lds_barrier();
-      T *out = (T *)a.out_XTX + fo * (size_t)K * K;
       if (fast) {
-        const double *st = st_lds[ff & 1];
-        double muc[VWG], sdc[VWG];
 #pragma unroll
-        for (int e = 0; e < VWG; ++e) { muc[e] = st[2 * ST + fc + e]; sdc[e] = st[3 * ST + fc + e]; }
-        T *od = out + off_d0;
+        for (int g = 0; g < NF; ++g) {
+          if (g >= ng) break;
+          TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
+          const double *st = st_lds[pass & 1][g];
+          double muc[VWG], sdc[VWG];
 #pragma unroll
-        for (int j = 0; j < NQG; ++j) {
-          const int lr = fr0 + FSTEP * j;
-          const double mur = st[lr], sdr = st[ST + lr];
-          vst_t vv;
+          for (int e = 0; e < VWG; ++e) { muc[e] = st[2 * ST + fc + e]; sdc[e] = st[3 * ST + fc + e]; }
+          T *od = (T *)a.out_XTX + (size_t)(a.seg0 + f_first + ff0 + g) * (size_t)K * K + off_d0;
 #pragma unroll
-          for (int e = 0; e < VWG; ++e) {
-            double v = (double)gpre[j][e] - (double)Ts[lr][fc + e];
-            if (cX) v -= swt * (mur * muc[e]);
-            if (sX) v = v * (sdr * sdc[e]);
-            vv[e] = (T)v;
+          for (int j = 0; j < NQG; ++j) {
+            const int lr = fr0 + FSTEP * j;
+            const double mur = st[lr], sdr = st[ST + lr];
+            vst_t vv;
+#pragma unroll
+            for (int e = 0; e < VWG; ++e) {
+              double v = (double)gpre[j][e] - (double)Ts[lr][fc + e];
+              if (cX) v -= swt[g] * (mur * muc[e]);
+              if (sX) v = v * (sdr * sdc[e]);
+              vv[e] = (T)v;
+            }
+            out_store(reinterpret_cast<vst_t *>(od), vv);
+            od += off_step;
+#pragma unroll
+            for (int e = 0; e < VWG; ++e) Ts[lr][fc + e] = vv[e];       // parked for the mirrored pass
           }
-          out_store(reinterpret_cast<vst_t *>(od), vv);
-          od += off_step;
-#pragma unroll
-          for (int e = 0; e < VWG; ++e) Ts[lr][fc + e] = vv[e];       // parked for the mirrored pass
         }
         lds_barrier();
-        T *om = out + off_m0;
 #pragma unroll
-        for (int j = 0; j < NQG; ++j) {
-          const int lr = fr0 + FSTEP * j;
-          vst_t vv;
+        for (int g = 0; g < NF; ++g) {
+          if (g >= ng) break;
+          TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
+          T *om = (T *)a.out_XTX + (size_t)(a.seg0 + f_first + ff0 + g) * (size_t)K * K + off_m0;
 #pragma unroll
-          for (int e = 0; e < VWG; ++e) vv[e] = Ts[fc + e][lr];          // finished, transposed
-          out_store(reinterpret_cast<vst_t *>(om), vv);
-          om += off_step;
+          for (int j = 0; j < NQG; ++j) {
+            const int lr = fr0 + FSTEP * j;
+            vst_t vv;
+#pragma unroll
+            for (int e = 0; e < VWG; ++e) vv[e] = Ts[fc + e][lr];          // finished, transposed
+            out_store(reinterpret_cast<vst_t *>(om), vv);
+            om += off_step;
+          }
         }
         lds_barrier();
       } else {
-        finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, st_lds[ff & 1], swt, cX, sX, tid, 256, gpre);
+        for (int g = 0; g < ng; ++g) {
+          TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
+          T *out = (T *)a.out_XTX + (size_t)(a.seg0 + f_first + ff0 + g) * (size_t)K * K;
+          finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, st_lds[pass & 1][g], swt[g], cX, sX,
+                                         tid, 256, gpre);
+        }
       }
-      // (both ways end with a barrier: As / Bs are free for the next fold)
+      // (both ways end with a barrier: As / Bs are free for the next pass)
     }
   } else {
+    TS *As = sm, *Bs = sm + SMALL_ROWS * SA_PITCH;
     for (int ff = 0; ff < nf; ++ff) {
       const int f = f_first + ff;
       const int n = n_all[ff];

@@ -921,8 +921,9 @@ class CVMatrix:
         return (csum[batch.offsets[1:]] - csum[batch.offsets[:-1]]).cpu().numpy()
 
     def prepare_folds_from_labels(self, labels, n_labels: Optional[int] = None) -> FoldBatch:
-        """Device-side ``Partitioner``: one integer fold label per row (NumPy array or tensor,
-        values in ``[0, n_labels)``) -> a ``FoldBatch`` built by ``cvm_partition_labels`` without
+        """Device-side ``Partitioner``: one fold label per row -- integers in ``[0, n_labels)`` (NumPy
+        array or tensor), or labels of any hashable kind (strings, floats, objects: factorised on the
+        host in first-seen order, one vectorised pass) -> a ``FoldBatch`` built by ``cvm_partition_labels`` without
         the host ever grouping the rows (any number of labels: up to 4096 one stable counting
         sort, more -- leave-one-out has one per row -- the same sort over 12-bit digits; labels
         that are ``arange(N) % P``, the reference benchmark's folds, or ``arange(N)`` are laid out
@@ -933,6 +934,28 @@ class CVMatrix:
             raise RuntimeError("call fit() first")
         lib = _lib.load()
         dev = self.device
+        keys = None
+        if not isinstance(labels, torch.Tensor):
+            try:
+                arr = np.asarray(labels).reshape(-1)
+            except ValueError:                         # (ragged objects, e.g. tuples next to strings)
+                labels = list(labels)
+                arr = np.fromiter(labels, dtype=object, count=len(labels))
+            if arr.dtype.kind not in "iub":
+                # labels of any hashable kind (strings, floats, mixed objects: partitioner.py:101-107
+                # takes them all): one vectorised host pass turns them into integer codes numbered by
+                # first appearance -- the reference's dict order -- and the grouping itself runs on the
+                # device like for integer labels; ``batch.labels`` lists the original labels
+                if arr.dtype.kind == "O":
+                    seen: dict = {}                    # (objects: the reference's own loop, partitioner.py:101-107)
+                    codes = np.fromiter((seen.setdefault(v, len(seen)) for v in labels), dtype=np.int64, count=arr.size)
+                    keys = list(seen)
+                else:
+                    import pandas as pd
+
+                    codes, uniq = pd.factorize(arr, sort=False, use_na_sentinel=False)
+                    keys = list(uniq)
+                labels, n_labels = np.asarray(codes, dtype=np.int64), len(keys)
         with torch.cuda.device(dev):
             if isinstance(labels, torch.Tensor):
                 lab = labels.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
@@ -967,7 +990,8 @@ class CVMatrix:
                         nz_val = (csum[d_off[1:]] - csum[d_off[:-1]]).cpu().numpy()
                     else:
                         nz_val = sizes.astype(np.int64)
-                    return FoldBatch(d_idx, d_off, host_offsets, nz_val, list(range(L)), None, self.N,
+                    return FoldBatch(d_idx, d_off, host_offsets, nz_val,
+                                     list(range(L)) if keys is None else [keys[i] for i in range(L)], None, self.N,
                                      w_gen=self._w_gen)
             idx = torch.empty(self.N, dtype=torch.int64, device=dev)
             offs = torch.empty(L + 1, dtype=torch.int64, device=dev)
@@ -1004,7 +1028,8 @@ class CVMatrix:
                 nz_val = (csum[d_off[1:]] - csum[d_off[:-1]]).cpu().numpy()
             else:
                 nz_val = sizes.copy()
-        return FoldBatch(d_idx, d_off, host_offsets, nz_val, [int(v) for v in order], None, self.N,
+        return FoldBatch(d_idx, d_off, host_offsets, nz_val,
+                         [int(v) for v in order] if keys is None else [keys[int(v)] for v in order], None, self.N,
                          w_gen=self._w_gen)
 
     def _staging(self, n: int) -> torch.Tensor:

@@ -95,3 +95,47 @@ def pls_fit_batched(XTX: torch.Tensor, XTY: torch.Tensor, A: int, *, return_fact
         if check and int(status.item()) != 0:
             raise RuntimeError("cvm_pls_fit: workgroups of a fold were not co-resident (barrier timed out).")
     return PLSFit(B, W, P, Q, R, n_fit)
+
+
+def pls_validation_sse(cvm, folds, stats, B: torch.Tensor):
+    """Weighted squared prediction errors of every fold's PLS models on the fold's own validation rows,
+    on the device (``cvm_pls_validation_sse``): ``cvm`` a fitted ``CVMatrix`` with Y, ``folds`` what
+    ``training_XTX_XTY_batched`` was given (a ``Partitioner``, index arrays or a ``FoldBatch``), ``stats``
+    the statistics tuple that call returned, ``B`` (F,A,K,M) from ``pls_fit_batched``.  Returns
+    ``(sse, wsum)``: float64 tensors (F,A,M) and (F,) -- the cross-validated RMSE with ``a + 1``
+    components is ``sqrt(sse.sum(0)[a] / wsum.sum())`` (``cv_rmse``)."""
+    if cvm.X is None or cvm.Y is None:
+        raise ValueError("pls_validation_sse needs a CVMatrix fitted with Y.")
+    batch = cvm.prepare_folds(folds)
+    muX, sdX, muY, sdY = stats
+    F, A, K, M = B.shape
+    if (K, M) != (cvm.K, cvm.M) or F != batch.n_folds:
+        raise ValueError("B does not belong to these folds / this model.")
+    if cvm._Kd != cvm._Ku or (cvm._Md or 0) != (cvm._Mu or 0) or cvm.output != "torch" or cvm._out_cast:
+        raise ValueError("pls_validation_sse takes device results of an unpadded float32 / float64 model "
+                         "(K even, float64: M even, or copy=False).")
+    lib = _lib.load()
+    dev = B.device
+    B = B.contiguous()
+    code = _lib.CVM_F64 if B.dtype == torch.float64 else _lib.CVM_F32
+    max_rows = int(batch.sizes.max()) if batch.n_folds else 0
+    with torch.cuda.device(dev):
+        nbytes = lib.cvm_pls_sse_workspace_bytes(F, max_rows, M, A)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        sse = torch.empty((F, A, M), dtype=torch.float64, device=dev)
+        wsum = torch.empty((F,), dtype=torch.float64, device=dev)
+        c = lambda t: None if t is None else t.contiguous()          # noqa: E731
+        muX, sdX, muY, sdY = c(muX), c(sdX), c(muY), c(sdY)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.cvm_pls_validation_sse(
+            _lib.ptr(cvm.X), _lib.ptr(cvm.Y), _lib.ptr(cvm.weights), _lib.ptr(batch.idx), _lib.ptr(batch.offsets), F,
+            max_rows, K, M, A, code, _lib.ptr(muX), _lib.ptr(sdX), _lib.ptr(muY), _lib.ptr(sdY), _lib.ptr(B),
+            _lib.ptr(sse), _lib.ptr(wsum), _lib.ptr(ws), nbytes, stream)
+        _lib.check(rc, "cvm_pls_validation_sse")
+        ws.record_stream(torch.cuda.current_stream(dev))
+    return sse, wsum
+
+
+def cv_rmse(sse: torch.Tensor, wsum: torch.Tensor) -> torch.Tensor:
+    """(A, M) cross-validated RMSE per number of components and response from ``pls_validation_sse``."""
+    return torch.sqrt(sse.sum(dim=0) / wsum.sum())

@@ -6,8 +6,9 @@ combined with Improved Kernel PLS", the out-of-tree `ikpls` package).
 
 1. CVMatrix.fit + training_XTX_XTY_batched   training-set XtX, XtY, means, stds of every fold   (HIP)
 2. pls_fit_batched                           A-component PLS coefficients of every fold          (HIP)
-3. predictions on each fold's validation rows and the RMSE per number of components -- a plain
-   batched GEMM, left to torch.matmul here (rocBLAS): it is not part of the library.
+3. pls_validation_sse                        squared validation errors of every fold's models        (HIP)
+   -> RMSE per number of components.  (Shapes whose device copies are padded -- odd K, float64 with
+   odd M -- take the same formula in plain torch operations.)
 """
 import os
 import sys
@@ -17,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cvmatrix_amd import CVMatrix, Partitioner  # noqa: E402
-from cvmatrix_amd.pls import pls_fit_batched  # noqa: E402
+from cvmatrix_amd.pls import cv_rmse, pls_fit_batched, pls_validation_sse  # noqa: E402
 
 
 def fast_cv_rmse(X, Y, labels, A, weights=None):
@@ -29,6 +30,9 @@ def fast_cv_rmse(X, Y, labels, A, weights=None):
     batch = cvm.prepare_folds(p)
     (XTX, XTY), (muX, sdX, muY, sdY) = cvm.training_XTX_XTY_batched(batch)
     B = pls_fit_batched(XTX, XTY, A).B                                   # (F, A, K, M)
+    if cvm._Kd == cvm._Ku and (cvm._Md or 0) == (cvm._Mu or 0):
+        sse_f, wsum_f = pls_validation_sse(cvm, batch, (muX, sdX, muY, sdY), B)
+        return cv_rmse(sse_f, wsum_f).cpu().numpy()
     sse = torch.zeros((A, Y.shape[1]), dtype=torch.float64, device=B.device)
     wsum = 0.0
     for f, key in enumerate(p.folds_dict):

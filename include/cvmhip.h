@@ -196,6 +196,21 @@ size_t cvm_pls_workspace_bytes(int64_t n_folds, int K, int M, int A, int dtype);
 int cvm_pls_fit(const void *XTX, const void *XTY, int64_t n_folds, int K, int M, int A, int dtype,
                 void *B, void *W, void *P, void *Q, void *R, int32_t *n_fit, int32_t *status,
                 void *ws, size_t ws_bytes, void *stream);
+/* Validation errors of the folds' PLS models -- the last step of the cross-validation the reference's
+ * README describes (README.md:23), which its consumer ikpls leaves to the caller: for fold f, the model
+ * with a+1 components and response m
+ *   sse[f][a][m] = sum over the fold's validation rows i (idx / offsets as in cvm_fold_update) of
+ *                  w_i * ( ((x_i - muX[f]) / sdX[f]) . B[f][a][:, m] * sdY[f][m] + muY[f][m] - y_im )^2
+ *   wsum[f]      = sum w_i    (w NULL: the row count)
+ * muX, sdX [n_folds][K], muY, sdY [n_folds][M] in `dtype`: the statistics outputs of cvm_fold_update
+ * (NULL: no centring / no scaling).  B as cvm_pls_fit wrote it.  sse float64[n_folds][A][M], wsum
+ * float64[n_folds].  MFMA in `dtype`, errors accumulated in float64 in a fixed order (no atomics).
+ * RMSE of the cross-validation with a+1 components: sqrt(sum_f sse[f][a][m] / sum_f wsum[f]). */
+size_t cvm_pls_sse_workspace_bytes(int64_t n_folds, int64_t max_fold_rows, int M, int A);
+int cvm_pls_validation_sse(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
+                           int64_t n_folds, int64_t max_fold_rows, int K, int M, int A, int dtype, const void *muX,
+                           const void *sdX, const void *muY, const void *sdY, const void *B, double *sse,
+                           double *wsum, void *ws, size_t ws_bytes, void *stream);
 /* info[0]=row slices per fold, [1]=rows per slice, [2]=folds per launch, [3]=1 if the slice of XTX
  * stays in LDS, 0 if it is streamed, 2: few folds -- the kernel that keeps the small state of a fold
  * (deflated XTY, P, R) whole in every slice and passes ONE per-fold barrier per component, XTX

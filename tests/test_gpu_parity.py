@@ -1079,6 +1079,34 @@ def test_device_partitioner_matches_host_partitioner(amd, N, L):
         m.prepare_folds_from_labels(bad, n_labels=L)
 
 
+@pytest.mark.parametrize("kind", ["str", "float", "object"])
+def test_device_partitioner_takes_any_hashable_label(amd, kind):
+    """partitioner.py:101-107 groups labels of any hashable kind: strings, floats and mixed objects go
+    through ``prepare_folds_from_labels`` too (factorised on the host in first-seen order, grouped on
+    the device) and give the host Partitioner's folds, labels and order."""
+    rng = np.random.default_rng(17)
+    N, K = 5000, 12
+    codes = rng.integers(0, 23, size=N)
+    if kind == "str":
+        labels = np.array([f"site-{c:02d}" for c in codes])
+    elif kind == "float":
+        labels = codes.astype(np.float64) * 0.5 - 3.25
+    else:
+        pool = [("a", 1), "b", 2.5, 7, None, frozenset({3})] + [f"k{i}" for i in range(17)]
+        labels = [pool[c] for c in codes]
+    m = amd.CVMatrix()
+    m.fit(rng.random((N, K)), None, rng.random(N) + 0.1)
+    part = amd.Partitioner(labels)
+    hb = m.prepare_folds(part)
+    db = m.prepare_folds_from_labels(labels)
+    assert db.labels == list(part.folds_dict)
+    assert np.array_equal(db.host_offsets, hb.host_offsets)
+    assert bool((db.idx == hb.idx).all()) and np.array_equal(db.nz_val, hb.nz_val)
+    a, _ = m.training_XTX_batched(hb)
+    b, _ = m.training_XTX_batched(db)
+    assert bool((a == b).all())
+
+
 @pytest.mark.parametrize("N,L,bad", [(6000, 5000, -5), (6000, 5000, -(2 ** 62)), (3000, 40, -1), (6000, 5000, 5000)])
 def test_device_partitioner_refuses_out_of_range_labels(amd, N, L, bad):
     """A label outside [0, n_labels) -- negative ones included, on the many-label radix route too --

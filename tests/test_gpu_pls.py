@@ -252,3 +252,49 @@ def test_four_barrier_kernel_still_agrees(pls):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x",
                         "-k", "not four_barrier and not example"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype,N,K,M,P,A,weighted,flags", [
+    (np.float64, 3000, 64, 4, 6, 7, True, (True, True, True, True)),
+    (np.float64, 2111, 130, 2, 5, 5, False, (True, True, False, False)),
+    (np.float64, 1500, 36, 16, 3, 20, True, (False, False, False, False)),
+    (np.float32, 4000, 128, 3, 8, 6, True, (True, True, True, True)),
+])
+def test_validation_sse_on_the_device(pls, dtype, N, K, M, P, A, weighted, flags):
+    """cvm_pls_validation_sse: the squared validation errors of every fold's models (every number of
+    components) against the same quantity computed with plain torch operations from the same
+    coefficients -- ragged folds, with and without weights / centring / scaling."""
+    import cvmatrix_amd as amd
+    from cvmatrix_amd.pls import cv_rmse, pls_fit_batched, pls_validation_sse
+
+    rng = np.random.default_rng(N + K)
+    L = rng.standard_normal((N, 5))
+    X = (L @ rng.standard_normal((5, K)) + 0.3 * rng.standard_normal((N, K))).astype(dtype)
+    Y = (L[:, :3] @ rng.standard_normal((3, M)) + 0.1 * rng.standard_normal((N, M))).astype(dtype)
+    w = (rng.random(N) + 0.1).astype(dtype) if weighted else None
+    labels = rng.integers(0, P, N)
+    p = amd.Partitioner(labels)
+    cvm = amd.CVMatrix(*flags, dtype=dtype)
+    cvm.fit(X, Y, w)
+    batch = cvm.prepare_folds(p)
+    (XTX, XTY), stats = cvm.training_XTX_XTY_batched(batch)
+    B = pls_fit_batched(XTX, XTY, A).B
+    sse, wsum = pls_validation_sse(cvm, batch, stats, B)
+    muX, sdX, muY, sdY = stats
+    f64 = torch.float64
+    for f, key in enumerate(p.folds_dict):
+        val = torch.from_numpy(p.get_validation_indices(key)).to(B.device)
+        Xs = cvm.X[val].to(f64)
+        if muX is not None: Xs = Xs - muX[f].to(f64)
+        if sdX is not None: Xs = Xs / sdX[f].to(f64)
+        pred = torch.matmul(Xs, B[f].to(f64))
+        if sdY is not None: pred = pred * sdY[f].to(f64)
+        if muY is not None: pred = pred + muY[f].to(f64)
+        e2 = (pred - cvm.Y[val].to(f64)) ** 2
+        wv = cvm.weights[val].to(f64) if weighted else torch.ones((val.numel(), 1), dtype=f64, device=B.device)
+        ref = (e2 * wv).sum(dim=1)
+        tol = 1e-10 if dtype is np.float64 else 2e-4
+        assert float((sse[f] - ref).abs().max()) <= tol * float(ref.abs().max()), (f, float((sse[f] - ref).abs().max()))
+        assert abs(float(wsum[f]) - float(wv.sum())) <= 1e-12 * float(wv.sum())
+    r = cv_rmse(sse, wsum)
+    assert r.shape == (A, M) and bool(torch.isfinite(r).all())

@@ -19,7 +19,8 @@ def run(name, N, K, M, P, A, dtype=np.float64, cpu=True, reps=7):
     m.fit(X, Y, w)
     nv = N // P
     folds = [np.arange(i * nv, (i + 1) * nv) for i in range(P)]
-    (XTX, XTY), _ = m.training_XTX_XTY_batched(m.prepare_folds(folds))
+    batch = m.prepare_folds(folds)
+    (XTX, XTY), stats = m.training_XTX_XTY_batched(batch)
     fit = pls_fit_batched(XTX, XTY, A)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,6 +35,15 @@ def run(name, N, K, M, P, A, dtype=np.float64, cpu=True, reps=7):
     gb = P * (passes * K * K * s + A * K * M * s) / 1e9
     line = (f"{name:30s} F={P:6d} K={K:5d} M={M:3d} A={A:3d}: {ms:8.3f} ms  {P/ms*1e3:10.0f} folds/s  "
             f"{ms/A*1e3:7.1f} us/component  slices={plan['slices']:3d} lds_xtx={int(plan['xtx_in_lds'])}  {gb/ms*1e3:7.0f} GB/s")
+    # the validation errors of all those models (cvm_pls_validation_sse): 2 n K A M flops per fold
+    from cvmatrix_amd.pls import pls_validation_sse
+    pls_validation_sse(m, batch, stats, fit.B); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0.record(); pls_validation_sse(m, batch, stats, fit.B); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms2 = float(np.median(ts))
+    line += f"   validation sse {ms2:7.3f} ms ({2.0 * P * nv * K * A * M / ms2 / 1e9:5.1f} TFLOP/s)"
     if cpu:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from oracle.ikpls_oracle import ikpls_fit
