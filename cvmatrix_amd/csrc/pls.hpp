@@ -1124,9 +1124,10 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
   const bool zok = r0 + zr < n;
   const T *xrow = X + rows[zr] * (int64_t)K;
   for (int k0 = 0; k0 < K; k0 += SSE_KS) {
-    T zv[4], bv[4];
+    constexpr int NEL = SSE_KS / 4;
+    T zv[NEL], bv[NEL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NEL; ++j) {
       const int k = k0 + zk + 4 * j;
       T z = (T)0;
       if (zok && k < K) {
@@ -1140,7 +1141,7 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
     }
     __syncthreads();                                          // the previous stage's fragments have been read
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { Zs[zk + 4 * j][zr] = zv[j]; Bs[bk + 4 * j][bc] = bv[j]; }
+    for (int j = 0; j < NEL; ++j) { Zs[zk + 4 * j][zr] = zv[j]; Bs[bk + 4 * j][bc] = bv[j]; }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < SSE_KS; ks += 4) {
