@@ -37,6 +37,12 @@ int main() {
   }
   run<64, 64>("64 x 64 (512 B rows)", buf, 4096, 30);
   run<8, 512>("8 x 512 (4 KB rows)", buf, 4096, 30);
+  // round 3: the float32 K = 4096 tile kernel writes 64 rows x 256 B, 16 KB apart (= 2048 doubles per row)
+  run<64, 32>("64 x 256 B, rows 16 KB apart", buf, 2048, 120);
+  run<64, 64>("64 x 512 B, rows 16 KB apart", buf, 2048, 120);
+  run<32, 128>("32 x 1 KB, rows 16 KB apart", buf, 2048, 120);
+  run<128, 32>("128 x 256 B, rows 16 KB apart", buf, 2048, 120);
+  run<128, 64>("128 x 512 B, rows 16 KB apart", buf, 2048, 120);
   hipFree(buf);
   return 0;
 }
