@@ -469,9 +469,25 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   if (y_mine) y_h = ((const T *)a.H)[(size_t)(a0 + yi) * M + ym];
   const int f_lo = by * a.fpb;
   const int f_hi = (f_lo + a.fpb < a.nb) ? f_lo + a.fpb : a.nb;
+  // the row numbers and row counts of ALL folds of this workgroup's group, once (round 3): inside the
+  // per-fold prefetch a global load that depends on another global load (offsets -> indices -> x)
+  // makes the wave wait for everything older in the in-order memory counter, the previous fold's
+  // stores included, three times per fold
+  __shared__ int64_t ridx_all[SA_FPB][NV];
+  __shared__ int n_grp[SA_FPB];
+  if (tid < SA_FPB * NV) {
+    const int ff = tid / NV, u = tid - ff * NV;
+    if (f_lo + ff < f_hi) {
+      const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f_lo + ff];
+      const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f_lo + ff + 1] - o0);
+      ridx_all[ff][u] = u < n ? (inl ? a.inl[u] : a.idx[o0 + u]) : 0;
+      if (u == 0) n_grp[ff] = n;
+    }
+  }
+  lds_barrier();
   auto fetch = [&](int f, Pre &p) {
-    const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
-    p.n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
+    const int64_t *ridx_f = ridx_all[f - f_lo];
+    p.n = __builtin_amdgcn_readfirstlane(n_grp[f - f_lo]);
     const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
 #pragma unroll
     for (int e = 0; e < VW; ++e) { p.muc[e] = 0.0; p.sdc[e] = 1.0; }
@@ -479,7 +495,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
 #pragma unroll
       for (int u = 0; u < NV; ++u)
         if (u < p.n) {
-          const int64_t ridx = inl ? a.inl[u] : a.idx[o0 + u];
+          const int64_t ridx = ridx_f[u];
           p.xc[u] = *reinterpret_cast<const vec_t *>(X + ridx * (int64_t)K + gc);
         }
       if (cX) p.muc = *reinterpret_cast<const dvec_t *>(fs + gc);
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
     p.sx = (T)0; p.sw = (T)1; p.sst = 0.0;
     if (tid < p.n * SR_ROWS) {
       const int r = tid / SR_ROWS, i = tid - r * SR_ROWS;
-      const int64_t ridx = inl ? a.inl[r] : a.idx[o0 + r];
+      const int64_t ridx = ridx_f[r];
       p.sw = WEIGHTED ? W[ridx] : (T)1;
       p.sx = (a0 + i < K) ? X[ridx * (int64_t)K + a0 + i] : (T)0;
     }
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
 #pragma unroll
       for (int u = 0; u < NV; ++u)
         if (u < p.n) {
-          const int64_t ridx = inl ? a.inl[u] : a.idx[o0 + u];
+          const int64_t ridx = ridx_f[u];
           p.yv[u] = Y[ridx * (int64_t)M + ym];
         }
       if (cX || cY) { p.ya = fs[a0 + yi]; p.yb = fs[2 * K + ym]; }
