@@ -213,7 +213,7 @@ __device__ __forceinline__ void inline_column_stat(const FinArgs &a, int f, bool
 
 // fold: training-set mean / std of every column; reference operation order
 // (cvmatrix.py:612-620, 709-745, 1043, 1079, 1119-1128)
-template <typename T> __global__ void fold_stats_kernel(const FinArgs a) {
+template <typename T> __global__ __launch_bounds__(256) void fold_stats_kernel(const FinArgs a) {
   const Geom &g = a.g;
   const int f = blockIdx.x;
   const int K = g.K, M = g.M;
@@ -457,6 +457,63 @@ __device__ __forceinline__ void fused_finish_direct(T (*Ts)[TP], const double *r
       }
     }
   }
+}
+// The same direct half for 32 rows of an OFF-DIAGONAL block with the G pieces already in registers:
+// the loads are issued by fused_g_preload32 before the accumulators are dumped to LDS and before the
+// workgroup barrier that follows (round 3: the two dependent rounds of G loads were 7.9 k cycles of
+// an off-diagonal item's epilogue, profiles/r3/fused_epilogue_stamps.txt)
+template <typename T> struct FusedPre {
+  static constexpr int VW = 16 / (int)sizeof(T);
+  static constexpr int JB = 16 / VW;
+  typedef T vt __attribute__((ext_vector_type(VW)));
+  vt gv[2][JB];
+};
+template <typename T>
+__device__ __forceinline__ void fused_g_preload32(FusedPre<T> &p, int a0, int b0, int K, const T *Gt, int lane, int row_lo) {
+  constexpr int VW = FusedPre<T>::VW, LPR = 64 / VW, JB = FusedPre<T>::JB;
+  typedef typename FusedPre<T>::vt vt;
+  const int sub = lane / LPR, lc = VW * (lane - sub * LPR);
+  const int gc = b0 + lc;
+  const int gcc = gc < K ? gc : 0;                 // (branch-free loads; pieces outside the matrix are never stored)
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int gr = a0 + row_lo + 16 * b + VW * j + sub;
+      p.gv[b][j] = *reinterpret_cast<const vt *>(Gt + (size_t)(gr < K ? gr : 0) * K + gcc);
+    }
+}
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_direct32(T (*Ts)[TP], const double *rs, int a0, int b0, int K, T *out,
+                                                      double swt, bool cX, bool sX, int lane, int row_lo,
+                                                      const FusedPre<T> &p) {
+  constexpr int VW = FusedPre<T>::VW, LPR = 64 / VW, JB = FusedPre<T>::JB;
+  typedef typename FusedPre<T>::vt vt;
+  const int sub = lane / LPR, lc = VW * (lane - sub * LPR);
+  const int gc = b0 + lc;
+  const bool col_ok = gc < K;
+  double muc[VW], sdc[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { muc[e] = rs[128 + lc + e]; sdc[e] = rs[192 + lc + e]; }
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int lr = row_lo + 16 * b + VW * j + sub, gr = a0 + lr;
+      if (!(col_ok && gr < K)) continue;
+      const double mur = rs[lr], sdr = rs[64 + lr];
+      vt vv;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        double v = (double)p.gv[b][j][e] - (double)Ts[lr][lc + e];
+        if (cX) v -= swt * (mur * muc[e]);
+        if (sX) v = v * (sdr * sdc[e]);
+        vv[e] = (T)v;
+      }
+      out_store(reinterpret_cast<vt *>(out + (size_t)gr * K + gc), vv);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) Ts[lr][lc + e] = vv[e];          // parked for the mirrored store
+    }
 }
 // Mirrored half: rows b0 + r for r in [row_lo, row_hi), columns a0..; out[b0 + r][a0 + c] = finished[c][r]
 template <typename T, int TP>

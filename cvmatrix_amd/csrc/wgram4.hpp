@@ -43,6 +43,13 @@ template <typename T> constexpr size_t lds4_bytes() { return (size_t)NBUF4 * BUF
 //   ROLER 0/1/2: compute wave without sums / with X column sums / with Y column sums
 //   ROLER 3: loader wave
 __host__ __device__ inline size_t fstat_len(int K, int M);
+template <typename T> struct FusedPre;                                          // finalize.hpp
+template <typename T>
+__device__ __forceinline__ void fused_g_preload32(FusedPre<T> &p, int a0, int b0, int K, const T *Gt, int lane, int row_lo);
+template <typename T, int TP>
+__device__ __forceinline__ void fused_finish_direct32(T (*Ts)[TP], const double *rs, int a0, int b0, int K, T *out,
+                                                      double swt, bool cX, bool sX, int lane, int row_lo,
+                                                      const FusedPre<T> &p);
 template <typename T, int TP>
 __device__ __forceinline__ void fused_finish_block(T (*Ts)[TP], const double *rs, bool diagb, int a0,
                                                    int b0, int K, const T *Gt, T *out,
@@ -335,9 +342,11 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         T (*Ts)[65] = reinterpret_cast<T (*)[65]>(slice);
         const double *rs = reinterpret_cast<const double *>(slice + wave_tile_bytes<T>());
         T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
+        FusedPre<T> gp;
+        if (active) fused_g_preload32<T>(gp, a0, b0, K, (const T *)a.G, lane, 32);   // in flight across B_dump
         lds_barrier();     // B_dump
         if (active)
-          fused_finish_direct<T, 65>(Ts, rs, false, a0, b0, K, (const T *)a.G, outp, swt, cX, sX, lane, 32, 64);
+          fused_finish_direct32<T, 65>(Ts, rs, a0, b0, K, outp, swt, cX, sX, lane, 32, gp);
         lds_barrier();     // B_parked (LDS only: the direct stores need not be acknowledged first)
         if (active) fused_finish_mirror<T, 65>(Ts, a0, b0, K, outp, lane, 32, 64);
       }
@@ -570,11 +579,16 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       T (*Ts)[65] = reinterpret_cast<T (*)[65]>(slice);
       double *rs = reinterpret_cast<double *>(slice + wave_tile_bytes<T>());
       T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
+      FusedPre<T> gp;
       if (active) {
-        rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
-        rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
-        rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
-        rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
+        // the statistics first, then the G pieces of this wave's 32 rows: both in flight while the
+        // accumulators go to LDS (the statistics are waited for alone: they were issued first)
+        const double r0v = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
+        const double r1v = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
+        const double r2v = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
+        const double r3v = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
+        fused_g_preload32<T>(gp, a0, b0, K, (const T *)a.G, lane, 0);
+        rs[lane] = r0v; rs[64 + lane] = r1v; rs[128 + lane] = r2v; rs[192 + lane] = r3v;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -591,7 +605,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       STAMP(f2);
 #endif
       if (active)
-        fused_finish_direct<T, 65>(Ts, rs, false, a0, b0, K, (const T *)a.G, outp, swt, cX, sX, lane, 0, 32);
+        fused_finish_direct32<T, 65>(Ts, rs, a0, b0, K, outp, swt, cX, sX, lane, 0, gp);
 #ifdef CVM_STAMPS
       STAMP(f3);
 #endif
