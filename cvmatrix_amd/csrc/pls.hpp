@@ -1096,8 +1096,8 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
     if (cb == 0 && tid == 0) *wpart = 0.0;
     return;
   }
-  __shared__ T Zs[2][SSE_KS][SSE_ZP];                         // [buffer][k][row]: the A operand's lanes run over rows
-  __shared__ T Bs[2][SSE_KS][SSE_BP];                         // [buffer][k][column]
+  __shared__ T Zs[SSE_KS][SSE_ZP];                            // [k][row]: the A operand's lanes run over rows
+  __shared__ T Bs[SSE_KS][SSE_BP];                            // [k][column]
   __shared__ int64_t rows[SSE_ROWS];
   __shared__ double wl[SSE_ROWS];
   __shared__ double red[4][SSE_COLS];
@@ -1116,18 +1116,16 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
   acc_t acc[4];
 #pragma unroll
   for (int nn = 0; nn < 4; ++nn) acc[nn] = (acc_t){0, 0, 0, 0};
-  // staging maps: Z element (row zr, k zk + 4 j), B element (k bk + 4 j, column bc), j < SSE_KS / 4.
-  // Two LDS buffers: the loads of stage s + 1 are in flight while stage s multiplies, one barrier
-  // per stage.
-  constexpr int NEL = SSE_KS / 4;
+  // staging maps: Z element (row zr, k zk + 4 j), j < 4; B element (k bk + 4 j, column bc)
   const int zr = tid & 63, zk = tid >> 6;
   const int bc = tid & 63, bk = tid >> 6;
   const int gcol = c0 + bc;
   const int ba = gcol < C ? gcol / M : 0, bm = gcol < C ? gcol - ba * M : 0;
   const bool zok = r0 + zr < n;
   const T *xrow = X + rows[zr] * (int64_t)K;
-  T zv[NEL], bv[NEL];
-  auto fetch = [&](int k0) {
+  for (int k0 = 0; k0 < K; k0 += SSE_KS) {
+    constexpr int NEL = SSE_KS / 4;
+    T zv[NEL], bv[NEL];
 #pragma unroll
     for (int j = 0; j < NEL; ++j) {
       const int k = k0 + zk + 4 * j;
@@ -1141,26 +1139,16 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
       const int kb = k0 + bk + 4 * j;
       bv[j] = (gcol < C && kb < K) ? Bf[((size_t)ba * K + kb) * M + bm] : (T)0;
     }
-  };
-  auto park = [&](int buf) {
+    __syncthreads();                                          // the previous stage's fragments have been read
 #pragma unroll
-    for (int j = 0; j < NEL; ++j) { Zs[buf][zk + 4 * j][zr] = zv[j]; Bs[buf][bk + 4 * j][bc] = bv[j]; }
-  };
-  fetch(0);
-  park(0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += SSE_KS, buf ^= 1) {
-    const bool more = k0 + SSE_KS < K;
-    if (more) fetch(k0 + SSE_KS);
+    for (int j = 0; j < NEL; ++j) { Zs[zk + 4 * j][zr] = zv[j]; Bs[bk + 4 * j][bc] = bv[j]; }
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < SSE_KS; ks += 4) {
-      const T af = Zs[buf][ks + lk][16 * wave + lc];
+      const T af = Zs[ks + lk][16 * wave + lc];
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) acc[nn] = MF<T>::mfma(af, Bs[buf][ks + lk][16 * nn + lc], acc[nn]);
+      for (int nn = 0; nn < 4; ++nn) acc[nn] = MF<T>::mfma(af, Bs[ks + lk][16 * nn + lc], acc[nn]);
     }
-    if (more) park(buf ^ 1);
-    __syncthreads();
   }
   // squared errors: register r of tile nn is (row 16 wave + drow(lane, r), column 16 nn + lc)
   const T *muY = a.muY ? (const T *)a.muY + (size_t)f * M : nullptr;
