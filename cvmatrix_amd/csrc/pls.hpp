@@ -1116,19 +1116,24 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
   acc_t acc[4];
 #pragma unroll
   for (int nn = 0; nn < 4; ++nn) acc[nn] = (acc_t){0, 0, 0, 0};
-  // staging maps: Z element (row zr, k zk + 4 j), j < 4; B element (k bk + 4 j, column bc)
-  const int zr = tid & 63, zk = tid >> 6;
+  // staging maps.  Z: thread -> (row zr = tid / 4, k quad zq = tid % 4): four CONSECUTIVE k of one row, so
+  // that a wave instruction touches 16 rows' lines once (a thread per (row, single k) touched 64 lines
+  // per instruction, 16 times what the stage needs: the kernel was bound by the memory pipe's ~3.5
+  // cycles per line touched, 22 TFLOP/s).  B: element (k bk + 4 j, column bc): a wave instruction =
+  // four 128-byte runs of M responses.
+  constexpr int NEL = SSE_KS / 4;
+  static_assert(NEL == 4, "the Z staging map takes four k per thread");
+  const int zr = tid >> 2, zq = tid & 3;
   const int bc = tid & 63, bk = tid >> 6;
   const int gcol = c0 + bc;
   const int ba = gcol < C ? gcol / M : 0, bm = gcol < C ? gcol - ba * M : 0;
   const bool zok = r0 + zr < n;
   const T *xrow = X + rows[zr] * (int64_t)K;
   for (int k0 = 0; k0 < K; k0 += SSE_KS) {
-    constexpr int NEL = SSE_KS / 4;
     T zv[NEL], bv[NEL];
 #pragma unroll
     for (int j = 0; j < NEL; ++j) {
-      const int k = k0 + zk + 4 * j;
+      const int k = k0 + 4 * zq + j;
       T z = (T)0;
       if (zok && k < K) {
         z = xrow[k];
@@ -1141,7 +1146,7 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
     }
     __syncthreads();                                          // the previous stage's fragments have been read
 #pragma unroll
-    for (int j = 0; j < NEL; ++j) { Zs[zk + 4 * j][zr] = zv[j]; Bs[bk + 4 * j][bc] = bv[j]; }
+    for (int j = 0; j < NEL; ++j) { Zs[4 * zq + j][zr] = zv[j]; Bs[bk + 4 * j][bc] = bv[j]; }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < SSE_KS; ks += 4) {
