@@ -235,3 +235,48 @@ def test_header_constants_match_the_python_binding():
     }
     for name, value in expect.items():
         assert defs.get(name) == value, (name, defs.get(name), value)
+
+
+def test_exact_index_comparison_helpers():
+    """The comparisons behind every served loop (cvmatrix_amd/cvmatrix.py): exact, not sampled."""
+    from cvmatrix_amd.cvmatrix import _same_indices, _same_objects, _NO_WEIGHTS, _WeightsToken
+
+    a = np.arange(0, 100000, 10)
+    b = a.copy()
+    assert _same_indices(a, b)
+    b[4321] += 1                                   # one interior element, not an end, not on any stride
+    assert not _same_indices(a, b)
+    b = a.copy(); b[100] += 5; b[200] -= 5          # same size, ends and sum
+    assert b.sum() == a.sum() and not _same_indices(a, b)
+    assert not _same_indices(a, a[:-1]) and _same_indices(a[::2], a[::2].copy())      # (non-contiguous views too)
+    assert _same_indices(a.astype(np.int32), a)                                       # other dtype, same values
+    x, y = np.arange(3), np.arange(3)
+    assert _same_objects([x, y], [x, y]) and not _same_objects([x, y], [x, y.copy()]) and not _same_objects([x], [x, y])
+    assert _WeightsToken() is not _WeightsToken() and _NO_WEIGHTS is _NO_WEIGHTS
+
+
+def test_local_counts_decide_the_checks_without_the_global_ones():
+    """CVMatrix._passes_on_local_counts: this process's counts are lower bounds of the global ones; when
+    even they leave every training set more non-zero weights than ddof no raise is possible."""
+    from cvmatrix_amd.cvmatrix import FoldBatch
+
+    m = CVMatrix(ddof=1)
+    sizes = np.array([10, 10], dtype=np.int64)
+    fb = FoldBatch(None, None, np.array([0, 10, 20], dtype=np.int64), sizes.copy(), None, np.arange(20), 20)
+    m.weights, m._n_total, m._nz_total = None, 20, 20
+    assert m._passes_on_local_counts(fb, True, True)              # 20 - 10 = 10 > ddof
+    one = FoldBatch(None, None, np.array([0, 20], dtype=np.int64), np.array([20]), None, np.arange(20), 20)
+    assert not m._passes_on_local_counts(one, True, True)         # the rank's only fold is all of its rows: must ask
+    assert m._passes_on_local_counts(one, False, False)           # nothing to check
+    m.weights, m._nz_total = object(), 12                         # weighted: counts of non-zero weights
+    fb.nz_val = np.array([10, 11])
+    assert not m._passes_on_local_counts(fb, True, True) and m._passes_on_local_counts(fb, True, True, only=0)
+    m.ddof = 0
+    assert m._passes_on_local_counts(fb, True, True)
+
+
+def test_emulated_rank_is_importable_without_a_gpu():
+    from cvmatrix_amd.emulate import EmulatedRank
+
+    r = EmulatedRank(emu_world=8, emu_rank=3, lazy_fit=True)
+    assert r.world == 8 and r.rank == 3 and r._exchanges_globals() and r.lazy_fit
