@@ -257,7 +257,7 @@ int cvm_pls_fit(const void *XTX, const void *XTY, int64_t n_folds, int K, int M,
                 void *ws, size_t ws_bytes, void *stream) {
   if (!XTX || !XTY || !B || !n_fit || !status || !ws) return fail(CVM_EINVAL, "cvm_pls_fit: null pointer%s");
   if (n_folds < 0 || K <= 0 || M <= 0 || A <= 0) return fail(CVM_EINVAL, "cvm_pls_fit: bad shape%s");
-  if (M > PLS_MAXM) return fail(CVM_EINVAL, "cvm_pls_fit: at most 32 responses%s");
+  if (M > PLS_MAXM) return fail(CVM_EINVAL, "cvm_pls_fit: at most 64 responses%s");
   if (A > PLS_MAXA) return fail(CVM_EINVAL, "cvm_pls_fit: at most 512 components%s");
   if (dtype == CVM_F64)
     return pls_fit_impl<double>(XTX, XTY, n_folds, K, M, A, B, W, P, Q, R, n_fit, status, ws, ws_bytes, (hipStream_t)stream);

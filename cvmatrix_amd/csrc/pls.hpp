@@ -18,7 +18,7 @@
 
 constexpr int PLS_THREADS = 512;
 constexpr int PLS_NW = PLS_THREADS / 64;
-constexpr int PLS_MAXM = 32;        // responses (the M x M eigenproblem lives in LDS)
+constexpr int PLS_MAXM = 64;        // responses (the M x M eigenproblem lives in LDS)
 constexpr int PLS_MAXA = 512;       // components
 constexpr size_t PLS_LDS_BUDGET = 150 * 1024;
 
@@ -40,6 +40,12 @@ struct PlsArgs {
   double *prw, *xu;
 };
 
+#ifdef CVM_STAMPS
+__device__ unsigned long long g_pls_stamps[16];
+#define PLS_COUNT_SQUARING() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x < 64) g_pls_stamps[15] += 1; } while (0)
+#else
+#define PLS_COUNT_SQUARING()
+#endif
 __host__ __device__ inline size_t pls_xch_len(int K, int M, int A, int S) {
   return (size_t)S * M * M + (size_t)S * (1 + A) + (size_t)K + (size_t)S * (1 + M);
 }
@@ -62,6 +68,26 @@ __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_add<0x118, 0xF, 0xC>(v);          // row_shr:8, banks 2-3: lane 15 of every row = row sum
   v = dpp_add<0x142, 0xA, 0xF>(v);          // row_bcast:15 into rows 1 and 3
   v = dpp_add<0x143, 0xC, 0xF>(v);          // row_bcast:31 into rows 2 and 3: lane 63 = total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// Largest of 64 non-negative values, the same in every lane (lanes without a source compare with +0.0).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_max(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, false);
+  return fmax(v, __hiloint2double(hi, lo));
+}
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+  v = dpp_max<0x111, 0xF, 0xF>(v);
+  v = dpp_max<0x112, 0xF, 0xF>(v);
+  v = dpp_max<0x114, 0xF, 0xE>(v);
+  v = dpp_max<0x118, 0xF, 0xC>(v);
+  v = dpp_max<0x142, 0xA, 0xF>(v);
+  v = dpp_max<0x143, 0xC, 0xF>(v);
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
@@ -124,7 +150,6 @@ __device__ __forceinline__ bool fold_barrier(unsigned *cnt, unsigned &target, in
 }
 
 #ifdef CVM_STAMPS
-__device__ unsigned long long g_pls_stamps[16];
 #define PLS_STAMP(i)                                                          \
   do {                                                                        \
     if (blockIdx.x == 0 && threadIdx.x == 0) {                                \
@@ -202,13 +227,14 @@ __device__ __forceinline__ void pls_gram_mfma(const double *Y, int yst, int n, i
   }
 }
 
-// one wave: m <- m^2 / trace(m^2) until m is numerically rank one (m symmetric, trace 1)
+// one wave: m <- m^2 / trace(m^2) until m is numerically rank one (m symmetric, trace 1).
+// trace(m^2) = sum of the squares of m's entries (m symmetric): it is reduced over the lanes from
+// the INPUT of a squaring while the matrix cores form the product, so the divisor is there when
+// the product is.
 template <int NB>
 __device__ __forceinline__ void pls_power_mfma(pls_v4d (&m)[NB][NB], int lane) {
-  const int col = lane & 15, sub = lane >> 4;
   for (int it = 0; it < 64; ++it) {
     pls_v4d sq[NB][NB];
-    double d = 0.0;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
@@ -219,13 +245,17 @@ __device__ __forceinline__ void pls_power_mfma(pls_v4d (&m)[NB][NB], int lane) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m[bk][bi][q], m[bk][bj][q], acc, 0, 0, 0);
         sq[bi][bj] = acc;
-        if (bi == bj) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) d += (sub + 4 * q == col) ? acc[q] : 0.0;
-        }
       }
+    double d = 0.0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d = fma(m[bi][bj][q], m[bi][bj][q], d);
+    PLS_COUNT_SQUARING();
     const double t2 = wave_sum(d);                             // sum lambda^2 with sum lambda = 1
-    const double inv = 1.0 / t2;
+    const double inv = __builtin_amdgcn_rcp(t2);               // a scaling only: the test below reads t2 itself
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
@@ -269,6 +299,7 @@ __device__ __forceinline__ void pls_gram_phase(const double *Y, int yst, int n, 
 template <int NB>
 __device__ __forceinline__ void pls_eig_phase(const double *S0, double tr, int M, double *fin, int lane) {
   const int col = lane & 15, sub = lane >> 4;
+  const double itr = 1.0 / tr;
   pls_v4d m[NB][NB];
 #pragma unroll
   for (int bi = 0; bi < NB; ++bi)
@@ -277,7 +308,7 @@ __device__ __forceinline__ void pls_eig_phase(const double *S0, double tr, int M
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = 16 * bi + sub + 4 * q, c = 16 * bj + col;
-        m[bi][bj][q] = (row < M && c < M) ? S0[(size_t)row * M + c] / tr : 0.0;
+        m[bi][bj][q] = (row < M && c < M) ? S0[(size_t)row * M + c] * itr : 0.0;
       }
   pls_power_mfma<NB>(m, lane);
 #pragma unroll
@@ -289,6 +320,156 @@ __device__ __forceinline__ void pls_eig_phase(const double *S0, double tr, int M
         const int row = 16 * bi + sub + 4 * q, c = 16 * bj + col;
         if (row < M && c < M) fin[(size_t)row * M + c] = m[bi][bj][q];
       }
+}
+
+// 32 < M <= 16 NB: only the blocks on and above the diagonal are accumulated (NB (NB + 1) / 2
+// accumulators instead of NB^2) and each is handed over at (i, j) and (j, i) -- the same sum, so
+// the matrix is symmetric to the bit.
+template <int NB, bool SLICED>
+__device__ __forceinline__ void pls_gram_phase_tri(const double *Y, int yst, int n, int M, double *ms,
+                                                   double *x_S_slice, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, col = lane & 15, sub = lane >> 4;
+  constexpr int NT = NB * (NB + 1) / 2;
+  pls_v4d s[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s[t] = pls_v4d{0.0, 0.0, 0.0, 0.0};
+  for (int r0 = 4 * wave; r0 < n; r0 += 4 * PLS_NW) {
+    const int r = r0 + sub;
+    double y[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) y[b] = (16 * b + col < M && r < n) ? Y[(size_t)r * yst + 16 * b + col] : 0.0;
+    int t = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+      for (int bj = bi; bj < NB; ++bj, ++t) s[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[bi], y[bj], s[t], 0, 0, 0);
+  }
+  int t = 0;
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+    for (int bj = bi; bj < NB; ++bj, ++t) {
+      if (t) __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ms[wave * 256 + (sub + 4 * q) * 16 + col] = s[t][q];
+      __syncthreads();
+      if (tid < 256) {
+        double msum = 0.0;
+#pragma unroll
+        for (int w = 0; w < PLS_NW; ++w) msum += ms[w * 256 + tid];
+        const int i = 16 * bi + (tid >> 4), j = 16 * bj + (tid & 15);
+        if (i < M && j < M) {
+          xput<SLICED>(&x_S_slice[i * M + j], msum);
+          if (bi != bj) xput<SLICED>(&x_S_slice[j * M + i], msum);
+        }
+      }
+    }
+}
+
+// 32 < M <= 16 NB: the squarings with the matrix in LDS and every wave at work -- block (bi, bj) of
+// the product by wave (bi NB + bj) mod waves, its operands read from LDS straight into the register
+// maps above (A[i][k] = cur[k][i]: the matrix is symmetric).  cur, scaled by `scale`, has trace 1;
+// the product is stored with that scaling and its trace (sum lambda^2) is the next divisor.  Two
+// LDS buffers in turn, one barrier per squaring.  Returns the buffer of the last product (not
+// divided by its trace: the caller takes a column's direction).  Called by all threads.
+template <int NB>
+__device__ __forceinline__ double *pls_eig_lds(const double *S0, double tr, int M, double *Ba, double *Bb,
+                                               double *trp, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, col = lane & 15, sub = lane >> 4;
+  const double *cur = S0;
+  double *nxt = Ba;
+  double scale = 1.0 / tr;
+  for (int it = 0; it < 64; ++it) {
+    const double s2 = scale * scale;
+    double d = 0.0;
+    for (int b = wave; b < NB * NB; b += PLS_NW) {
+      const int bi = b / NB, bj = b - bi * NB;
+      const int ca = 16 * bi + col, cb = 16 * bj + col;
+      pls_v4d acc = {0.0, 0.0, 0.0, 0.0};
+      double av[4 * NB], bv[4 * NB];                           // all operands in flight before the first MFMA
+#pragma unroll
+      for (int t = 0; t < 4 * NB; ++t) {
+        const int k = 4 * t + sub;
+        av[t] = (k < M && ca < M) ? cur[(size_t)k * M + ca] : 0.0;
+        bv[t] = (k < M && cb < M) ? cur[(size_t)k * M + cb] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < 4 * NB; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * bi + sub + 4 * q;
+        const double v = acc[q] * s2;
+        if (row < M && cb < M) nxt[(size_t)row * M + cb] = v;
+        if (bi == bj && sub + 4 * q == col) d += v;
+      }
+    }
+    PLS_COUNT_SQUARING();
+    d = wave_sum(d);
+    if (lane == 0) trp[(it & 1) * PLS_NW + wave] = d;
+    __syncthreads();
+    double t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < PLS_NW; ++w) t2 += trp[(it & 1) * PLS_NW + w];
+    scale = __builtin_amdgcn_rcp(t2);
+    cur = nxt;
+    nxt = (nxt == Ba) ? Bb : Ba;
+    if (1.0 - t2 < 1e-13) break;                               // the same test as pls_power_mfma
+  }
+  return const_cast<double *>(cur);
+}
+
+// q = the dominant eigenvector of the symmetric M x M matrix S0 (LDS), left in qv[0, M): repeated
+// squaring B_0 = S / trace, B_{t+1} = B_t^2 / trace(B_t^2) -- trace(B_t^2) = sum lambda^2 (trace 1
+// before) reaches 1 when B_t is numerically rank one -- then the column with the largest diagonal
+// entry, polished by two power steps with S0 itself.  Called by all threads after a barrier that
+// completed S0; Ba, Bb: two more M x M buffers, trp: 2 x waves numbers.  The small reductions
+// (trace, largest diagonal, norms) are one lane per entry and a wave reduction, the same in every wave.
+#ifdef CVM_STAMPS
+#define PLS_QSTAMP(i) do { if (stamp_p && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); g_pls_stamps[i] += now_ - *stamp_p; } } while (0)
+#else
+#define PLS_QSTAMP(i)
+#endif
+__device__ __forceinline__ void pls_dominant_q(const double *S0, double *Ba, double *Bb, double *trp, double *qv,
+                                               int M, int tid, unsigned long long *stamp_p = nullptr) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const double tr = wave_sum(lane < M ? S0[(size_t)lane * M + lane] : 0.0);
+  if (!(tr > 0.0)) {
+    if (tid < M) qv[tid] = 0.0;
+    __syncthreads();
+    return;
+  }
+  double *fin = Ba;                                            // the (nearly) rank-one power of S
+  if (M <= 32) {
+    // wave 0, the matrix in registers (see the register maps above)
+    if (wave == 0) {
+      if (M <= 16) pls_eig_phase<1>(S0, tr, M, fin, lane);
+      else pls_eig_phase<2>(S0, tr, M, fin, lane);
+    }
+    __syncthreads();
+  } else {
+    fin = M <= 48 ? pls_eig_lds<3>(S0, tr, M, Ba, Bb, trp, tid) : pls_eig_lds<4>(S0, tr, M, Ba, Bb, trp, tid);
+  }
+  PLS_QSTAMP(12);                                              // (diagnostic builds: cycles since phase 2a began)
+  double *scr = fin == Bb ? Ba : Bb;
+  const double dg = lane < M ? fmax(fin[(size_t)lane * M + lane], 0.0) : 0.0;
+  const double mx = wave_max_nonneg(dg);
+  int best = __ffsll((unsigned long long)__ballot(lane < M && dg == mx)) - 1;   // the lowest index among equals
+  if (best < 0) best = 0;
+  if (tid < M) qv[tid] = fin[(size_t)tid * M + best];
+  __syncthreads();
+  PLS_QSTAMP(13);
+  for (int polish = 0; polish < 2; ++polish) {
+    double v = 0.0;
+    if (tid < M) {
+      for (int k = 0; k < M; ++k) v += S0[(size_t)k * M + tid] * qv[k];        // S0 is symmetric to the bit
+      scr[tid] = v;
+    }
+    __syncthreads();
+    const double sv = lane < M ? scr[lane] : 0.0;
+    const double nn = sqrt(wave_sum(sv * sv));
+    if (tid < M) qv[tid] = nn > 0.0 ? v / nn : 0.0;
+    __syncthreads();
+  }
 }
 
 // dst[p] = sum over the S slices of x[t * len + p], p in [0, len): a thread per element, the
@@ -381,7 +562,9 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
     if (M > 1) {
       // ---- 1: partial XTY^T XTY of the slice's rows ----------------------------------------
       if (M <= 16) pls_gram_phase<1, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
-      else pls_gram_phase<2, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
+      else if (M <= 32) pls_gram_phase<2, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
+      else if (M <= 48) pls_gram_phase_tri<3, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
+      else pls_gram_phase_tri<4, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
       PLS_STAMP(1);
       if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
       PLS_STAMP(2);
@@ -390,37 +573,12 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
       // before) reaches 1 when B_t is numerically rank one.
       xreduce<SLICED>(x_S, MM, S, S0, tid);
       __syncthreads();
-      double tr = 0.0;
-      for (int i = 0; i < M; ++i) tr += S0[(size_t)i * M + i];
-      double *fin = Ba;                                        // the (nearly) rank-one power of S
-      if (tr > 0.0) {
-        // wave 0, the matrix in registers (see the register maps above)
-        if (wave == 0) {
-          if (M <= 16) pls_eig_phase<1>(S0, tr, M, fin, lane);
-          else pls_eig_phase<2>(S0, tr, M, fin, lane);
-        }
-        __syncthreads();
-        // the column with the largest diagonal entry, then two power steps with the sum itself
-        double *scr = Bb;
-        int best = 0;
-        for (int i = 1; i < M; ++i) if (fin[(size_t)i * M + i] > fin[(size_t)best * M + best]) best = i;
-        if (tid < M) qv[tid] = fin[(size_t)tid * M + best];
-        __syncthreads();
-        for (int polish = 0; polish < 2; ++polish) {
-          double v = 0.0;
-          if (tid < M) for (int k = 0; k < M; ++k) v += S0[(size_t)tid * M + k] * qv[k];
-          if (tid < M) scr[tid] = v;
-          __syncthreads();
-          double nn = 0.0;
-          for (int k = 0; k < M; ++k) nn += scr[k] * scr[k];
-          nn = sqrt(nn);
-          if (tid < M) qv[tid] = nn > 0.0 ? v / nn : 0.0;
-          __syncthreads();
-        }
-      } else {
-        if (tid < M) qv[tid] = 0.0;
-        __syncthreads();
-      }
+#ifdef CVM_STAMPS
+      if (blockIdx.x == 0 && tid == 0) g_pls_stamps[14] += __builtin_readcyclecounter() - stamp_;
+      pls_dominant_q(S0, Ba, Bb, ms, qv, M, tid, &stamp_);
+#else
+      pls_dominant_q(S0, Ba, Bb, ms, qv, M, tid);
+#endif
     }
     PLS_STAMP(3);
     // ---- 2b: w of the slice (not normalised yet), its partial norm and partial P^T w -------
@@ -660,37 +818,11 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_rep_kernel(const PlsArgs a) {
     if (M > 1) {
       // ---- XTY^T XTY over all rows, its dominant eigenvector q (as in pls_kernel, nothing traded)
       if (M <= 16) pls_gram_phase<1, false>(Yl, yst, K, M, ms, S0, tid);
-      else pls_gram_phase<2, false>(Yl, yst, K, M, ms, S0, tid);
+      else if (M <= 32) pls_gram_phase<2, false>(Yl, yst, K, M, ms, S0, tid);
+      else if (M <= 48) pls_gram_phase_tri<3, false>(Yl, yst, K, M, ms, S0, tid);
+      else pls_gram_phase_tri<4, false>(Yl, yst, K, M, ms, S0, tid);
       __syncthreads();
-      double tr = 0.0;
-      for (int i = 0; i < M; ++i) tr += S0[(size_t)i * M + i];
-      double *fin = Ba;
-      if (tr > 0.0) {
-        if (wave == 0) {
-          if (M <= 16) pls_eig_phase<1>(S0, tr, M, fin, lane);
-          else pls_eig_phase<2>(S0, tr, M, fin, lane);
-        }
-        __syncthreads();
-        double *scr = Bb;
-        int best = 0;
-        for (int i = 1; i < M; ++i) if (fin[(size_t)i * M + i] > fin[(size_t)best * M + best]) best = i;
-        if (tid < M) qv[tid] = fin[(size_t)tid * M + best];
-        __syncthreads();
-        for (int polish = 0; polish < 2; ++polish) {
-          double v = 0.0;
-          if (tid < M) for (int k = 0; k < M; ++k) v += S0[(size_t)tid * M + k] * qv[k];
-          if (tid < M) scr[tid] = v;
-          __syncthreads();
-          double nn = 0.0;
-          for (int k = 0; k < M; ++k) nn += scr[k] * scr[k];
-          nn = sqrt(nn);
-          if (tid < M) qv[tid] = nn > 0.0 ? v / nn : 0.0;
-          __syncthreads();
-        }
-      } else {
-        if (tid < M) qv[tid] = 0.0;
-        __syncthreads();
-      }
+      pls_dominant_q(S0, Ba, Bb, ms, qv, M, tid);
     }
     // ---- w (all rows), its norm, P^T w ---------------------------------------------------------
     double nrm2 = 0.0;

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-MAX_RESPONSES = 32
+MAX_RESPONSES = 64
 MAX_COMPONENTS = 512
 
 

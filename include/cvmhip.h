@@ -185,7 +185,7 @@ int cvm_partition_labels(const int64_t *labels, int64_t N, int64_t n_labels, int
  * README.md:23, cvmatrix/partitioner.py:27-31: `ikpls`, fast cross-validation); the reference
  * itself holds no PLS code, so there is no reference line to cite beyond those.
  *   XTX [n_folds][K][K], XTY [n_folds][K][M]   the out_XTX / out_XTY of cvm_fold_update (not modified)
- *   A                    components, 1 <= A <= 512;  M <= 32
+ *   A                    components, 1 <= A <= 512;  M <= 64
  *   B   [n_folds][A][K][M]   B[f][a] = regression coefficients with a+1 components (required)
  *   W, P, R [n_folds][K][A], Q [n_folds][M][A]      weights / loadings / rotations (each may be NULL)
  *   n_fit  int32[n_folds]    components extracted (< A only if XTY deflated to zero: the rest stay 0)

@@ -83,6 +83,11 @@ def fold_matrices(N, K, M, P, seed, dtype=np.float64, weighted=True):
     (500, 40, 20, 4, 8),       # 16 < M <= 32: the M x M matrix in 2 x 2 MFMA blocks
     (700, 48, 32, 300, 6),
     (400, 36, 17, 2, 5),
+    (500, 40, 33, 4, 6),       # 32 < M <= 64: the squarings in LDS by all waves (3 x 3, 4 x 4 blocks)
+    (600, 64, 48, 3, 8),
+    (700, 48, 64, 300, 5),
+    (400, 72, 50, 2, 6),
+    (1500, 512, 64, 10, 5),    # too large for the replicated-state kernel: XTY cut in slices
 ])
 def test_folds_from_cvmatrix_match_oracle(pls, N, K, M, P, A):
     from cvmatrix_amd import CVMatrix
@@ -158,7 +163,7 @@ def test_argument_errors(pls):
     with pytest.raises(ValueError):
         pls.pls_fit_batched(XTX, XTY.float(), 2)
     with pytest.raises(ValueError):
-        pls.pls_fit_batched(XTX, torch.ones((1, 4, 33), dtype=torch.float64, device="cuda"), 2)
+        pls.pls_fit_batched(XTX, torch.ones((1, 4, 65), dtype=torch.float64, device="cuda"), 2)
     with pytest.raises(TypeError):
         pls.pls_fit_batched(XTX.cpu(), XTY.cpu(), 2)
 
@@ -259,6 +264,7 @@ def test_four_barrier_kernel_still_agrees(pls):
     (np.float64, 2111, 130, 2, 5, 5, False, (True, True, False, False)),
     (np.float64, 1500, 36, 16, 3, 20, True, (False, False, False, False)),
     (np.float32, 4000, 128, 3, 8, 6, True, (True, True, True, True)),
+    (np.float64, 2000, 96, 40, 4, 6, True, (True, True, True, True)),      # 32 < M <= 64
 ])
 def test_validation_sse_on_the_device(pls, dtype, N, K, M, P, A, weighted, flags):
     """cvm_pls_validation_sse: the squared validation errors of every fold's models (every number of

@@ -76,4 +76,4 @@ def test_device_pls_plan_is_host_logic():
     p = pls_plan(20, 4096, 1, 20, np.float32)           # wide K: sliced, streamed
     assert p["slices"] > 1 and p["slices"] * p["folds_per_launch"] <= 256
     with pytest.raises(RuntimeError):
-        pls_plan(4, 16, 33, 2)
+        pls_plan(4, 16, 65, 2)

@@ -61,3 +61,6 @@ if __name__ == "__main__":
     run("K=500 M=10, 2000 folds", 100000, 500, 10, 2000, 20)
     run("C4 shape", 200000, 1024, 32, 64, 20)
     run("C5 shape fp32", 50000, 4096, 1, 20, 20, np.float32)
+    run("C3 shape, M=48", 100000, 512, 48, 10, 20)
+    run("C3 shape, M=64", 100000, 512, 64, 10, 20)
+    run("K=128 M=64, 100 folds", 100000, 128, 64, 100, 20)

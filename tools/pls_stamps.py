@@ -19,9 +19,16 @@ def run(F, K, M, A, dtype=torch.float64):
     pls_fit_batched(XTX, XTY, A)
     lib.cvm_debug_pls_stamps(buf, 1)
     a = np.array(list(buf), dtype=np.float64)
-    print(f"F={F} K={K} M={M} A={A} {pls_plan(F, K, M, A)}  total {a.sum()/A:.0f} shader-clock cycles/component")
+    print(f"F={F} K={K} M={M} A={A} {pls_plan(F, K, M, A)}  total {a[:12].sum()/A:.0f} shader-clock cycles/component")
+    print(f"   squarings          {a[15] / A:10.1f} per component")
+    print(f"   within 2a, cumulative: xreduce {a[14]/A:.0f}, squarings done {a[12]/A:.0f}, column picked {a[13]/A:.0f} cycles/component")
+    a[12:16] = 0
     for i, nm in enumerate(NAMES):
         print(f"   {nm:18s} {a[i]/ (1 if i == 0 else A):10.0f} cycles{'' if i == 0 else '/component'}")
+if len(sys.argv) > 2:
+    for spec in sys.argv[2:]:
+        run(*[int(v) for v in spec.split(",")])
+    sys.exit(0)
 run(10, 512, 16, 20)
 run(1000, 512, 16, 20)
 run(20, 4096, 1, 10, torch.float32)
