@@ -457,6 +457,29 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
   return CVM_OK;
 }
 
+// Folds of at most so many rows take the direct kernels (small_folds.hpp).  Beyond one 32-row chunk
+// the direct kernels pay about 0.2 of a fold's store time per 16 rows, the fused Gram route
+// (one unit per fold) starts higher and grows slower; the crossover was measured per shape on
+// one box (tools/exp_small_limit.py, profiles/r3/exp_small_limit.txt: outputs in TB/s, direct /
+// fused): float64 K=512 33 rows 2.36 / 2.35, 48 rows 2.07 / 2.29; K=1024 48 rows 2.81 / 2.65, 64
+// rows 2.34 / 2.46; K=2048 48 rows 3.09 / 2.88, 64 rows 2.51 / 2.58; K=4096 (G no longer fits the
+// caches of the fused epilogue) 33 rows 3.53 / 1.65, 128 rows 1.65 / 1.24; float32 K=512 48 rows
+// 1.91 / 1.87, 64 rows 1.59 / 1.73; K=1024 ... 4096 64 rows 2.13 / 2.02 ... 2.38 / 2.35, 80 rows
+// 1.77 / 1.84 ... 2.04 / 2.24.  CVM_SMALL_MAXN (32 .. 128) overrides the table for measurements
+// and tests.
+int small_route_limit(int K, int esize) {
+  static const int forced = [] {
+    const char *e = getenv("CVM_SMALL_MAXN");
+    int v = e ? atoi(e) : 0;
+    if (e && v < SMALL_ROWS) v = SMALL_ROWS;
+    if (v > SMALL_MAXN) v = SMALL_MAXN;
+    return v;
+  }();
+  if (forced) return forced;
+  if (esize == 4) return K < 768 ? 48 : 64;
+  return K < 768 ? SMALL_ROWS : (K < 4096 ? 48 : SMALL_MAXN);
+}
+
 template <typename T>
 int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *idx, const int64_t *offsets,
                     int64_t n_folds, int64_t max_rows, int K, int M, unsigned flags, double ddof, double resolution,
@@ -490,7 +513,9 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     const int64_t wg1 = (int64_t)(a.nT64 + a.P64) * nb;
     int fpb = (int)(wg1 / (16 * 256));
     if (fpb < 1) fpb = 1;
-    if (fpb > 8) fpb = 8;
+    // (the workgroup keeps the row numbers of its folds in 256 slots: 8 folds of up to 32 rows, 4 of 64, 2 of 128)
+    a.rshift = max_rows <= 32 ? 5 : (max_rows <= 64 ? 6 : 7);
+    if (fpb > (256 >> a.rshift)) fpb = 256 >> a.rshift;
     a.nb = (int)nb; a.fpb = fpb;
     const dim3 gs((unsigned)nb), ga((unsigned)(a.nT64 + a.P64), (unsigned)((nb + fpb - 1) / fpb));
     // one- and two-row folds (leave-one-out) of a matrix whose rows are not whole 128-byte lines and
@@ -599,7 +624,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   }
   const WsCarve wq = carve_queue(ws, ws_bytes);
   ws_bytes = wq.usable;
-  if (max_rows <= SMALL_ROWS)
+  if (max_rows <= small_route_limit(K, (int)sizeof(T)))
     return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
   const bool want_xtx = (flags & CVM_RET_XTX) && out_XTX, want_xty = (flags & CVM_RET_XTY) && out_XTY;

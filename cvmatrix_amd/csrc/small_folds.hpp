@@ -1,5 +1,5 @@
 // small_folds.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
-// Direct HBM-bound kernels for folds of at most 32 rows.
+// Direct HBM-bound kernels for folds of few rows (at most SMALL_MAXN, staged SMALL_ROWS at a time).
 #pragma once
 
 // ----------------------------------------------------------------------------------
@@ -16,7 +16,8 @@
 //                       reference's order (cvmatrix.py:1001-1010) and the tile is written
 //                       twice -- as is and transposed through LDS -- with coalesced stores.
 // ----------------------------------------------------------------------------------
-constexpr int SMALL_ROWS = 32;
+constexpr int SMALL_ROWS = 32;          // rows staged at a time (one chunk); folds of at most so many take one pass
+constexpr int SMALL_MAXN = 128;         // the kernels take folds of up to so many rows, SMALL_ROWS at a time
 struct SmallArgs {
   const void *X, *Y, *w;
   const int64_t *idx, *offs;
@@ -35,6 +36,7 @@ struct SmallArgs {
   int inl_n;
   int64_t inl[SMALL_ROWS];
   int nb, fpb;                         // folds of this launch, folds per workgroup of small_apply_kernel
+  int rshift;                          // small_apply_kernel: 1 << rshift row slots per fold (32, 64, 128); fpb << rshift <= 256
   int gx, gy;                          // small_apply_kernel: tiles + panels, fold groups
 };
 
@@ -45,8 +47,8 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
   const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
   const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
-  __shared__ int64_t rows[SMALL_ROWS];
-  __shared__ double wl[SMALL_ROWS];
+  __shared__ int64_t rows[SMALL_MAXN];
+  __shared__ double wl[SMALL_MAXN];
   if ((int)threadIdx.x < n) {
     const int64_t r = inl ? a.inl[threadIdx.x] : a.idx[o0 + threadIdx.x];
     rows[threadIdx.x] = r;
@@ -146,20 +148,15 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
   // As: w * x, columns of the tile's rows; Bs: x (or y), columns of the tile's columns (SMALL_ROWS
   // rows of SA_PITCH each); Ts: the tile for the finish and the transposed store -- it reuses the
   // As / Bs space.  Elements are T: float32 problems stage and accumulate in float32.
-  // NF folds go through a pass together.  NF = 2 for float32 was measured (the tile kernel is bound by
-  // instructions per byte -- float32 moves half the bytes of float64 for the same instruction count,
-  // 4.5 against 5.8 TB/s with no rows at all -- and a pass pays barriers, loop control and output
-  // offsets once): SLOWER, 16-row folds 0.761 -> 0.831 ms, 32-row folds 0.884 -> 1.065 ms -- three
-  // workgroups per CU instead of five, more registers.  NF stays 1; the code keeps the parameter.
   typedef T TS;
-  constexpr int NF = 1;
   constexpr int AB_ELEMS = 2 * SMALL_ROWS * SA_PITCH, TS_ELEMS = ST * (ST + 1);
   constexpr int SLOT = AB_ELEMS > TS_ELEMS ? AB_ELEMS : TS_ELEMS;
-  __shared__ __attribute__((aligned(16))) TS sm[NF * SLOT];
-  __shared__ int64_t rows_all[SA_FPB][SMALL_ROWS];
-  __shared__ T wl_all[SA_FPB][SMALL_ROWS];
+  constexpr int NSLOT = SA_FPB * SMALL_ROWS;     // row slots of a workgroup: fpb folds x (1 << rshift) rows
+  __shared__ __attribute__((aligned(16))) TS sm[SLOT];
+  __shared__ int64_t rows_all[NSLOT];
+  __shared__ T wl_all[NSLOT];
   __shared__ int n_all[SA_FPB];
-  __shared__ double st_lds[2][NF][4 * ST];       // the folds' means / stds of the tile's rows and columns
+  __shared__ double st_lds[2][4 * ST];           // the fold's means / stds of the tile's rows and columns
   const bool xtx_part = x < a.nT64;
   if (xtx_part ? !a.out_XTX : (!a.out_XTY || M == 0)) return;
   int ti = 0, tj = 0;
@@ -167,22 +164,22 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
   const int a0 = (xtx_part ? ti : x - a.nT64) * ST, b0 = tj * ST;
   const int f_first = by * a.fpb;
   const int nf = (a.nb - f_first < a.fpb) ? a.nb - f_first : a.fpb;      // folds of this workgroup
+  const int rshift = a.rshift;
   // ---- every fold's row numbers, weights and row count, once ----------------------------------
   {
-    const int ff = tid >> 5, j = tid & 31;       // 8 folds x 32 row slots = 256 threads
-    int n = 0;
+    const int ff = tid >> rshift, j = tid & ((1 << rshift) - 1);         // fpb folds x row slots = 256 threads at most
     if (ff < nf) {
       const int f = f_first + ff;
       const int64_t o0 = inl ? 0 : a.offs[a.seg0 + f];
-      n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
+      const int n = inl ? a.inl_n : (int)(a.offs[a.seg0 + f + 1] - o0);
       int64_t r = 0;
       T wv = (T)0;
       if (j < n) {
         r = inl ? a.inl[j] : a.idx[o0 + j];
         wv = WEIGHTED ? W[r] : (T)1;
       }
-      rows_all[ff][j] = r;
-      wl_all[ff][j] = wv;
+      rows_all[tid] = r;
+      wl_all[tid] = wv;
       if (j == 0) n_all[ff] = n;
     }
   }
@@ -192,39 +189,36 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
     constexpr int NQG = ST * (ST / VWG) / 256;
     T gpre[NQG][VWG];
     finish_tile_preload<T, NQG>(gpre, a0, b0, K, (const T *)a.G, (const T *)a.out_XTX, tid, 256);
-    // staging element j of this thread: row sr0 + 4 j of the fold, column sc of the tile; up to
+    // staging element j of this thread: row sr0 + 4 j of the chunk, column sc of the tile; up to
     // SMALL_ROWS * 64 / 256 = 8 elements, each an A-side and a B-side value
     constexpr int NE = SMALL_ROWS * ST / 256;
     const int sc = tid & (ST - 1), sr0 = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches below)
     const bool ca_ok = a0 + sc < K, cb_ok = b0 + sc < K;
-    T pa[NF][NE], pb[NF][NE];
-    double pst[NF], pswt[NF];
-    auto request = [&](int ff0) {                // rows and statistics of folds ff0 .. ff0 + NF - 1 -> registers
+    T pa[NE], pb[NE];
+    double pst = 0.0, pswt = 0.0;
+    // rows of chunk ch of fold ff (and, with its first chunk, the fold's statistics) -> registers
+    auto request = [&](int ff, int ch) {
+      const int nc = n_all[ff] - SMALL_ROWS * ch;              // rows left from this chunk on
+      const int base = (ff << rshift) + SMALL_ROWS * ch;
 #pragma unroll
-      for (int g = 0; g < NF; ++g) {
-        const int ff = ff0 + g;
-        const int n = ff < nf ? n_all[ff] : 0;
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-          const int r = sr0 + 4 * j;
-          pa[g][j] = (T)0; pb[g][j] = (T)0;
-          if (r < n) {
-            const int64_t row = rows_all[ff][r];
-            if (ca_ok) pa[g][j] = X[row * (int64_t)K + a0 + sc];
-            if (cb_ok) pb[g][j] = X[row * (int64_t)K + b0 + sc];
-          }
-        }
-        pst[g] = 0.0; pswt[g] = 0.0;
-        if (ff < nf) {
-          const double *fs = a.fstats + (size_t)(f_first + ff) * fstat_len(K, M);
-          pswt[g] = fs[2 * K + 2 * M];
-          const int part = tid / ST, l = tid - part * ST;      // stage_tile_stats, one value per thread
-          const int col = ((part < 2) ? a0 : b0) + l;
-          pst[g] = (col < K) ? fs[((part & 1) ? K : 0) + col] : ((part & 1) ? 1.0 : 0.0);
+      for (int j = 0; j < NE; ++j) {
+        const int r = sr0 + 4 * j;
+        pa[j] = (T)0; pb[j] = (T)0;
+        if (r < nc) {
+          const int64_t row = rows_all[base + r];
+          if (ca_ok) pa[j] = X[row * (int64_t)K + a0 + sc];
+          if (cb_ok) pb[j] = X[row * (int64_t)K + b0 + sc];
         }
       }
+      if (ch == 0) {
+        const double *fs = a.fstats + (size_t)(f_first + ff) * fstat_len(K, M);
+        pswt = fs[2 * K + 2 * M];
+        const int part = tid / ST, l = tid - part * ST;        // stage_tile_stats, one value per thread
+        const int col = ((part < 2) ? a0 : b0) + l;
+        pst = (col < K) ? fs[((part & 1) ? K : 0) + col] : ((part & 1) ? 1.0 : 0.0);
+      }
     };
-    request(0);
+    request(0, 0);
     const int wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
     // Fast finish of a tile that lies wholly inside the matrix, off the diagonal, with 16-byte
     // accessible rows (all but the edge and diagonal tiles of a large K): piece j of this thread is
@@ -239,113 +233,106 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
     const size_t off_step = (size_t)FSTEP * K;
     typedef T vst_t __attribute__((ext_vector_type(VWG)));
     typedef typename MF<T>::acc_t acc_t;
-    int pass = 0;
-    for (int ff0 = 0; ff0 < nf; ff0 += NF, ++pass) {
-      const int ng = nf - ff0 < NF ? nf - ff0 : NF;            // folds of this pass
-      double swt[NF];
-      int n4[NF];
-      // the folds' rows (A side weighted, zero rows up to a multiple of 4) and statistics -> LDS
+    TS *As = sm, *Bs = sm + SMALL_ROWS * SA_PITCH;
+    TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm);
+    // One pass = one chunk of at most SMALL_ROWS rows of one fold; the accumulators live across the
+    // chunks of a fold (one chunk for folds of at most SMALL_ROWS rows) and the tile is finished after the last.  (Two folds per pass were
+    // measured for float32 -- the tile kernel is bound by instructions per byte, and a pass pays
+    // barriers, loop control and output offsets once: SLOWER, 16-row folds 0.761 -> 0.831 ms, three
+    // workgroups per CU instead of five.)
+    int pp = 0;
+    for (int ff = 0; ff < nf; ++ff, pp ^= 1) {
+      const int n = n_all[ff];
+      const int nch = n > SMALL_ROWS ? (n + SMALL_ROWS - 1) / SMALL_ROWS : 1;
+      double swt = 0.0;
+      acc_t acc[4];
 #pragma unroll
-      for (int g = 0; g < NF; ++g) {
-        const int ff = ff0 + g;
-        n4[g] = g < ng ? (n_all[ff] + 3) & ~3 : 0;
-        swt[g] = pswt[g];
-        TS *As = sm + g * SLOT, *Bs = As + SMALL_ROWS * SA_PITCH;
+      for (int nn = 0; nn < 4; ++nn) acc[nn] = (acc_t){0, 0, 0, 0};
+      for (int ch = 0; ch < nch; ++ch) {
+        const int left = n - SMALL_ROWS * ch;
+        const int n4 = ((left < SMALL_ROWS ? left : SMALL_ROWS) + 3) & ~3;   // zero rows up to a multiple of 4
+        const int base = (ff << rshift) + SMALL_ROWS * ch;
+        // the chunk's rows (A side weighted) and, with the first chunk, the fold's statistics -> LDS
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
           const int r = sr0 + 4 * j;
-          if (r < n4[g]) {
-            As[r * SA_PITCH + sc] = WEIGHTED ? (T)(wl_all[ff][r] * pa[g][j]) : pa[g][j];
-            Bs[r * SA_PITCH + sc] = pb[g][j];
+          if (r < n4) {
+            As[r * SA_PITCH + sc] = WEIGHTED ? (T)(wl_all[base + r] * pa[j]) : pa[j];
+            Bs[r * SA_PITCH + sc] = pb[j];
           }
         }
-        st_lds[pass & 1][g][tid] = pst[g];
-      }
-      lds_barrier();
-      if (ff0 + NF < nf) request(ff0 + NF);      // in flight during the arithmetic and the stores below
-      // rank-n updates of the 64 x 64 tile on the matrix cores: wave w -> row tile w, 4 column tiles
-      acc_t acc[NF][4];
-#pragma unroll
-      for (int g = 0; g < NF; ++g) {
-        const TS *As = sm + g * SLOT, *Bs = As + SMALL_ROWS * SA_PITCH;
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) acc[g][nn] = (acc_t){0, 0, 0, 0};
-        for (int k0 = 0; k0 < n4[g]; k0 += 4) {
+        if (ch == 0) {
+          st_lds[pp][tid] = pst;
+          swt = pswt;
+        }
+        lds_barrier();
+        {                                        // in flight during the arithmetic and the stores below
+          const int nff = ch + 1 < nch ? ff : ff + 1, nchk = ch + 1 < nch ? ch + 1 : 0;
+          if (nff < nf) request(nff, nchk);
+        }
+        // rank-n update of the 64 x 64 tile on the matrix cores: wave w -> row tile w, 4 column tiles
+        for (int k0 = 0; k0 < n4; k0 += 4) {
           const T af = As[(k0 + lk) * SA_PITCH + 16 * wave + lc];
           T bf[4];
 #pragma unroll
           for (int nn = 0; nn < 4; ++nn) bf[nn] = Bs[(k0 + lk) * SA_PITCH + 16 * nn + lc];
 #pragma unroll
-          for (int nn = 0; nn < 4; ++nn) acc[g][nn] = MF<T>::mfma(af, bf[nn], acc[g][nn]);
+          for (int nn = 0; nn < 4; ++nn) acc[nn] = MF<T>::mfma(af, bf[nn], acc[nn]);
         }
+        lds_barrier();   // every wave is done with As/Bs: the next chunk, or Ts, may overwrite them
       }
-      lds_barrier();     // every wave is done with As/Bs: Ts may overwrite them
 #pragma unroll
-      for (int g = 0; g < NF; ++g) {
-        TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
+      for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Ts[16 * wave + MF<T>::drow(lane, r)][16 * nn + lc] = acc[g][nn][r];
-      }
+        for (int r = 0; r < 4; ++r) Ts[16 * wave + MF<T>::drow(lane, r)][16 * nn + lc] = acc[nn][r];
       lds_barrier();
+      const size_t fo = (size_t)(a.seg0 + f_first + ff) * (size_t)K * K;
       if (fast) {
+        const double *st = st_lds[pp];
+        double muc[VWG], sdc[VWG];
 #pragma unroll
-        for (int g = 0; g < NF; ++g) {
-          if (g >= ng) break;
-          TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
-          const double *st = st_lds[pass & 1][g];
-          double muc[VWG], sdc[VWG];
+        for (int e = 0; e < VWG; ++e) { muc[e] = st[2 * ST + fc + e]; sdc[e] = st[3 * ST + fc + e]; }
+        T *od = (T *)a.out_XTX + fo + off_d0;
 #pragma unroll
-          for (int e = 0; e < VWG; ++e) { muc[e] = st[2 * ST + fc + e]; sdc[e] = st[3 * ST + fc + e]; }
-          T *od = (T *)a.out_XTX + (size_t)(a.seg0 + f_first + ff0 + g) * (size_t)K * K + off_d0;
+        for (int j = 0; j < NQG; ++j) {
+          const int lr = fr0 + FSTEP * j;
+          const double mur = st[lr], sdr = st[ST + lr];
+          vst_t vv;
 #pragma unroll
-          for (int j = 0; j < NQG; ++j) {
-            const int lr = fr0 + FSTEP * j;
-            const double mur = st[lr], sdr = st[ST + lr];
-            vst_t vv;
-#pragma unroll
-            for (int e = 0; e < VWG; ++e) {
-              double v = (double)gpre[j][e] - (double)Ts[lr][fc + e];
-              if (cX) v -= swt[g] * (mur * muc[e]);
-              if (sX) v = v * (sdr * sdc[e]);
-              vv[e] = (T)v;
-            }
-            out_store(reinterpret_cast<vst_t *>(od), vv);
-            od += off_step;
-#pragma unroll
-            for (int e = 0; e < VWG; ++e) Ts[lr][fc + e] = vv[e];       // parked for the mirrored pass
+          for (int e = 0; e < VWG; ++e) {
+            double v = (double)gpre[j][e] - (double)Ts[lr][fc + e];
+            if (cX) v -= swt * (mur * muc[e]);
+            if (sX) v = v * (sdr * sdc[e]);
+            vv[e] = (T)v;
           }
+          out_store(reinterpret_cast<vst_t *>(od), vv);
+          od += off_step;
+#pragma unroll
+          for (int e = 0; e < VWG; ++e) Ts[lr][fc + e] = vv[e];       // parked for the mirrored pass
         }
         lds_barrier();
+        T *om = (T *)a.out_XTX + fo + off_m0;
 #pragma unroll
-        for (int g = 0; g < NF; ++g) {
-          if (g >= ng) break;
-          TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
-          T *om = (T *)a.out_XTX + (size_t)(a.seg0 + f_first + ff0 + g) * (size_t)K * K + off_m0;
+        for (int j = 0; j < NQG; ++j) {
+          const int lr = fr0 + FSTEP * j;
+          vst_t vv;
 #pragma unroll
-          for (int j = 0; j < NQG; ++j) {
-            const int lr = fr0 + FSTEP * j;
-            vst_t vv;
-#pragma unroll
-            for (int e = 0; e < VWG; ++e) vv[e] = Ts[fc + e][lr];          // finished, transposed
-            out_store(reinterpret_cast<vst_t *>(om), vv);
-            om += off_step;
-          }
+          for (int e = 0; e < VWG; ++e) vv[e] = Ts[fc + e][lr];          // finished, transposed
+          out_store(reinterpret_cast<vst_t *>(om), vv);
+          om += off_step;
         }
         lds_barrier();
       } else {
-        for (int g = 0; g < ng; ++g) {
-          TS (*Ts)[ST + 1] = reinterpret_cast<TS (*)[ST + 1]>(sm + g * SLOT);
-          T *out = (T *)a.out_XTX + (size_t)(a.seg0 + f_first + ff0 + g) * (size_t)K * K;
-          finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, out, st_lds[pass & 1][g], swt[g], cX, sX,
-                                         tid, 256, gpre);
-        }
+        finish_store_tile<T, true, TS>(Ts, ti == tj, a0, b0, K, (const T *)a.G, (T *)a.out_XTX + fo, st_lds[pp], swt, cX, sX,
+                                       tid, 256, gpre);
       }
       // (both ways end with a barrier: As / Bs are free for the next pass)
     }
   } else {
+    // XTY panel: 64 rows of XTY x up to 64 responses at a time; output e = tid + 256 i of the panel
+    // accumulates over the chunks of the fold in row order
     TS *As = sm, *Bs = sm + SMALL_ROWS * SA_PITCH;
+    constexpr int NO = ST * ST / 256;
     for (int ff = 0; ff < nf; ++ff) {
       const int f = f_first + ff;
       const int n = n_all[ff];
@@ -354,27 +341,42 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
       const size_t fo = (size_t)(a.seg0 + f);
       const T *Ht = (const T *)a.H;
       T *out = (T *)a.out_XTY + fo * (size_t)K * M;
-      if (ff) lds_barrier();                   // the previous fold is done with As / Bs
-      for (int e = tid; e < n * ST; e += 256) {
-        const int r = e / ST, c = e - r * ST;
-        const T xa = (a0 + c < K) ? X[rows_all[ff][r] * (int64_t)K + a0 + c] : (T)0;
-        As[r * SA_PITCH + c] = WEIGHTED ? (T)(wl_all[ff][r] * xa) : xa;
-      }
       for (int m0 = 0; m0 < M; m0 += ST) {
-        lds_barrier();
-        for (int e = tid; e < n * ST; e += 256) {
-          const int r = e / ST, c = e - r * ST;
-          Bs[r * SA_PITCH + c] = (m0 + c < M) ? Y[rows_all[ff][r] * (int64_t)M + m0 + c] : (T)0;
-        }
-        lds_barrier();
         const int mw = (M - m0 < ST) ? M - m0 : ST;
-        for (int e = tid; e < ST * mw; e += 256) {
+        TS acc[NO];
+#pragma unroll
+        for (int i = 0; i < NO; ++i) acc[i] = 0;
+        for (int c0 = 0; c0 < n; c0 += SMALL_ROWS) {
+          const int nc = n - c0 < SMALL_ROWS ? n - c0 : SMALL_ROWS;
+          const int base = (ff << rshift) + c0;
+          lds_barrier();                         // the previous chunk / panel / fold is done with As / Bs
+          for (int e = tid; e < nc * ST; e += 256) {
+            const int r = e / ST, c = e - r * ST;
+            const int64_t row = rows_all[base + r];
+            const T xa = (a0 + c < K) ? X[row * (int64_t)K + a0 + c] : (T)0;
+            As[r * SA_PITCH + c] = WEIGHTED ? (T)(wl_all[base + r] * xa) : xa;
+            Bs[r * SA_PITCH + c] = (m0 + c < M) ? Y[row * (int64_t)M + m0 + c] : (T)0;
+          }
+          lds_barrier();
+#pragma unroll
+          for (int i = 0; i < NO; ++i) {
+            const int e = tid + 256 * i;
+            if (e < ST * mw) {
+              const int la = e / mw, lm = e - la * mw;
+              TS s_ = acc[i];
+              for (int r = 0; r < nc; ++r) s_ += As[r * SA_PITCH + la] * Bs[r * SA_PITCH + lm];
+              acc[i] = s_;
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NO; ++i) {
+          const int e = tid + 256 * i;
+          if (e >= ST * mw) continue;
           const int la = e / mw, lm = e - la * mw;
           const int ga = a0 + la, gm = m0 + lm;
           if (ga >= K) continue;
-          TS acc = 0;
-          for (int r = 0; r < n; ++r) acc += As[r * SA_PITCH + la] * Bs[r * SA_PITCH + lm];
-          double v = (double)Ht[(size_t)ga * M + gm] - (double)acc;
+          double v = (double)Ht[(size_t)ga * M + gm] - (double)acc[i];
           if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + gm]);
           if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + gm]);
           else if (sX) v = v * fs[K + ga];

@@ -56,7 +56,8 @@ def main():
                     assert bool((bx[f] == bx[f].T).all())
     # mid-size folds (the fused single-split epilogue, or the two-stage route under CVM_NO_FUSED) and
     # folds of a few rows (tile kernel / whole-rows kernel, CVM_NO_DIRECT): tools/route_matrix.sh's switches
-    for (N, K, M, nv, seed) in ((6000, 132, 2, 150, 5), (3000, 70, 3, 8, 6), (2400, 70, 0, 1, 7), (4000, 260, 2, 25, 8)):
+    for (N, K, M, nv, seed) in ((6000, 132, 2, 150, 5), (3000, 70, 3, 8, 6), (2400, 70, 0, 1, 7), (4000, 260, 2, 25, 8),
+                              (4500, 200, 3, 90, 9)):      # (90 rows: the direct kernels in three chunks under CVM_SMALL_MAXN)
         rng = np.random.default_rng(seed)
         X = rng.random((N, K)) + 0.1
         Y = rng.random((N, M)) if M else None

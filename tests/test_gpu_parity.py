@@ -1487,7 +1487,8 @@ def test_forced_split_plans(plan):
 
 
 @pytest.mark.parametrize("switch", ["CVM_NO_FUSED=1", "CVM_FORCE_FALLBACK=1", "CVM_NO_SWEEP_MERGE=1", "CVM_NO_DIRECT=1",
-                                    "CVM_NO_COMPACT=1", "CVM_NO_INLINE_STATS=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0"])
+                                    "CVM_NO_COMPACT=1", "CVM_NO_INLINE_STATS=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0",
+                                    "CVM_SMALL_MAXN=128"])
 def test_route_forcing_switches(switch):
     """One pass of tools/route_matrix.sh inside the suite: every route-forcing switch of the library
     (read once per process, hence a subprocess each) over tests/forced_plan_check.py -- two-stage
@@ -1516,8 +1517,9 @@ def test_wide_matrices_k8192_k16384():
     assert r.stdout.count("XTX err") == 4, r.stdout
 
 
-@pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["300", "101"]), ("fuzz_small.py", ["500", "102"])])
-def test_randomised_routes_against_the_oracle(tool, args):
+@pytest.mark.parametrize("tool,args,env", [("fuzz_all.py", ["300", "101"], {}), ("fuzz_small.py", ["500", "102"], {}),
+                                           ("fuzz_small.py", ["250", "103"], {"CVM_SMALL_MAXN": "128"})])
+def test_randomised_routes_against_the_oracle(tool, args, env):
     """tools/fuzz_all.py / fuzz_small.py: random shapes, fold structures, element types, flags,
     weights, ddof, lazy or eager fit and call styles through every route of the fold stage,
     against the oracle (float64 1e-10; float32 twice the oracle's own float32 error + 2e-5)."""
@@ -1525,7 +1527,7 @@ def test_randomised_routes_against_the_oracle(tool, args):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), *args], capture_output=True, text=True,
-                       timeout=900)
+                       timeout=900, env=dict(os.environ, **env))
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
