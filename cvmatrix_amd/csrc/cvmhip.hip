@@ -143,6 +143,15 @@ int cvm_debug_pls_stamps(unsigned long long *host_out, int reset) {
   }
   return CVM_OK;
 }
+int cvm_debug_sse_stamps(unsigned long long *host_out, int reset) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sse_stamps), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_sse_stamps), z, sizeof(z)));
+  }
+  return CVM_OK;
+}
 int cvm_debug_stamps4(unsigned long long *host_out) {
   HIP_OK(hipDeviceSynchronize());
   HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps4), sizeof(unsigned long long) * 1024 * 8));

@@ -1202,38 +1202,63 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
 // tiles; the squared errors are summed over the rows in a fixed order (registers -> lanes ->
 // waves -> a second small kernel over the row chunks: no float atomics).
 // ----------------------------------------------------------------------------------
-constexpr int SSE_ROWS = 64, SSE_COLS = 64, SSE_KS = 16, SSE_ZP = 80, SSE_BP = 80;   // pitches: conflict-free MFMA operand reads
+constexpr int SSE_ROWS = 64, SSE_KS = 16, SSE_ZP = 80, SSE_MAXNT = 6;   // (Z pitch 80: conflict-free MFMA operand reads)
+#ifdef CVM_STAMPS
+__device__ unsigned long long g_sse_stamps[8];
+#define SSE_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); g_sse_stamps[i] += now_ - sstamp_; sstamp_ = now_; } } while (0)
+#else
+#define SSE_STAMP(i)
+#endif
 struct SseArgs {
   const void *X, *Y, *w, *muX, *sdX, *muY, *sdY, *B;
   const int64_t *idx, *offs;
   int K, M, A, n_chunks;        // n_chunks: row chunks of the longest fold
+  int st_in_lds;                // the fold's K means and reciprocal standard deviations fit in LDS next to the stages
   double *part;                 // [F][n_chunks][A M] partial sums, [F][n_chunks] weight sums behind them
   double *sse, *wsum;
   int64_t F;
 };
 
-template <typename T>
+// Workgroup = 64 validation rows x W = 64 NT of the A M columns (a, m); wave w owns the 16 NT columns
+// from 16 NT w on, for all 64 rows: 4 x NT MFMA tiles, 4 A and NT B fragment reads per 4 NT MFMAs.
+// One workgroup per CU (the two LDS stages of B take most of it), one wave per SIMD: the matrix
+// pipe of a SIMD is never shared with another wave's vector arithmetic (a VALU instruction behind a
+// stream of float64 MFMAs of ANOTHER wave waits hundreds of cycles, tools/dma_vs_mfma.hip -- the
+// round-3 kernel, 64 x 64 tiles at several workgroups per CU, stood at 24 TFLOP/s), the next
+// stage's rows and coefficients are requested before the stage's MFMAs and written to the other
+// LDS buffer after them, one barrier per 16 k.  Rows are standardised on the way to LDS with the
+// reciprocal standard deviation (v_rcp + one Newton step: within 1 ulp of the division).
+// V: elements per global load (16 bytes' worth when K and M are multiples of that and the arrays are
+// aligned, else 1).  A vector-memory instruction costs the issuing wave hundreds of cycles on a busy CU
+// (tools/dma_issue.hip) and these waves also feed the matrix cores: 32 eight-byte loads per thread and
+// stage held the kernel at 25 TFLOP/s; with 16-byte loads and the statistics in LDS a stage takes 12.
+template <typename T, int NT, int V>
 __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
+  constexpr int W = 64 * NT, BP = W + 16;                     // LDS pitch of B: conflict-free fragment reads
+#ifdef CVM_STAMPS
+  unsigned long long sstamp_ = __builtin_readcyclecounter();
+#endif
   const int K = a.K, M = a.M, C = a.A * M;
-  const int chunk = blockIdx.x, cb = blockIdx.y, f = blockIdx.z;
+  const int chunk = blockIdx.x, cg = blockIdx.y, f = blockIdx.z;
   const int64_t o0 = a.offs[f];
   const int n = (int)(a.offs[f + 1] - o0);
   const int r0 = chunk * SSE_ROWS;
   double *part = a.part + ((size_t)f * a.n_chunks + chunk) * C;
   double *wpart = a.part + (size_t)a.F * a.n_chunks * C + (size_t)f * a.n_chunks + chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lk = lane >> 4, lc = lane & 15;
-  const int c0 = cb * SSE_COLS;
+  const int c0 = cg * W;
+  const int Cg = C - c0 < W ? C - c0 : W;                     // columns of this group
   if (r0 >= n) {                                              // past this fold's rows: zeros
-    for (int c = tid; c < SSE_COLS; c += 256) if (c0 + c < C) part[c0 + c] = 0.0;
-    if (cb == 0 && tid == 0) *wpart = 0.0;
+    for (int c = tid; c < Cg; c += 256) part[c0 + c] = 0.0;
+    if (cg == 0 && tid == 0) *wpart = 0.0;
     return;
   }
-  __shared__ T Zs[SSE_KS][SSE_ZP];                            // [k][row]: the A operand's lanes run over rows
-  __shared__ T Bs[SSE_KS][SSE_BP];                            // [k][column]
+  extern __shared__ __attribute__((aligned(16))) unsigned char sse_smem[];
+  T *Zs = reinterpret_cast<T *>(sse_smem);                    // [2][KS][ZP], [k][row]: the A operand's lanes run over rows
+  T *Bs = Zs + 2 * SSE_KS * SSE_ZP;                           // [2][KS][BP], [k][column]
   __shared__ int64_t rows[SSE_ROWS];
   __shared__ double wl[SSE_ROWS];
-  __shared__ double red[4][SSE_COLS];
-  const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;
+  const T *X = (const T *)a.X, *Y = (const T *)a.Y, *Wt = (const T *)a.w;
   const T *muX = a.muX ? (const T *)a.muX + (size_t)f * K : nullptr;
   const T *sdX = a.sdX ? (const T *)a.sdX + (size_t)f * K : nullptr;
   const T *Bf = (const T *)a.B + (size_t)f * a.A * K * M;
@@ -1241,81 +1266,211 @@ __global__ __launch_bounds__(256) void pls_sse_kernel(const SseArgs a) {
     const bool ok = r0 + tid < n;
     const int64_t r = ok ? a.idx[o0 + r0 + tid] : 0;
     rows[tid] = r;
-    wl[tid] = ok ? (W ? (double)W[r] : 1.0) : 0.0;
+    wl[tid] = ok ? (Wt ? (double)Wt[r] : 1.0) : 0.0;
   }
   __syncthreads();
   typedef typename MF<T>::acc_t acc_t;
-  acc_t acc[4];
+  acc_t acc[4][NT];
 #pragma unroll
-  for (int nn = 0; nn < 4; ++nn) acc[nn] = (acc_t){0, 0, 0, 0};
-  // staging maps.  Z: thread -> (row zr = tid / 4, k quad zq = tid % 4): four CONSECUTIVE k of one row, so
-  // that a wave instruction touches 16 rows' lines once (a thread per (row, single k) touched 64 lines
-  // per instruction, 16 times what the stage needs: the kernel was bound by the memory pipe's ~3.5
-  // cycles per line touched, 22 TFLOP/s).  B: element (k bk + 4 j, column bc): a wave instruction =
-  // four 128-byte runs of M responses.
-  constexpr int NEL = SSE_KS / 4;
-  static_assert(NEL == 4, "the Z staging map takes four k per thread");
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[rt][t] = (acc_t){0, 0, 0, 0};
+  // staging maps.  Z: thread -> (row zr = tid / 4, k quad zq = tid % 4): four CONSECUTIVE k of one
+  // row (a wave instruction touches 16 rows' lines once), 4 / V loads.  B: piece e = tid + 256 i of
+  // the stage's 16 x (W / V) pieces of V columns: k = e / (W / V), columns (e % (W / V)) V ...
+  // All loads are branch-free -- rows past the fold's end re-read row 0, k past K re-reads the
+  // last piece, columns past the group's end re-read column 0, and the values are zeroed in
+  // `store`: a per-thread branch around a load makes the compiler wait for everything in flight.
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  constexpr int ZL = 4 / V < 1 ? 1 : 4 / V;                   // Z loads per thread and stage
+  constexpr int ZV = 4 / ZL;                                  // elements per Z load (V, or 4 when V > 4 never happens)
+  static_assert(V == 1 || V == 2 || V == 4, "V is 1 or 16 bytes' worth");
+  constexpr int WP = W / V;                                   // pieces per k row
+  constexpr int NB = SSE_KS * WP / 256;                       // B loads per thread and stage
   const int zr = tid >> 2, zq = tid & 3;
-  const int bc = tid & 63, bk = tid >> 6;
-  const int gcol = c0 + bc;
-  const int ba = gcol < C ? gcol / M : 0, bm = gcol < C ? gcol - ba * M : 0;
   const bool zok = r0 + zr < n;
   const T *xrow = X + rows[zr] * (int64_t)K;
-  for (int k0 = 0; k0 < K; k0 += SSE_KS) {
-    T zv[NEL], bv[NEL];
-#pragma unroll
-    for (int j = 0; j < NEL; ++j) {
-      const int k = k0 + 4 * zq + j;
-      T z = (T)0;
-      if (zok && k < K) {
-        z = xrow[k];
-        if (muX) z = z - muX[k];
-        if (sdX) z = z / sdX[k];
-      }
-      zv[j] = z;
-      const int kb = k0 + bk + 4 * j;
-      bv[j] = (gcol < C && kb < K) ? Bf[((size_t)ba * K + kb) * M + bm] : (T)0;
-    }
-    __syncthreads();                                          // the previous stage's fragments have been read
-#pragma unroll
-    for (int j = 0; j < NEL; ++j) { Zs[4 * zq + j][zr] = zv[j]; Bs[bk + 4 * j][bc] = bv[j]; }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < SSE_KS; ks += 4) {
-      const T af = Zs[ks + lk][16 * wave + lc];
-#pragma unroll
-      for (int nn = 0; nn < 4; ++nn) acc[nn] = MF<T>::mfma(af, Bs[ks + lk][16 * nn + lc], acc[nn]);
+  const bool has_mu = muX != nullptr, has_sd = sdX != nullptr;
+  // statistics: (mean, 1 / sd) of all K columns in LDS when they fit, else read per stage
+  double *stl = reinterpret_cast<double *>(Bs + 2 * SSE_KS * BP);
+  const bool st_lds = a.st_in_lds != 0;
+  if (st_lds) {
+    for (int k = tid; k < K; k += 256) {
+      stl[2 * k] = has_mu ? (double)muX[k] : 0.0;
+      stl[2 * k + 1] = has_sd ? 1.0 / (double)sdX[k] : 1.0;
     }
   }
-  // squared errors: register r of tile nn is (row 16 wave + drow(lane, r), column 16 nn + lc)
+  const T *mup = has_mu ? muX : xrow, *sdp = has_sd ? sdX : xrow;   // (absent statistics: a harmless second read of the row)
+  size_t boff[NB];
+  int blds[NB];
+  bool bok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int e = tid + 256 * i;
+    const int kk = e / WP, col = (e - kk * WP) * V;
+    bok[i] = c0 + col < C;                                    // (C is a multiple of V in the vector build)
+    const int gcol = bok[i] ? c0 + col : 0;
+    const int ba = gcol / M, bm = gcol - ba * M;
+    boff[i] = ((size_t)ba * K + kk) * M + bm;
+    blds[i] = kk * BP + col;
+  }
+  vec_t zv[ZL], zm[ZL], zs[ZL], bv[NB];
+  auto loadZ = [&](int j, int k0) {
+    const int k = k0 + 4 * zq + ZV * j;
+    const int kc = k < K ? k : K - ZV;
+    zv[j] = *reinterpret_cast<const vec_t *>(xrow + kc);
+    if (!st_lds) {
+      zm[j] = *reinterpret_cast<const vec_t *>(mup + kc);
+      zs[j] = *reinterpret_cast<const vec_t *>(sdp + kc);
+    }
+  };
+  auto loadB = [&](int i, int k0) {
+    // (k0 + kk < K except in the last stage: there the row K - 1 is re-read and zeroed in storeB)
+    const int kk = (tid + 256 * i) / WP;
+    const size_t ko = (size_t)(k0 + kk < K ? k0 : K - 1 - kk) * M;
+    bv[i] = *reinterpret_cast<const vec_t *>(Bf + boff[i] + ko);
+  };
+  auto storeZ = [&](int j, int k0, int buf) {
+    T *Zb = Zs + buf * SSE_KS * SSE_ZP;
+#pragma unroll
+    for (int e = 0; e < ZV; ++e) {
+      const int kq = 4 * zq + ZV * j + e, k = k0 + kq;
+      double mu, isd;
+      if (st_lds) {
+        const int kc = k < K ? k : K - 1;
+        mu = stl[2 * kc]; isd = stl[2 * kc + 1];
+      } else {
+        mu = has_mu ? (double)zm[j][e] : 0.0;
+        const double sd = has_sd ? (double)zs[j][e] : 1.0;
+        isd = __builtin_amdgcn_rcp(sd);
+        isd = fma(fma(-sd, isd, 1.0), isd, isd);
+      }
+      const T z = (T)(((double)zv[j][e] - mu) * isd);
+      Zb[kq * SSE_ZP + zr] = (zok && k < K) ? z : (T)0;
+    }
+  };
+  auto storeB = [&](int i, int k0, int buf) {
+    T *Bb = Bs + buf * SSE_KS * BP;
+    const int kk = (tid + 256 * i) / WP;
+    const bool ok = bok[i] && k0 + kk < K;
+    vec_t v = bv[i];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = ok ? v[e] : (T)0;
+    *reinterpret_cast<vec_t *>(Bb + blds[i]) = v;
+  };
+  // The next stage's requests and LDS writes are dealt out over the stage's 4 NT groups of four MFMAs
+  // ("steps"), one or two per step and pinned there: a vector-memory instruction takes its wave
+  // 150-450 cycles to issue on a busy CU and the matrix pipe runs dry behind a clump of them
+  // (tools/sse_stamps.py: 12 loads 2.0 k, arithmetic and LDS writes 1.9 k cycles per stage next to
+  // 6.8 k of MFMAs, one after the other).  Requests in the first half of the steps (rows first),
+  // writes in the second half (coefficients first, rows -- the longest latency -- last).
+  constexpr int STEPS = 4 * NT, NL = ZL + NB, NLS = (STEPS + 1) / 2, LPS = (NL + NLS - 1) / NLS;
+  constexpr int NSS = STEPS - NLS, SPS = (NL + NSS - 1) / NSS;
+  auto aux = [&](int step, int k1, int buf) {
+    if (step < NLS) {
+#pragma unroll
+      for (int q = 0; q < LPS; ++q) {
+        const int idx = step * LPS + q;
+        if (idx < ZL) loadZ(idx, k1);
+        else if (idx < NL) loadB(idx - ZL, k1);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < SPS; ++q) {
+        const int idx = (step - NLS) * SPS + q;
+        if (idx < NB) storeB(idx, k1, buf);
+        else if (idx < NL) storeZ(idx - NB, k1, buf);
+      }
+    }
+  };
+  const int nst = (K + SSE_KS - 1) / SSE_KS;
+#pragma unroll
+  for (int j = 0; j < ZL; ++j) loadZ(j, 0);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) loadB(i, 0);
+  if (st_lds) __syncthreads();                                // (stl)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) storeB(i, 0, 0);
+#pragma unroll
+  for (int j = 0; j < ZL; ++j) storeZ(j, 0, 0);
+  __syncthreads();
+  SSE_STAMP(0);
+  // (narrow groups, NT < 3: several workgroups share a CU and hide each other's latencies; the
+  //  requests go first, the writes last, unpinned -- C = 20 at K = 4096 in float32: 0.95 ms against
+  //  1.6 ms with the pinned interleave)
+  constexpr bool PIN = NT >= 3;
+  for (int s = 0; s < nst; ++s) {
+    const bool more = s + 1 < nst;
+    const int k1 = (s + 1) * SSE_KS, nbuf = (s + 1) & 1;      // (that buffer was last read before the previous barrier)
+    const T *Zb = Zs + (s & 1) * SSE_KS * SSE_ZP, *Bb = Bs + (s & 1) * SSE_KS * BP;
+    if (!PIN && more) {
+#pragma unroll
+      for (int j = 0; j < ZL; ++j) loadZ(j, k1);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) loadB(i, k1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < SSE_KS; ks += 4) {
+      T af[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) af[rt] = Zb[(ks + lk) * SSE_ZP + 16 * rt + lc];
+      // (tiles past the group's last column multiply zeros: the four waves run side by side on
+      //  their SIMDs, skipping a tile in one of them would not shorten the stage)
+      T bf[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bf[t] = Bb[(ks + lk) * BP + 16 * (wave * NT + t) + lc];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt][t] = MF<T>::mfma(af[rt], bf[t], acc[rt][t]);
+        if (PIN) {
+          if (more) aux((ks / 4) * NT + t, k1, nbuf);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (!PIN && more) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) storeB(i, k1, nbuf);
+#pragma unroll
+      for (int j = 0; j < ZL; ++j) storeZ(j, k1, nbuf);
+    }
+    SSE_STAMP(2);
+    __syncthreads();
+    SSE_STAMP(4);
+  }
+  // squared errors: register r of tile (rt, t) is (row 16 rt + drow(lane, r), column 16 (wave NT + t) + lc);
+  // summed over registers, row tiles, then the four lane groups -- a fixed order
   const T *muY = a.muY ? (const T *)a.muY + (size_t)f * M : nullptr;
   const T *sdY = a.sdY ? (const T *)a.sdY + (size_t)f * M : nullptr;
 #pragma unroll
-  for (int nn = 0; nn < 4; ++nn) {
-    const int col = c0 + 16 * nn + lc;
-    const int m = col < C ? col % M : 0;
+  for (int t = 0; t < NT; ++t) {
+    const int lcol = 16 * (wave * NT + t) + lc;
+    const bool valid = lcol < Cg;
+    const int col = c0 + lcol;
+    const int m = valid ? col % M : 0;
     const double sy = sdY ? (double)sdY[m] : 1.0, my = muY ? (double)muY[m] : 0.0;
-    double s = 0.0;
+    double sacc = 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lr = 16 * wave + MF<T>::drow(lane, r);
-      if (col < C && r0 + lr < n) {
-        const double e = (double)acc[nn][r] * sy + my - (double)Y[rows[lr] * (int64_t)M + m];
-        s += wl[lr] * (e * e);
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = 16 * rt + MF<T>::drow(lane, r);
+        if (valid && r0 + lr < n) {
+          const double e = (double)acc[rt][t][r] * sy + my - (double)Y[rows[lr] * (int64_t)M + m];
+          sacc += wl[lr] * (e * e);
+        }
       }
-    }
-    // over the four lane groups of the wave (rows), in order
-    const double s1 = __shfl(s, lc + 16), s2 = __shfl(s, lc + 32), s3 = __shfl(s, lc + 48);
-    const double sw = ((__shfl(s, lc) + s1) + s2) + s3;
-    if (lk == 0) red[wave][16 * nn + lc] = sw;
+    const double s1 = __shfl(sacc, lc + 16), s2 = __shfl(sacc, lc + 32), s3 = __shfl(sacc, lc + 48);
+    const double sw = ((__shfl(sacc, lc) + s1) + s2) + s3;
+    if (lk == 0 && valid) part[col] = sw;
   }
-  __syncthreads();
-  if (tid < SSE_COLS && c0 + tid < C) part[c0 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-  if (cb == 0 && tid == 0) {
+  if (cg == 0 && tid == 0) {
     double t = 0.0;
     for (int i = 0; i < SSE_ROWS; ++i) t += wl[i];
     *wpart = t;
   }
+  SSE_STAMP(5);
 }
 
 // sums over a fold's row chunks, in chunk order
@@ -1362,8 +1517,35 @@ int pls_sse_impl(const void *X, const void *Y, const void *w, const int64_t *idx
   a.sse = sse; a.wsum = wsum;
   const int C = A * M;
   if (F > 65535) return fail(CVM_EINVAL, "cvm_pls_validation_sse: at most 65535 folds per call%s");
-  hipLaunchKernelGGL((pls_sse_kernel<T>), dim3((unsigned)chunks, (unsigned)((C + SSE_COLS - 1) / SSE_COLS), (unsigned)F),
-                     dim3(256), 0, st, a);
+  // 16 NT columns per wave: as few column groups as possible (every group stages the rows again),
+  // then as little padding as possible
+  int nt = 1, best = 1 << 30;
+  for (int c = 1; c <= SSE_MAXNT; ++c) {
+    const int groups = (C + 64 * c - 1) / (64 * c);
+    const int cost = groups * (4 * c + 1);
+    if (cost < best) { best = cost; nt = c; }
+  }
+  const unsigned groups = (unsigned)((C + 64 * nt - 1) / (64 * nt));
+  size_t lds = (size_t)2 * SSE_KS * (SSE_ZP + 64 * nt + 16) * sizeof(T);
+  // (statistics in LDS only where they do not cost residency: one workgroup per CU anyway, or a short K)
+  a.st_in_lds = (lds + (size_t)K * 16 + 2048 <= PLS_LDS_BUDGET && (lds > 80 * 1024 || K <= 512)) ? 1 : 0;
+  if (a.st_in_lds) lds += (size_t)K * 16;
+  constexpr int VW = 16 / (int)sizeof(T);
+  const bool vec = K % VW == 0 && M % VW == 0 && K >= 4 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
+                   (!muX || (uintptr_t)muX % 16 == 0) && (!sdX || (uintptr_t)sdX % 16 == 0);
+  void (*kern)(const SseArgs) = nullptr;
+#define CVM_SSE_PICK(N) kern = vec ? pls_sse_kernel<T, N, VW> : pls_sse_kernel<T, N, 1>
+  switch (nt) {
+    case 1: CVM_SSE_PICK(1); break;
+    case 2: CVM_SSE_PICK(2); break;
+    case 3: CVM_SSE_PICK(3); break;
+    case 4: CVM_SSE_PICK(4); break;
+    case 5: CVM_SSE_PICK(5); break;
+    default: CVM_SSE_PICK(6); break;
+  }
+#undef CVM_SSE_PICK
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)chunks, groups, (unsigned)F), dim3(256), lds, st, a);
   const int64_t ne = F * C > F ? F * C : F;
   hipLaunchKernelGGL(pls_sse_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a);
   HIP_OK(hipGetLastError());
