@@ -265,6 +265,9 @@ def test_four_barrier_kernel_still_agrees(pls):
     (np.float64, 1500, 36, 16, 3, 20, True, (False, False, False, False)),
     (np.float32, 4000, 128, 3, 8, 6, True, (True, True, True, True)),
     (np.float64, 2000, 96, 40, 4, 6, True, (True, True, True, True)),      # 32 < M <= 64
+    (np.float64, 1200, 48, 40, 3, 12, True, (True, True, True, True)),     # 480 columns: two column groups
+    (np.float32, 1500, 64, 8, 4, 30, False, (True, True, True, True)),     # float32, 16-byte loads, 240 columns
+    (np.float64, 900, 35, 3, 3, 4, True, (True, False, True, False)),      # odd K, odd M: the scalar loads
 ])
 def test_validation_sse_on_the_device(pls, dtype, N, K, M, P, A, weighted, flags):
     """cvm_pls_validation_sse: the squared validation errors of every fold's models (every number of
@@ -280,8 +283,14 @@ def test_validation_sse_on_the_device(pls, dtype, N, K, M, P, A, weighted, flags
     w = (rng.random(N) + 0.1).astype(dtype) if weighted else None
     labels = rng.integers(0, P, N)
     p = amd.Partitioner(labels)
-    cvm = amd.CVMatrix(*flags, dtype=dtype)
-    cvm.fit(X, Y, w)
+    if K % 2 or M % 2:
+        # odd shapes are padded in a private copy (and refused here); on the caller's own device
+        # arrays they stay as they are: the kernel's scalar loads
+        cvm = amd.CVMatrix(*flags, dtype=dtype, copy=False)
+        cvm.fit(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), None if w is None else torch.from_numpy(w).cuda())
+    else:
+        cvm = amd.CVMatrix(*flags, dtype=dtype)
+        cvm.fit(X, Y, w)
     batch = cvm.prepare_folds(p)
     (XTX, XTY), stats = cvm.training_XTX_XTY_batched(batch)
     B = pls_fit_batched(XTX, XTY, A).B

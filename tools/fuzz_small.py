@@ -16,7 +16,7 @@ for c in range(cases):
     K = int(rng.choice([3, 17, 64, 100, 130, 200, 256, 300, 500, 512, 640, 1000]))
     if rng.random() < 0.3:
         K += int(rng.integers(1, 4))
-    M = int(rng.choice([0, 1, 3, 10, 40]))
+    M = int(rng.choice([0, 1, 3, 10, 40, 70]))      # (70: two 64-response panels of XTY in the tile kernel)
     nmax = int(rng.choice([1, 2, 3, 8, 16, 32, 33, 50, 100, 128]))      # (beyond 32: several chunks, where the limit of the shape -- or CVM_SMALL_MAXN -- sends them there)
     P = int(rng.choice([1, 2, 9, 40, 300] if nmax <= 32 else [1, 2, 9, 40]))
     N = max(P * nmax + 7, 60)
