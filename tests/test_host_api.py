@@ -280,3 +280,38 @@ def test_emulated_rank_is_importable_without_a_gpu():
 
     r = EmulatedRank(emu_world=8, emu_rank=3, lazy_fit=True)
     assert r.world == 8 and r.rank == 3 and r._exchanges_globals() and r.lazy_fit
+
+
+def test_periodic_labels_take_the_formula_and_build_the_same_dict():
+    """Partitioner._init_periodic (arange(N) % P, arange(N)): the same keys, order, dtypes and index
+    arrays as the sorting path, for periodic, nearly periodic and aperiodic labels."""
+    import cvmatrix_amd.partitioner as pm
+    from cvmatrix_amd import Partitioner
+
+    def general(arr):
+        orig = pm.Partitioner._init_periodic
+        pm.Partitioner._init_periodic = lambda self, a: False
+        try:
+            return Partitioner(arr)
+        finally:
+            pm.Partitioner._init_periodic = orig
+
+    rng = np.random.default_rng(0)
+    cases = [np.arange(1000) % 10, np.arange(1003) % 7, np.arange(50), np.zeros(9, dtype=np.int64), np.array([5]),
+             (np.arange(40) % 4) * 3 + 2, np.r_[np.arange(30) % 5, 7], rng.integers(0, 4, 200),
+             np.array([3, 1, 2, 3, 1, 2, 3, 1]), np.arange(20)[::-1].copy(), np.arange(64) % 2 == 0,
+             np.arange(12, dtype=np.int8) % 3, np.array([0, 1, 0, 1, 1, 0]), np.arange(9000) % 4500]
+    took = 0
+    for a in cases:
+        p, q = Partitioner(a), general(a)
+        took += bool(pm.Partitioner._init_periodic(Partitioner.__new__(Partitioner), a)) if a.size else 0
+        assert list(p.folds_dict.keys()) == list(q.folds_dict.keys())
+        for k in p.folds_dict:
+            x, y = p.folds_dict[k], q.folds_dict[k]
+            assert x.dtype == y.dtype and np.array_equal(x, y)
+        for i, k in enumerate(p.folds_dict):
+            if i < 3:
+                assert pm.partitioner_pos(p.folds_dict[k]) == (p, i)
+        with pytest.raises(ValueError, match="Fold nope not found."):
+            p.get_validation_indices("nope")
+    assert took >= 8          # the periodic ones did take the formula
