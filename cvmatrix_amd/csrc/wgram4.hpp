@@ -694,14 +694,90 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
 
 // ----------------------------------------------------------------------------------
 // Compute waves of a DIAGONAL tile (panel x same panel, first Y chunk), balanced: the upper
-// triangle of the tile's 8x8 grid of 16x16 MFMA tiles has 36 tiles; wave W takes grid rows W
-// and 7-W (8-W and W+1 tiles: 9 for every wave) plus the XTY tiles of those two row-tiles, so
-// all four waves issue 9 + 2*NBY MFMAs per k-step (11 with M <= 16) instead of 16 -- and share
-// the column sums (two row-tiles each).  Its operands: the raw fragments of column tiles
-// W..7 (the B side), of which those of rows W and 7-W, weighted, are the A side.
-// Nothing below the diagonal tiles is computed: the finalize kernels mirror the upper ones.
+// triangle of the tile's 8x8 grid of 16x16 MFMA tiles has 36 tiles, 9 + 2 NBY MFMAs per k-step
+// and wave with the XTY tiles (11 with M <= 16) instead of 16, nothing below the diagonal tiles
+// (the finalize kernels mirror the upper ones).  Who does what is a table (DiagTab):
+//   * "rows W and 7-W" (rounds 1-2; kept for two Y tiles, M > 16): wave W takes grid rows W and
+//     7-W (8-W and W+1 tiles), the XTY tiles and the column sums of those two row-tiles; it holds
+//     the raw fragments of column tiles W..7 -- 8, 7, 6, 5 of them, the busiest wave reads 10
+//     fragments per k-step for its 11 MFMAs;
+//   * "two triangles, two strips" (round 3, one Y tile): waves 0 and 3 take the upper triangles of
+//     the grid's 4x4 corner blocks (10 tiles, fragments of 4 column tiles), waves 1 and 2 the rows
+//     0-1 and 2-3 of the off-diagonal 4x4 block (8 tiles, fragments of 6 column tiles); the XTY
+//     tiles go where they even the MFMAs out (1 + 3 + 3 + 1: a wave that holds x_t forms w x_t
+//     with one multiply) -- 11 MFMAs each as before, 6 / 8 / 8 / 6 fragment reads.  The same
+//     MFMA sequence per accumulator whoever runs it: the same bits.  (Measured: no faster than
+//     the first, DESIGN.md section 7 -- the fragment reads are not what a diagonal stage waits for.)
 //   YSTAT: this wave also sums the Y columns, sw and nz (wave 3 of panel 0)
 // ----------------------------------------------------------------------------------
+struct DiagTab {
+  int nf, na, ng, nx;
+  int ft[8];            // column tiles whose raw fragments the wave holds (the B side)
+  int at[4];            // the weighted (A side) fragments it forms: indices into ft
+  int ga[10], gb[10];   // G tiles: A index (into at), B index (into ft)
+  int xa[3];            // XTY row tiles: A index
+  int ca[2];            // column sums of two tiles: A index
+  int rd[8];            // the order the fragments of the next k-step are read in: A sides first
+};
+constexpr DiagTab diag_tab_fill(int W, bool strips) {
+  DiagTab t{};
+  if (!strips) {
+    const int R1 = 7 - W;
+    t.nf = 8 - W;
+    for (int j = 0; j < t.nf; ++j) t.ft[j] = W + j;
+    t.na = 2; t.at[0] = 0; t.at[1] = R1 - W;
+    t.ng = 9;
+    for (int j = 0; j < t.nf; ++j) { t.ga[j] = 0; t.gb[j] = j; }
+    for (int j = 0; j < W + 1; ++j) { t.ga[t.nf + j] = 1; t.gb[t.nf + j] = R1 - W + j; }
+    t.nx = 2; t.xa[0] = 0; t.xa[1] = 1;
+    t.ca[0] = 0; t.ca[1] = 1;
+    return t;
+  }
+  if (W == 0 || W == 3) {                 // a 4x4 corner block's upper triangle
+    const int b = W == 0 ? 0 : 4;
+    t.nf = 4; t.na = 4;
+    for (int j = 0; j < 4; ++j) { t.ft[j] = b + j; t.at[j] = j; }
+    t.ng = 0;
+    for (int i = 0; i < 4; ++i)
+      for (int j = i; j < 4; ++j) { t.ga[t.ng] = i; t.gb[t.ng] = j; ++t.ng; }
+    t.nx = 1; t.xa[0] = W == 0 ? 0 : 3;   // XTY of tile 0 / tile 7
+    t.ca[0] = W == 0 ? 0 : 2; t.ca[1] = W == 0 ? 1 : 3;   // column sums of tiles 0, 1 / 6, 7
+    return t;
+  }
+  // W == 1: rows 0, 1 x columns 4..7; W == 2: rows 2, 3 x columns 4..7
+  const int r = W == 1 ? 0 : 2;
+  t.nf = 6;
+  t.ft[0] = r; t.ft[1] = r + 1;
+  for (int j = 0; j < 4; ++j) t.ft[2 + j] = 4 + j;
+  t.ng = 0;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j) { t.ga[t.ng] = i; t.gb[t.ng] = 2 + j; ++t.ng; }
+  if (W == 1) {                           // w x of tiles 0, 1, 4, 5; XTY 1, 4, 5; column sums 4, 5
+    t.na = 4; t.at[0] = 0; t.at[1] = 1; t.at[2] = 2; t.at[3] = 3;
+    t.nx = 3; t.xa[0] = 1; t.xa[1] = 2; t.xa[2] = 3;
+    t.ca[0] = 2; t.ca[1] = 3;
+  } else {                                // w x of tiles 2, 3, 6; XTY 2, 3, 6; column sums 2, 3
+    t.na = 3; t.at[0] = 0; t.at[1] = 1; t.at[2] = 4;
+    t.nx = 3; t.xa[0] = 0; t.xa[1] = 1; t.xa[2] = 2;
+    t.ca[0] = 0; t.ca[1] = 1;
+  }
+  return t;
+}
+constexpr DiagTab diag_tab(int W, bool strips) {
+  DiagTab t = diag_tab_fill(W, strips);
+  int n = 0;
+  for (int q = 0; q < t.na; ++q) t.rd[n++] = t.at[q];
+  for (int j = 0; j < t.nf; ++j) {
+    bool is_a = false;
+    for (int q = 0; q < t.na; ++q) is_a = is_a || t.at[q] == j;
+    if (!is_a) t.rd[n++] = j;
+  }
+  return t;
+}
+#ifndef CVM_DIAG_STRIPS
+#define CVM_DIAG_STRIPS 1
+#endif
+
 template <typename T, bool WEIGHTED, bool GATHER, int W, int NBY, bool YSTAT, bool FUSEDR = false>
 __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int xcd_q, int slot_q) {
   typedef typename MF<T>::acc_t acc_t;
@@ -722,14 +798,13 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   r0 = uni64(r0); r1 = uni64(r1);
   const int nstages = uni((int)((r1 - r0 + STAGE_ROWS - 1) / STAGE_ROWS));
 
-  constexpr int R0 = W, R1 = 7 - W;      // this wave's two grid rows
-  constexpr int NB0 = 8 - W;             // column tiles W..7: B fragments held
-  constexpr int NG = 9;                  // G tiles: NB0 of row R0, W + 1 of row R1
-  acc_t acc[NG], acch[2 * NBY];
+  constexpr DiagTab P = diag_tab(W, CVM_DIAG_STRIPS && NBY == 1);
+  constexpr int NF = P.nf, NA = P.na, NG = P.ng, NX = P.nx;
+  acc_t acc[NG], acch[NX * NBY];
 #pragma unroll
   for (int i = 0; i < NG; ++i) acc[i] = (acc_t){0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < 2 * NBY; ++i) acch[i] = (acc_t){0, 0, 0, 0};
+  for (int i = 0; i < NX * NBY; ++i) acch[i] = (acc_t){0, 0, 0, 0};
   double st_s[2] = {0, 0}, st_q[2] = {0, 0};
   double sy[NBY], qy[NBY], sw_ = 0, nz_ = 0, ng_ = 0;
 #pragma unroll
@@ -742,11 +817,11 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   __syncthreads();   // B_a
   __syncthreads();   // B_-1: stage 0 is in buffer 0
 
-  T bf[2][NB0], aw[2][2], yf[2][NBY], wv[2];
+  T bf[2][NF], aw[2][NA], yf[2][NBY], wv[2];
   auto read_frags = [&](const T *buf, int ks, int slot) {
     const int r = 4 * ks + lk;
 #pragma unroll
-    for (int j = 0; j < NB0; ++j) bf[slot][j] = buf[r * PITCH + 16 * (W + j) + lc];
+    for (int j = 0; j < NF; ++j) bf[slot][j] = buf[r * PITCH + 16 * P.ft[j] + lc];
 #pragma unroll
     for (int n = 0; n < NBY; ++n) yf[slot][n] = buf[PANEL_ELEMS + r * YPITCH + 16 * n + lc];
     wv[slot] = buf[2 * PANEL_ELEMS + r];
@@ -754,13 +829,18 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   // weighting and column sums of one k-step's fragments: same row classes and combine order
   // as everywhere else (a constant-one column gives s == q == sw bit for bit)
   auto prepare = [&](int c) {
-    const T x0 = bf[c][0], x1 = bf[c][R1 - W];
-    const T p0 = WEIGHTED ? (T)(x0 * wv[c]) : x0, p1 = WEIGHTED ? (T)(x1 * wv[c]) : x1;
-    if (!FUSEDR) {   // (the fused route gets its statistics from colstats_kernel)
-      st_s[0] += p0; st_q[0] += (T)(p0 * x0);
-      st_s[1] += p1; st_q[1] += (T)(p1 * x1);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const T x = bf[c][P.at[q]];
+      aw[c][q] = WEIGHTED ? (T)(x * wv[c]) : x;
     }
-    aw[c][0] = p0; aw[c][1] = p1;
+    if (!FUSEDR) {   // (the fused route gets its statistics from colstats_kernel)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const T x = bf[c][P.at[P.ca[q]]], pv = aw[c][P.ca[q]];
+        st_s[q] += pv; st_q[q] += (T)(pv * x);
+      }
+    }
     if (YSTAT && !FUSEDR) {
 #pragma unroll
       for (int n = 0; n < NBY; ++n) {
@@ -773,6 +853,14 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
       ng_ += (wv[c] < (T)0) ? 1.0 : 0.0;
     }
   };
+  // MFMA i of a k-step: the G tiles in table order, then the XTY tiles
+  auto mfma_i = [&](int i, int c) {
+    if (i < NG) acc[i] = MF<T>::mfma(aw[c][P.ga[i]], bf[c][P.gb[i]], acc[i]);
+    else {
+      const int h = i - NG, x = h / NBY, n = h - x * NBY;
+      acch[x * NBY + n] = MF<T>::mfma(aw[c][P.xa[x]], yf[c][n], acch[x * NBY + n]);
+    }
+  };
   read_frags(smem, 0, 0);
   prepare(0);
 #pragma unroll 1
@@ -782,33 +870,23 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = ks & 1;
+      constexpr int NM = NG + NX * NBY;
 #if CVM_INTERLEAVE
       // one LDS read of the next k-step right behind each MFMA, the order pinned (see the
-      // off-diagonal wave in wgram4_body): first what the weighting / column sums need (w, the two
-      // A-side fragments, the Y fragments), then the other fragments; the weighting and the sums of
-      // the next k-step behind the last MFMA.  NR = NB0 + NBY + 1 reads for NM = 9 + 2 NBY MFMAs.
-      constexpr int NR = NB0 + NBY + 1, NM = NG + 2 * NBY;
+      // off-diagonal wave in wgram4_body): first what the weighting / column sums need (w, the
+      // A-side fragments, the Y fragments), then the other fragments (DiagTab::rd); the weighting
+      // and the sums of the next k-step behind the last MFMA.  NR = NF + NBY + 1 reads for NM MFMAs.
+      constexpr int NR = NF + NBY + 1;
       static_assert(NR <= NM, "more fragment reads than MFMAs in a k-step");
       const T *rb = ks < 3 ? buf : nbuf;
       const int r = 4 * (ks < 3 ? ks + 1 : 0) + lk;
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
-        if (i < NB0) acc[i] = MF<T>::mfma(aw[c][0], bf[c][i], acc[i]);
-        else if (i < NG) acc[i] = MF<T>::mfma(aw[c][1], bf[c][R1 - W + (i - NB0)], acc[i]);
-        else {
-          const int h = i - NG, n = h >> 1;                 // (row R0, Y tile n), (row R1, Y tile n)
-          if ((h & 1) == 0) acch[n] = MF<T>::mfma(aw[c][0], yf[c][n], acch[n]);
-          else acch[NBY + n] = MF<T>::mfma(aw[c][1], yf[c][n], acch[NBY + n]);
-        }
+        mfma_i(i, c);
         if (i == 0) wv[c ^ 1] = rb[2 * PANEL_ELEMS + r];
-        else if (i == 1) bf[c ^ 1][0] = rb[r * PITCH + 16 * W + lc];
-        else if (i == 2) bf[c ^ 1][R1 - W] = rb[r * PITCH + 16 * R1 + lc];
-        else if (i < 3 + NBY) yf[c ^ 1][i - 3] = rb[PANEL_ELEMS + r * YPITCH + 16 * (i - 3) + lc];
-        else if (i < NR) {
-          const int k = i - (3 + NBY);                      // the other fragments, in order
-          const int j = (k + 1 < R1 - W) ? k + 1 : k + 2;
-          bf[c ^ 1][j] = rb[r * PITCH + 16 * (W + j) + lc];
-        }
+        else if (i <= NA) bf[c ^ 1][P.rd[i - 1]] = rb[r * PITCH + 16 * P.ft[P.rd[i - 1]] + lc];
+        else if (i <= NA + NBY) yf[c ^ 1][i - NA - 1] = rb[PANEL_ELEMS + r * YPITCH + 16 * (i - NA - 1) + lc];
+        else if (i < NR) bf[c ^ 1][P.rd[i - 1 - NBY]] = rb[r * PITCH + 16 * P.ft[P.rd[i - 1 - NBY]] + lc];
         if (i == NM - 1) prepare(c ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -816,17 +894,12 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
       if (ks < 3) read_frags(buf, ks + 1, c ^ 1); else read_frags(nbuf, 0, c ^ 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < NB0; ++j) acc[j] = MF<T>::mfma(aw[c][0], bf[c][j], acc[j]);
+      for (int i = 0; i < NM / 2; ++i) mfma_i(i, c);
       __builtin_amdgcn_sched_barrier(0);
       prepare(c ^ 1);   // the other slot: its LDS reads were issued most of a k-step ago
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < W + 1; ++j) acc[NB0 + j] = MF<T>::mfma(aw[c][1], bf[c][R1 - W + j], acc[NB0 + j]);
-#pragma unroll
-      for (int n = 0; n < NBY; ++n) {
-        acch[n] = MF<T>::mfma(aw[c][0], yf[c][n], acch[n]);
-        acch[NBY + n] = MF<T>::mfma(aw[c][1], yf[c][n], acch[NBY + n]);
-      }
+      for (int i = NM / 2; i < NM; ++i) mfma_i(i, c);
       __builtin_amdgcn_sched_barrier(0);
 #endif
     }
@@ -837,7 +910,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
     // ---- fused epilogue (one unit per fold): the four waves put their tiles of the upper
     // triangle into one 128 x 128 image in the LDS ring, then waves 0, 1 and 3 finish the
     // 64 x 64 blocks (0,0), (0,1) and (1,1) as in wgram4_body; every wave finishes the XTY
-    // rows of its two row-tiles itself.
+    // rows of its row-tiles itself.
     __syncthreads();   // all loaders have drained their LDS-DMA
     const int K = g.K, M = g.M;
     const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
@@ -849,12 +922,12 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
       T *out = (T *)a.out_XTY + fo * (size_t)K * M;
       const T *Ht = (const T *)a.H;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NX; ++i)
 #pragma unroll
         for (int n = 0; n < NBY; ++n)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = ti * TILE + 16 * (i ? R1 : R0) + MF<T>::drow(lane, r), col = 16 * n + lc;
+            const int row = ti * TILE + 16 * P.ft[P.at[P.xa[i]]] + MF<T>::drow(lane, r), col = 16 * n + lc;
             if (row < K && col < M) {
               double v = (double)Ht[(size_t)row * M + col] - (double)acch[i * NBY + n][r];
               if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
@@ -869,13 +942,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
       constexpr int TP = TILE + 1;
       T (*Td)[TP] = reinterpret_cast<T (*)[TP]>(smem_raw);
 #pragma unroll
-      for (int j = 0; j < NB0; ++j)
+      for (int j = 0; j < NG; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Td[16 * R0 + MF<T>::drow(lane, r)][16 * (W + j) + lc] = acc[j][r];
-#pragma unroll
-      for (int j = 0; j < W + 1; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Td[16 * R1 + MF<T>::drow(lane, r)][16 * (R1 + j) + lc] = acc[NB0 + j][r];
+        for (int r = 0; r < 4; ++r)
+          Td[16 * P.ft[P.at[P.ga[j]]] + MF<T>::drow(lane, r)][16 * P.ft[P.gb[j]] + lc] = acc[j][r];
       double *rs0 = reinterpret_cast<double *>(smem_raw + diag_tile_bytes<T>());
       if (W != 2) {
         // waves 0, 1, 3 set up the statistics of blocks 0, 1, 2
@@ -901,12 +971,11 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
     return ((v + v1) + v2) + v3;
   };
   double *st = unit_stats<T>(a.ws, g, u);
-  {
-    const double s0 = comb(st_s[0]), q0 = comb(st_q[0]), s1 = comb(st_s[1]), q1 = comb(st_q[1]);
-    if (lk == 0) {
-      st[ti * TILE + 16 * R0 + lc] = s0; st[g.Kp + ti * TILE + 16 * R0 + lc] = q0;
-      st[ti * TILE + 16 * R1 + lc] = s1; st[g.Kp + ti * TILE + 16 * R1 + lc] = q1;
-    }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double sv = comb(st_s[q]), qv = comb(st_q[q]);
+    const int tile = P.ft[P.at[P.ca[q]]];
+    if (lk == 0) { st[ti * TILE + 16 * tile + lc] = sv; st[g.Kp + ti * TILE + 16 * tile + lc] = qv; }
   }
   if (YSTAT) {
 #pragma unroll
@@ -925,25 +994,20 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   if (g.M > 0) {
     T *hp = unit_h<T>(a.ws, g, u) + (size_t)ti * TILE * g.Mp;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NX; ++i)
 #pragma unroll
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          hp[(size_t)(16 * (i ? R1 : R0) + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] =
+          hp[(size_t)(16 * P.ft[P.at[P.xa[i]]] + MF<T>::drow(lane, r)) * g.Mp + 16 * n + lc] =
               (n < NBY) ? acch[i * NBY + (n < NBY ? n : 0)][r] : 0.0;
   }
   T *tp = unit_tiles<T>(a.ws, g, u) + (size_t)it * TILE * TILE;
 #pragma unroll
-  for (int j = 0; j < NB0; ++j)
+  for (int j = 0; j < NG; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      tp[(16 * R0 + MF<T>::drow(lane, r)) * TILE + 16 * (W + j) + lc] = acc[j][r];
-#pragma unroll
-  for (int j = 0; j < W + 1; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      tp[(16 * R1 + MF<T>::drow(lane, r)) * TILE + 16 * (R1 + j) + lc] = acc[NB0 + j][r];
+      tp[(16 * P.ft[P.at[P.ga[j]]] + MF<T>::drow(lane, r)) * TILE + 16 * P.ft[P.gb[j]] + lc] = acc[j][r];
   ROLE_EXIT();
 }
 
