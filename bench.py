@@ -896,6 +896,34 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(bts / ms1 / 1e6, 1), "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
                              "bytes_per_fold": "s*n*(K+M+1) + 8n"}}
+        # mid-size folds (between the HBM regime and the headline's ten big folds): the same rows cut
+        # into 100 and 1000 folds, the batched fold stage of the eager object (one unit per fold:
+        # the Gram kernel with the fused epilogue).  Roofline time = the larger of the algorithmic
+        # flops at the MFMA peak and the bytes that must move (outputs, G once per fold, rows) at
+        # the HBM peak; `frac` = that time / the measured time.
+        if supp is not None and batch is not None and args.workload in ("C2", "C3") and X is not None:
+            for Pm in (100, 1000):
+                nvm = N // Pm
+                foldsm = [np.arange(f, N, Pm)[:nvm] for f in range(Pm)]
+                bm = eager.prepare_folds(foldsm)
+                o_ = eager.training_XTX_XTY_batched(bm); del o_
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                tl = []
+                for _ in range(5):
+                    e0.record(); o_ = eager.training_XTX_XTY_batched(bm); e1.record()
+                    torch.cuda.synchronize(); tl.append(e0.elapsed_time(e1)); del o_
+                ms1 = float(np.median(tl))
+                fl = Pm * nvm * (K * (K + 1) + 2.0 * K * M)
+                bt = Pm * (es * nvm * (K + M + 1) + 8 * nvm + 2.0 * es * K * (K + M))
+                peak_fl = PEAK_TFLOPS[dtype] * 1e12
+                t_fl, t_bt = fl / peak_fl * 1e3, bt / (PEAK_HBM_GBS * 1e9) * 1e3
+                supp[f"mid-size folds ({args.workload} rows, P={Pm}, n_val={nvm})"] = {
+                    "folds": Pm, "ms": round(ms1, 4), "folds_per_s": round(Pm / ms1 * 1e3, 1),
+                    "roofline": {"bound": "mfma" if t_fl >= t_bt else "hbm", "flops_ms_at_peak": round(t_fl, 4),
+                                 "bytes_ms_at_peak": round(t_bt, 4), "frac": round(max(t_fl, t_bt) / ms1, 4),
+                                 "flops": "n*(K(K+1) + 2KM) per fold", "bytes": "s*n*(K+M+1) + 8n + 2*s*K*(K+M) per fold"}}
+                del bm, foldsm
         # the step after the path: Improved Kernel PLS (20 components) on the
         # training matrices of this workload's folds, where the fold stage left them
         if supp is not None and batch is not None:
