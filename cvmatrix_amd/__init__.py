@@ -6,7 +6,7 @@ The arithmetic runs in hand-written HIP kernels (cvmatrix_amd/csrc/) reached
 through the C ABI of include/cvmhip.h.  There is no CPU fallback: without a GPU and the
 built libcvmhip.so, ``CVMatrix.fit`` raises."""
 
-__version__ = "0.1.0"
+__version__ = "0.3.0"
 __all__ = ["CVMatrix", "Partitioner", "FoldBatch"]
 
 from .partitioner import Partitioner

@@ -53,7 +53,7 @@ def _embedded_hash_without_loading(path: str = OUT):
         return None
     with open(path, "rb") as f:
         blob = f.read()
-    tag = b"cvmhip 0.2.0 (gfx950) src "
+    tag = b"cvmhip 0.3.0 (gfx950) src "
     i = blob.find(tag)
     if i < 0:
         return None

@@ -56,7 +56,7 @@ extern "C" {
 #ifndef CVM_SRC_SHA
 #define CVM_SRC_SHA "unknown"
 #endif
-const char *cvm_version(void) { return "cvmhip 0.2.0 (gfx950) src " CVM_SRC_SHA; }
+const char *cvm_version(void) { return "cvmhip 0.3.0 (gfx950) src " CVM_SRC_SHA; }
 const char *cvm_source_hash(void) { return CVM_SRC_SHA; }
 const char *cvm_last_error(void) { return g_err; }
 
