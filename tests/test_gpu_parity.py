@@ -1520,6 +1520,46 @@ def test_wide_matrices_k8192_k16384():
     assert r.stdout.count("XTX err") == 4, r.stdout
 
 
+@pytest.mark.parametrize("dtype,K,M,nv", [(np.float64, 4096, 2, 100), (np.float64, 1024, 4, 44), (np.float32, 1024, 3, 60),
+                                          (np.float32, 512, 1, 45)])
+def test_direct_route_beyond_one_chunk_by_the_default_table(amd, dtype, K, M, nv):
+    """Folds of 33 ... 128 rows where the library's own table (small_route_limit, host.hpp) sends
+    them to the direct kernels in several 32-row chunks -- float64 K >= 4096 up to 128 rows,
+    768 <= K < 4096 up to 48; float32 up to 64 / 48 -- against the oracle, ragged folds, weights
+    with zeros."""
+    rng = np.random.default_rng(K + nv)
+    P = 5
+    N = P * nv + 40
+    X = rng.random((N, K)).astype(dtype)
+    Y = rng.random((N, M)).astype(dtype)
+    w = rng.random(N).astype(dtype)
+    w[rng.choice(N, N // 10, replace=False)] = 0
+    perm = rng.permutation(N)
+    sizes = [nv, nv - 7, nv, 33, nv - 1]
+    folds, o = [], 0
+    for n in sizes:
+        folds.append(np.sort(perm[o:o + n])); o += n
+    flags = (True, True, True, True)
+    if dtype is np.float64:
+        m, _ = _compare_with_oracle(amd, X, Y, w, folds, flags)
+        (bx, _), _ = m.training_XTX_XTY_batched(folds)
+    else:
+        m = amd.CVMatrix(*flags, dtype=np.float32)
+        m.fit(X, Y, w)
+        o = OracleCVMatrix(*flags)
+        o.fit(X.astype(np.float64), Y.astype(np.float64), w.astype(np.float64))
+        o32 = OracleCVMatrix(*flags, dtype=np.float32)
+        o32.fit(X, Y, w)
+        (bx, by), _ = m.training_XTX_XTY_batched(folds)
+        for f, v in enumerate(folds):
+            (rx, ry), _ = o.training_XTX_XTY(v)
+            (sx, sy), _ = o32.training_XTX_XTY(v)
+            assert_fp32_like_reference(bx[f], rx, sx, f"fold{f} XTX")
+            assert_fp32_like_reference(by[f], ry, sy, f"fold{f} XTY")
+    for f in range(P):
+        assert bool((bx[f] == bx[f].T).all())
+
+
 @pytest.mark.parametrize("tool,args,env", [("fuzz_all.py", ["300", "101"], {}), ("fuzz_small.py", ["500", "102"], {}),
                                            ("fuzz_small.py", ["250", "103"], {"CVM_SMALL_MAXN": "128"})])
 def test_randomised_routes_against_the_oracle(tool, args, env):
