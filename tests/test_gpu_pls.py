@@ -313,3 +313,17 @@ def test_validation_sse_on_the_device(pls, dtype, N, K, M, P, A, weighted, flags
         assert abs(float(wsum[f]) - float(wv.sum())) <= 1e-12 * float(wv.sum())
     r = cv_rmse(sse, wsum)
     assert r.shape == (A, M) and bool(torch.isfinite(r).all())
+
+
+def test_randomised_shapes_against_the_oracle():
+    """tools/fuzz_pls.py: random N, K, M (1 ... 64), fold counts, components, element types, flags and
+    weights -- the coefficients of every well-determined component against the NumPy oracle
+    (float64 1e-8) and the validation errors against the same formula in torch operations (1e-9)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pls.py"), "120", "21"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
