@@ -262,6 +262,11 @@ def main():
                          "supplementary or CPU legs): the command profiled under "
                          "rocprofv3 for profiles/, so that every launch in the trace is a "
                          "launch of the timed region")
+    ap.add_argument("--brief", action="store_true",
+                    help="--headline-only plus the full-size from-scratch parity check: what the default N=1 run "
+                         "starts as a child process for every other BASELINE workload (other_workloads)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the child runs of the other BASELINE workloads (C2, C4, C5) at N=1")
     ap.add_argument("--rows", type=int, default=0, help="override the global N (debug / tests)")
     ap.add_argument("--device-data", action="store_true",
                     help="generate the inputs on the device (default for C4)")
@@ -567,7 +572,7 @@ def main():
             ms = float(tt.item())
         return ms
 
-    ho = args.headline_only
+    ho = args.headline_only or args.brief
     if emu:
         # ---- one emulated rank: breakdown, pipelined figure, parity of THIS rank's folds, one line ----
         bd = breakdown(timed_model, batch)
@@ -699,7 +704,7 @@ def main():
                 ok = False
                 notes.append(f"digest FAILED on rank {rank}: {e}")
         # full-size property check on the last fold of rank 0 (a collective when world > 1)
-        if not ho and (mode == "row_sharded" or rank == 0):
+        if (not ho or args.brief) and (mode == "row_sharded" or rank == 0):
             # (replicated: rank 0 holds every row and checks alone, nothing collective)
             cw = world if mode == "row_sharded" else 1
             try:
@@ -830,6 +835,26 @@ def main():
         supp = None
         if world == 1 and not args.rows and not ho:
             supp = {}
+
+            def back_to_back(call, reps=8, samples=3, warm_s=0.04):
+                """ms per call, measured like the headline: >= 30 ms of the same work first (the GPU's
+                clocks and the memory system's state), then `reps` calls between ONE pair of events."""
+                a_ = time.perf_counter()
+                while time.perf_counter() - a_ < warm_s:
+                    call()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                tl_ = []
+                for _ in range(samples):
+                    e0.record()
+                    for _k in range(reps):
+                        call()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    tl_.append(e0.elapsed_time(e1) / reps)
+                return float(np.median(tl_))
+
+            stream_ptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for name, (n_, k_, m_, nv_, nf_, dt_) in {
                 "C5-hbm (K=4096,M=1,f32,n_val=16)": (20000, 4096, 1, 16, 48, np.float32),
                 "K=4096,M=1,f64,n_val=16": (20000, 4096, 1, 16, 48, np.float64),
@@ -843,15 +868,28 @@ def main():
                 ms_ = CVMatrix(dtype=dt_, copy=False, device=dev, lazy_fit=False)
                 ms_.fit(Xs, Ys, ws_)
                 bs_ = ms_.prepare_folds([np.arange(i * nv_, (i + 1) * nv_) for i in range(nf_)])
-                o_ = ms_.training_XTX_XTY_batched(bs_); del o_
+
+                def call_():
+                    o_ = ms_.training_XTX_XTY_batched(bs_)
+                    del o_
+                ms1 = back_to_back(call_)
+                # the call's kernels by the library's own events (4 calls back to back)
+                lib.cvm_timing_enable(1)
+                for _k in range(4):
+                    call_()
                 torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                tl = []
-                for _ in range(5):
-                    e0.record(); o_ = ms_.training_XTX_XTY_batched(bs_); e1.record()
-                    torch.cuda.synchronize(); tl.append(e0.elapsed_time(e1)); del o_
-                ms1 = float(np.median(tl))
+                kms, kn = (C.c_double * 4)(), (C.c_int64 * 4)()
+                lib.cvm_timing_read_kinds(kms, kn)
+                lib.cvm_timing_enable(0)
+                # what this box's memory system takes when nothing but the outputs is written: one launch of
+                # nontemporal 16-byte stores over a buffer of the outputs' size, timed the same way
                 sz = np.dtype(dt_).itemsize
+                obytes = (nf_ * k_ * (k_ + m_) * sz + 15) // 16 * 16
+                probe = torch.empty(obytes, dtype=torch.uint8, device=dev)
+                pp_ = C.c_void_p(probe.data_ptr())
+                fill_ms = back_to_back(lambda: lib.cvm_fill_probe(pp_, C.c_size_t(obytes), stream_ptr), warm_s=0.02)
+                fill_gbs = obytes / fill_ms / 1e6
+                del probe
                 bts = nf_ * (sz * nv_ * (k_ + m_ + 1) + 8 * nv_ + 2 * sz * k_ * (k_ + m_))
                 # what the memory system must move at least when the full-data matrices stay in
                 # cache (they are the same for every fold): the outputs + the rows, G and H once
@@ -861,10 +899,19 @@ def main():
                 # per-fold formula of SURVEY 8(d) also bills a read of G and H per fold, which the
                 # caches serve -- its GB/s is reported for reference, without a fraction (it is not
                 # a roofline figure: it can exceed the peak)
+                ach = bts_mem / ms1 / 1e6
                 supp[name] = {"folds": nf_, "ms": round(ms1, 4), "folds_per_s": round(nf_ / ms1 * 1e3, 1),
-                              "roofline": {"bound": "hbm", "achieved": round(bts_mem / ms1 / 1e6, 1),
+                              "timing": "median of 3 samples of 8 calls back to back between one pair of events, after "
+                                        ">= 40 ms of the same calls (like the headline's steps)",
+                              "kernel_ms": {"small_stats_kernel": round(kms[2] / max(kn[2], 1), 4),
+                                            "update_kernels": round(kms[3] / max(kn[3], 1), 4),
+                                            "what": "the library's events around the statistics kernel and around the update "
+                                                    "kernels of a call (tile / whole-rows kernel + XTY panels), mean of 4 calls"},
+                              "fill_probe_GBps": round(fill_gbs, 1),
+                              "roofline": {"bound": "hbm", "achieved": round(ach, 1),
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                           "frac": round(bts_mem / ms1 / 1e6 / PEAK_HBM_GBS, 4),
+                                           "frac": round(ach / PEAK_HBM_GBS, 4),
+                                           "frac_of_fill": round(ach / fill_gbs, 4),
                                            "bytes_per_launch": "folds*(s*n*(K+M+1) + 8n + s*K*(K+M)) + s*K*(K+M): outputs and rows "
                                                                "once per fold, G and H once per launch",
                                            "per_fold_formula_GBps": round(bts / ms1 / 1e6, 1),
@@ -876,23 +923,11 @@ def main():
         if supp is not None and batch is not None:
             # (on the eager object: after a sweep the lazy one derives the statistics from the
             #  partials it still holds, without touching the rows)
-            eager.training_statistics_batched(batch)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            tl = []
-            for _ in range(10):
-                # (a call is two kernels of ~0.08 ms: eight calls back to back per sample, like the
-                #  steps of the headline, so that the device's rate is measured, not one launch latency)
-                e0.record()
-                for _k in range(8):
-                    eager.training_statistics_batched(batch)
-                e1.record()
-                torch.cuda.synchronize(); tl.append(e0.elapsed_time(e1) / 8)
-            ms1 = float(np.median(tl))
+            ms1 = back_to_back(lambda: eager.training_statistics_batched(batch), warm_s=0.02)
             bts = float((es * n_val * (K + M + 1) + 8 * n_val).sum())
             supp[f"training_statistics ({args.workload})"] = {
                 "folds": P, "ms": round(ms1, 4), "folds_per_s": round(P / ms1 * 1e3, 1),
-                "timing": "8 calls back to back per sample",
+                "timing": "8 calls back to back per sample, 3 samples, after 20 ms of the same calls",
                 "roofline": {"bound": "hbm", "achieved": round(bts / ms1 / 1e6, 1), "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
                              "bytes_per_fold": "s*n*(K+M+1) + 8n"}}
@@ -906,20 +941,17 @@ def main():
                 nvm = N // Pm
                 foldsm = [np.arange(f, N, Pm)[:nvm] for f in range(Pm)]
                 bm = eager.prepare_folds(foldsm)
-                o_ = eager.training_XTX_XTY_batched(bm); del o_
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                tl = []
-                for _ in range(5):
-                    e0.record(); o_ = eager.training_XTX_XTY_batched(bm); e1.record()
-                    torch.cuda.synchronize(); tl.append(e0.elapsed_time(e1)); del o_
-                ms1 = float(np.median(tl))
+                def callm_():
+                    o_ = eager.training_XTX_XTY_batched(bm)
+                    del o_
+                ms1 = back_to_back(callm_, reps=6)
                 fl = Pm * nvm * (K * (K + 1) + 2.0 * K * M)
                 bt = Pm * (es * nvm * (K + M + 1) + 8 * nvm + 2.0 * es * K * (K + M))
                 peak_fl = PEAK_TFLOPS[dtype] * 1e12
                 t_fl, t_bt = fl / peak_fl * 1e3, bt / (PEAK_HBM_GBS * 1e9) * 1e3
                 supp[f"mid-size folds ({args.workload} rows, P={Pm}, n_val={nvm})"] = {
                     "folds": Pm, "ms": round(ms1, 4), "folds_per_s": round(Pm / ms1 * 1e3, 1),
+                    "timing": "6 calls back to back per sample, 3 samples, after 40 ms of the same calls",
                     "roofline": {"bound": "mfma" if t_fl >= t_bt else "hbm", "flops_ms_at_peak": round(t_fl, 4),
                                  "bytes_ms_at_peak": round(t_bt, 4), "frac": round(max(t_fl, t_bt) / ms1, 4),
                                  "flops": "n*(K(K+1) + 2KM) per fold", "bytes": "s*n*(K+M+1) + 8n + 2*s*K*(K+M) per fold"}}
@@ -943,6 +975,39 @@ def main():
                 "folds": P, "ms": round(ms1, 4), "folds_per_s": round(P / ms1 * 1e3, 1),
                 "us_per_component": round(ms1 / A_pls * 1e3, 2), "plan": pp}
             del bx, by
+        # the other BASELINE.json GPU workloads at N=1, each as a child run of this script (`--brief`: the
+        # pre-warm, 2 warm-up and 3 timed sweep steps, the Gram launch by the library's events, the
+        # in-run parity gate incl. the from-scratch check at full size) -- so that the driver's line
+        # carries all four configurations, not C3 alone
+        others = None
+        if world == 1 and not args.rows and not ho and not args.no_other_workloads and not emu:
+            import subprocess
+
+            others = {}
+            for wl_ in ("C2", "C4", "C5"):
+                if wl_ == args.workload:
+                    continue
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl_, "--steps", "3", "--warmup", "2",
+                       "--brief", "--no-live-traffic"] + (["--device-data"] if wl_ == "C5" else [])
+                a_ = time.perf_counter()
+                try:
+                    r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                    line_ = [ln for ln in r_.stdout.splitlines() if ln.startswith("{")]
+                    j_ = json.loads(line_[-1]) if line_ else None
+                except Exception as e:  # noqa: BLE001
+                    j_, r_ = None, None
+                    others[wl_] = {"error": repr(e)}
+                if j_ is not None:
+                    rf_ = j_["roofline"]
+                    others[wl_] = {"workload": j_["config"]["workload"], "data": j_["data"], "dtype": j_["dtype"],
+                                   "steps": j_["steps"], "warmup": j_["warmup"],
+                                   "ms_per_step": j_["ms_per_step"], "folds_per_s": j_["value"],
+                                   "gram_avg_launch_ms": rf_["avg_launch_ms"], "gram_launches_timed": rf_["launches_timed"],
+                                   "gram_flops_per_launch": rf_["flops_per_launch"], "achieved_TFLOPs": rf_["achieved"],
+                                   "peak_TFLOPs": rf_["peak"], "frac": rf_["frac"], "parity": j_["parity"],
+                                   "wall_s": round(time.perf_counter() - a_, 1)}
+                elif wl_ not in others:
+                    others[wl_] = {"error": f"rc={r_.returncode}: {(r_.stderr or '')[-300:]}"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not ho:
             from oracle.cvmatrix_oracle import run_cv
@@ -1032,6 +1097,7 @@ def main():
             "step_breakdown": bd, "pipelined": pipe,
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu,
             "supplementary_hbm_regime": supp,
+            "other_workloads": others,
             "lib": lib.cvm_version().decode(),
         }
         result = {k: (None if isinstance(v, float) and v != v else v) for k, v in result.items()}

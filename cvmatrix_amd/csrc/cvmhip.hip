@@ -39,6 +39,7 @@ namespace {
 #include "finalize.hpp"
 #include "colstats.hpp"
 #include "small_folds.hpp"
+#include "small_tile.hpp"
 #include "host.hpp"
 #include "partition.hpp"
 #include "pls.hpp"
@@ -87,7 +88,7 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
   (void)n_idx;
   if (max_fold_rows <= SMALL_ROWS) {   // direct path: only the per-fold statistics live in ws
     const int64_t nb = n_folds < 32768 ? (n_folds > 0 ? n_folds : 1) : 32768;
-    return (size_t)nb * fstat_len(K, M) * 8 + QUEUE_RESERVE;
+    return (size_t)nb * small_ws_per_fold(K, M, dtype == CVM_F64 ? 8 : 4) + 512 + QUEUE_RESERVE;
   }
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, !(flags & CVM_RET_XTX));
   const int splits = plan_stride(n_folds, max_fold_rows, g, dtype == CVM_F64 ? 8 : 4);
@@ -317,22 +318,43 @@ int cvm_timing_enable(int on) {
   return CVM_OK;
 }
 
-int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold) {
+static int timing_collect(double *ms, int64_t *n) {      // ms[4], n[4] by kind; resets the list
   std::lock_guard<std::mutex> lk(g_timing_mu);
-  double ms[2] = {0, 0};
-  int64_t n[2] = {0, 0};
+  for (int k = 0; k < 4; ++k) { ms[k] = 0; n[k] = 0; }
   for (int i = 0; i < g_ntimed; ++i) {
     HIP_OK(hipEventSynchronize(g_timed[i].b));
     float t = 0;
     HIP_OK(hipEventElapsedTime(&t, g_timed[i].a, g_timed[i].b));
-    ms[g_timed[i].kind] += t;
-    ++n[g_timed[i].kind];
+    const int k = g_timed[i].kind;
+    if (k >= 0 && k < 4) { ms[k] += t; ++n[k]; }
   }
   g_ntimed = 0;
+  return CVM_OK;
+}
+
+int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold) {
+  double ms[4];
+  int64_t n[4];
+  const int rc = timing_collect(ms, n);
+  if (rc != CVM_OK) return rc;
   if (ms_fit) *ms_fit = ms[0];
   if (n_fit) *n_fit = n[0];
   if (ms_fold) *ms_fold = ms[1];
   if (n_fold) *n_fold = n[1];
+  return CVM_OK;
+}
+
+int cvm_timing_read_kinds(double *ms4, int64_t *n4) {
+  if (!ms4 || !n4) return fail(CVM_EINVAL, "cvm_timing_read_kinds: null pointer%s");
+  return timing_collect(ms4, n4);
+}
+
+int cvm_fill_probe(void *buf, size_t bytes, void *stream) {
+  if (!buf || bytes % 16 || (uintptr_t)buf % 16) return fail(CVM_EINVAL, "cvm_fill_probe: 16-byte pieces%s");
+  const size_t pieces = bytes / 16;
+  if (!pieces) return CVM_OK;
+  hipLaunchKernelGGL(fill_probe_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (float *)buf, pieces);
+  HIP_OK(hipGetLastError());
   return CVM_OK;
 }
 

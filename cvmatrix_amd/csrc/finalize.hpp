@@ -21,6 +21,14 @@ template <typename V> __device__ __forceinline__ void out_store(V *p, V v) {
 #endif
 }
 
+// the write ceiling of the device with this kind of store (cvm_fill_probe): linear, 16 bytes per lane
+__global__ __launch_bounds__(256) void fill_probe_kernel(float *buf, size_t pieces) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 *p = reinterpret_cast<v4 *>(buf);
+  const v4 z = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (size_t)gridDim.x * 256) out_store(p + i, z);
+}
+
 // Scaling by the training-set standard deviations (cvmatrix.py:1007-1010: XTX / (sd_a sd_b), XTY /
 // (sd_a sd_y)): the per-fold statistics vector `fstats` holds the RECIPROCAL stds, one division per
 // column and fold (fold_stats_kernel / small_stats_kernel), and every finish computes

@@ -27,6 +27,23 @@ std::atomic<bool> g_timing{false};
 std::mutex g_timing_mu;
 TimedLaunch g_timed[MAX_TIMED];
 int g_ntimed = 0;        // slots handed out (guarded by g_timing_mu)
+// kinds: 0 Gram launch of the fit stage, 1 of the fold stage, 2 small_stats_kernel, 3 the small-fold update kernels
+inline TimedLaunch *timed_begin(int kind, hipStream_t st) {
+  if (!g_timing.load(std::memory_order_relaxed)) return nullptr;
+  TimedLaunch *tl = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (g_ntimed >= MAX_TIMED) return nullptr;
+    tl = &g_timed[g_ntimed++];
+    if (!tl->a) {
+      if (hipEventCreate(&tl->a) != hipSuccess || hipEventCreate(&tl->b) != hipSuccess) { --g_ntimed; return nullptr; }
+    }
+    tl->kind = kind;
+  }
+  if (hipEventRecord(tl->a, st) != hipSuccess) return nullptr;
+  return tl;
+}
+inline void timed_end(TimedLaunch *tl, hipStream_t st) { if (tl) (void)hipEventRecord(tl->b, st); }
 enum { KIND_FIT = 0, KIND_FOLD = 1 };
 
 // once-per-device flags of hipFuncSetAttribute: a bit mask updated atomically (setting the
@@ -467,6 +484,10 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // 1.91 / 1.87, 64 rows 1.59 / 1.73; K=1024 ... 4096 64 rows 2.13 / 2.02 ... 2.38 / 2.35, 80 rows
 // 1.77 / 1.84 ... 2.04 / 2.24.  CVM_SMALL_MAXN (32 .. 128) overrides the table for measurements
 // and tests.
+// workspace of the direct small-fold route per fold: the statistics vector + small_tile_kernel's record
+inline size_t small_ws_per_fold(int K, int M, int esize) {
+  return fstat_len(K, M) * 8 + small_rec_layout(K, esize).stride;
+}
 int small_route_limit(int K, int esize) {
   static const int forced = [] {
     const char *e = getenv("CVM_SMALL_MAXN");
@@ -486,15 +507,26 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
                     const void *G, const void *H, const double *gstats, void *out_XTX, void *out_XTY,
                     void *out_muX, void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
                     void *ws, size_t ws_bytes, hipStream_t st) {
-  const size_t per_fold = fstat_len(K, M) * 8;
-  int64_t nb_max = (int64_t)(ws_bytes / per_fold);
+  // per fold: the float64 statistics vector and the record small_tile_kernel reads (small_tile.hpp)
+  const SmallRecLayout rl = small_rec_layout(K, (int)sizeof(T));
+  const size_t per_fold = small_ws_per_fold(K, M, (int)sizeof(T));
+  int64_t nb_max = (int64_t)((ws_bytes > 256 ? ws_bytes - 256 : 0) / per_fold);
   if (nb_max < 1) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
   if (nb_max > 32768) nb_max = 32768;   // grid.y
+  if (nb_max > n_folds) nb_max = n_folds;
   static const bool no_direct = getenv("CVM_NO_DIRECT") != nullptr;   // tests: force the transposing kernel
   SmallArgs a;
   memset(&a, 0, sizeof(a));
   a.X = X; a.Y = Y; a.w = w; a.idx = idx; a.offs = offsets; a.K = K; a.M = M;
   a.G = G; a.H = H; a.gstats = gstats; a.fstats = (double *)ws;
+  a.rec = (char *)ws + align_up((size_t)nb_max * fstat_len(K, M) * 8, 256);
+  a.rec_stride = rl.stride; a.rec_mu = rl.mu; a.rec_isd = rl.isd; a.rec_rows = rl.rows; a.rec_w = rl.w;
+  // small_tile_kernel (CVM_SMALL_TILE: 0 = the round-3 kernels only (default), 1 = this kernel, 2 = also in place of the
+  // whole-rows kernel): rows and G in whole 16-byte pieces, folds of at most SMALL_ROWS rows
+  static const int tile_mode = getenv("CVM_SMALL_TILE") ? atoi(getenv("CVM_SMALL_TILE")) : 0;
+  const bool tile_ok = tile_mode > 0 && max_rows <= SMALL_ROWS && ((size_t)K * sizeof(T)) % 16 == 0 &&
+                       ((uintptr_t)X % 16 == 0) && ((uintptr_t)G % 16 == 0) && ((uintptr_t)out_XTX % 16 == 0) &&
+                       (flags & CVM_RET_XTX) && out_XTX;
   a.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
   a.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
   a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY;
@@ -515,9 +547,15 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     if (fpb < 1) fpb = 1;
     // (the workgroup keeps the row numbers of its folds in 256 slots: 8 folds of up to 32 rows, 4 of 64, 2 of 128)
     a.rshift = max_rows <= 32 ? 5 : (max_rows <= 64 ? 6 : 7);
+    static const int fpb_env = getenv("CVM_SMALL_FPB") ? atoi(getenv("CVM_SMALL_FPB")) : 0;   // (measurements)
+    if (fpb_env > 0) fpb = fpb_env;
     if (fpb > (256 >> a.rshift)) fpb = 256 >> a.rshift;
     a.nb = (int)nb; a.fpb = fpb;
-    const dim3 gs((unsigned)nb), ga((unsigned)(a.nT64 + a.P64), (unsigned)((nb + fpb - 1) / fpb));
+    // (statistics: one workgroup per fold and block of 256 columns -- a thread that walks 16 columns of 16 rows
+    //  one load at a time took 44 us at K = 4096, a seventh of the whole call)
+    int sy = (K + M + 255) / 256;
+    while ((int64_t)sy * nb > 65535 * 4 && sy > 1) sy = (sy + 1) / 2;
+    const dim3 gs((unsigned)nb, (unsigned)sy), ga((unsigned)(a.nT64 + a.P64), (unsigned)((nb + fpb - 1) / fpb));
     // one- and two-row folds (leave-one-out) of a matrix whose rows are not whole 128-byte lines and
     // fit one column chunk: whole rows of the full output, nothing transposed (small_rows_kernel;
     // measured +23 % at the reference's published leave-one-out shape K = 500 in float64 and +25 %
@@ -526,19 +564,24 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     const int vw = 16 / (int)sizeof(T);
     const int lpr = K <= 64 * vw ? 64 : (K <= 128 * vw ? 128 : 256);     // pieces per row of a workgroup
     const int tc = lpr * vw;
-    const bool direct = !no_direct && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
+    const bool direct = !no_direct && !(tile_ok && tile_mode >= 2) && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
                         (size_t)K * K * sizeof(T) <= ((size_t)2 << 20) + (64 << 10) &&
                         ((size_t)K * sizeof(T)) % 16 == 0 && ((size_t)K * sizeof(T)) % 128 != 0 &&
                         ((uintptr_t)G % 16 == 0) && ((uintptr_t)X % 16 == 0) &&
                         (!a.out_XTX || (uintptr_t)a.out_XTX % 16 == 0);
+    TimedLaunch *t_st = timed_begin(2, st);
     if (w) hipLaunchKernelGGL((small_stats_kernel<T, true>), gs, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((small_stats_kernel<T, false>), gs, dim3(256), 0, st, a);
+    timed_end(t_st, st);
+    TimedLaunch *t_up = (a.out_XTX || a.out_XTY) ? timed_begin(3, st) : nullptr;
     if (a.out_XTX || a.out_XTY) {
       if (direct) {
         const int panels = ((K + SR_ROWS - 1) / SR_ROWS) * ((K + tc - 1) / tc);
         int fpr = (int)((int64_t)panels * nb / (16 * 256));
         if (fpr < 1) fpr = 1;
         if (fpr > 8) fpr = 8;   // (measured flat from 8 to 16, worse at 32: too few workgroups)
+        static const int fpr_env = getenv("CVM_SMALL_FPR") ? atoi(getenv("CVM_SMALL_FPR")) : 0;   // (measurements)
+        if (fpr_env > 0) fpr = fpr_env > SA_FPB ? SA_FPB : fpr_env;
         a.fpb = fpr;
         a.gx = panels; a.gy = (int)((nb + fpr - 1) / fpr);
         const dim3 gd((unsigned)(8 * (((size_t)a.gx * a.gy + 7) / 8)));
@@ -551,6 +594,43 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         else if (lpr == 128) CVM_ROWS(128);
         else CVM_ROWS(256);
 #undef CVM_ROWS
+      } else if (tile_ok) {
+        // every 64 x 64 tile of XTX by small_tile_kernel; the XTY panels by the round-3 kernel
+        // k-steps of a fold: its rows and, when XTX is centred, the row of means; + the isd step
+        a.tsteps = (int)((max_rows + ((flags & CVM_CENTER_X) ? 1 : 0) + 3) / 4) + 1;
+        const int64_t tiles = (int64_t)a.P64 * a.P64;
+        static const int fpb_forced = getenv("CVM_SMALL_FPB") ? atoi(getenv("CVM_SMALL_FPB")) : 0;
+        int fpt = (int)(tiles * nb / (24 * 256));              // folds per workgroup: >= 24 workgroups per CU in the launch
+        if (fpt > 8) fpt = 8;
+        if (fpb_forced > 0) fpt = fpb_forced;
+        if (fpt > TL_FPB) fpt = TL_FPB;
+        if (fpt < 1) fpt = 1;
+        SmallArgs t = a;
+        static const int tile_dbg = getenv("CVM_TILE_DEBUG") ? atoi(getenv("CVM_TILE_DEBUG")) : 0;
+        t.dbg = tile_dbg;
+        t.fpb = fpt; t.x0 = 0;
+        t.gx = (int)tiles; t.gy = (int)((nb + fpt - 1) / fpt);
+        const size_t lds = small_tile_lds<T>(t.tsteps, fpt);
+        if (lds > 64 * 1024) {
+          int dev = 0;
+          HIP_OK(hipGetDevice(&dev));
+          static std::atomic<unsigned long long> attr_done{0};   // one bit per device
+          if (attr_needed(attr_done, dev)) {
+            HIP_OK(hipFuncSetAttribute((const void *)small_tile_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set(attr_done, dev);
+          }
+        }
+        const dim3 gt_((unsigned)(8 * (((size_t)t.gx * t.gy + 7) / 8)));
+        hipLaunchKernelGGL((small_tile_kernel<T>), gt_, dim3(256), lds, st, t);
+        if (a.out_XTY && M > 0) {
+          // (one fold per workgroup: the panels of a group of 8 folds one after the other took 47 us at K = 4096)
+          a.fpb = 1;
+          a.x0 = a.nT64; a.gx = a.P64; a.gy = (int)nb;
+          const dim3 g1((unsigned)(8 * (((size_t)a.gx * a.gy + 7) / 8)));
+          if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), g1, dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((small_apply_kernel<T, false>), g1, dim3(256), 0, st, a);
+          a.x0 = 0;
+        }
       } else {
         a.gx = (int)ga.x; a.gy = (int)ga.y;
         const dim3 g1((unsigned)(8 * (((size_t)ga.x * ga.y + 7) / 8)));
@@ -558,6 +638,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         else hipLaunchKernelGGL((small_apply_kernel<T, false>), g1, dim3(256), 0, st, a);
       }
     }
+    timed_end(t_up, st);
     HIP_OK(hipGetLastError());
   }
   return CVM_OK;

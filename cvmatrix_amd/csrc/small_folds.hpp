@@ -38,6 +38,13 @@ struct SmallArgs {
   int nb, fpb;                         // folds of this launch, folds per workgroup of small_apply_kernel
   int rshift;                          // small_apply_kernel: 1 << rshift row slots per fold (32, 64, 128); fpb << rshift <= 256
   int gx, gy;                          // small_apply_kernel: tiles + panels, fold groups
+  int x0;                              // small_apply_kernel: first tile / panel number of this launch
+  // small_tile_kernel (small_tile.hpp): the per-fold records small_stats_kernel leaves for it
+  char *rec;                           // nullptr: no records
+  unsigned rec_stride, rec_mu, rec_isd, rec_rows, rec_w;
+  int tsteps;                          // k-steps one operand buffer holds
+  int dbg;                             // small_tile_kernel, measurements only (CVM_TILE_DEBUG; results are wrong): 1 no MFMA
+                                       // loop, 2 no operand DMAs, 4 no transpose before the stores
 };
 
 template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_stats_kernel(const SmallArgs a) {
@@ -61,6 +68,17 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const double swt = gsw - swv, nzt = gnz - nzv;
   const double divisor = (nzt - a.ddof) * swt / nzt;
   double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+  char *rec = a.rec ? a.rec + (size_t)f * a.rec_stride : nullptr;
+  if (rec && blockIdx.y == 0 && threadIdx.x < SMALL_ROWS) {
+    // the fold's row numbers and weights where small_tile_kernel finds them with one load
+    const bool in = (int)threadIdx.x < n;
+    reinterpret_cast<int64_t *>(rec + a.rec_rows)[threadIdx.x] = in ? rows[threadIdx.x] : (int64_t)-1;
+    reinterpret_cast<T *>(rec + a.rec_w)[threadIdx.x] = in ? (T)wl[threadIdx.x] : (T)0;
+    if (threadIdx.x == 0) {
+      *reinterpret_cast<int *>(rec) = n;
+      *reinterpret_cast<double *>(rec + 8) = swt;
+    }
+  }
   if (threadIdx.x == 0 && blockIdx.y == 0) {
     fs[2 * K + 2 * M] = swt;
     if (a.out_fold) {
@@ -78,14 +96,26 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
     const int cc = isX ? c : c - K;
     if (isX ? !(want_muX) : !(want_muY)) continue;
     double sv = 0, qv = 0;
-    for (int r = 0; r < n; ++r) {
-      const T xv = isX ? X[rows[r] * (int64_t)K + cc] : Y[rows[r] * (int64_t)M + cc];
-      if (sizeof(T) == 8) {
-        const T pv = WEIGHTED ? (T)((T)wl[r] * xv) : xv;
-        sv += (double)pv; qv += (double)(pv * xv);
-      } else {
-        const double pv = wl[r] * (double)xv;
-        sv += pv; qv += pv * (double)xv;
+    // eight rows requested at a time (a row past the fold's end re-reads its last row: branch-free, so
+    // that the loads of a batch are in flight together), summed in row order
+    const T *col = isX ? X + cc : Y + cc;
+    const int64_t ld = isX ? K : M;
+    for (int r0 = 0; r0 < n; r0 += 8) {
+      T xb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xb[u] = col[rows[r0 + u < n ? r0 + u : n - 1] * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (r0 + u >= n) break;
+        const T xv = xb[u];
+        const int r = r0 + u;
+        if (sizeof(T) == 8) {
+          const T pv = WEIGHTED ? (T)((T)wl[r] * xv) : xv;
+          sv += (double)pv; qv += (double)(pv * xv);
+        } else {
+          const double pv = wl[r] * (double)xv;
+          sv += pv; qv += pv * (double)xv;
+        }
       }
     }
     const double gs = isX ? a.gstats[cc] : a.gstats[2 * K + cc];
@@ -102,6 +132,10 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
     }
     fs[isX ? cc : 2 * K + cc] = mu;
     fs[isX ? K + cc : 2 * K + M + cc] = 1.0 / sd;     // reciprocal: the finish multiplies (finalize.hpp)
+    if (rec && isX) {
+      reinterpret_cast<T *>(rec + a.rec_mu)[cc] = (T)mu;
+      reinterpret_cast<T *>(rec + a.rec_isd)[cc] = (T)(1.0 / sd);
+    }
     T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
     const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
     if (omu) omu[o] = (T)mu;
@@ -138,7 +172,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
   const unsigned per = (tot + 7) / 8;
   const unsigned item = (lin & 7) * per + (lin >> 3);
   if (item >= tot) return;
-  const int x = (int)(item % (unsigned)a.gx), by = (int)(item / (unsigned)a.gx);
+  const int x = a.x0 + (int)(item % (unsigned)a.gx), by = (int)(item / (unsigned)a.gx);
   const int K = a.K, M = a.M;
   const int tid = threadIdx.x;
   const T *X = (const T *)a.X, *Y = (const T *)a.Y, *W = (const T *)a.w;

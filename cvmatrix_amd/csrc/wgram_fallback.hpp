@@ -22,6 +22,11 @@
 __device__ double g_zero_line[128];  // zero-initialised at code-object load
 __device__ double g_one_line[2] = {1.0, 1.0};
 __device__ float g_one_line_f[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+// 1 KiB of ones per element type (small_tile_kernel: the "reciprocal standard deviations" of a call that scales nothing)
+#define CVM_R8(x) x, x, x, x, x, x, x, x
+__device__ double g_ones_line_d[128] = {CVM_R8(CVM_R8(1.0)), CVM_R8(CVM_R8(1.0))};
+__device__ float g_ones_line_f[256] = {CVM_R8(CVM_R8(1.0f)), CVM_R8(CVM_R8(1.0f)), CVM_R8(CVM_R8(1.0f)), CVM_R8(CVM_R8(1.0f))};
+#undef CVM_R8
 #ifdef CVM_STAMPS
 // diagnostic build only: per (workgroup, wave) cycle sums of the three phases of a stage
 __device__ unsigned long long g_stamps[1024 * 8 * 4];

@@ -225,6 +225,17 @@ int cvm_pls_plan(int64_t n_folds, int K, int M, int A, int dtype, int64_t *info)
  * meant for bench.py. */
 int cvm_timing_enable(int on);
 int cvm_timing_read(double *ms_fit, int64_t *n_fit, double *ms_fold, int64_t *n_fold);
+/* The same list by kind: ms4 / n4 [0] Gram launches of the fit stage, [1] of the fold stage, [2] the
+ * statistics kernel of the small-fold route (small_stats_kernel), [3] its update kernels (everything
+ * a call launches after the statistics: tile / whole-rows kernel and the XTY panels). */
+int cvm_timing_read_kinds(double *ms4, int64_t *n4);
+
+/* Benchmark support: the write ceiling of this device, measured with the product's own kind of store --
+ * one launch that fills `bytes` (a multiple of 16) from `buf` (16-byte aligned) with zeros by nontemporal
+ * 16-byte stores in linear order.  bench.py times it on the output buffer of the HBM-regime shapes, in the
+ * same run, so that a measured rate can be read against what THIS box's memory system takes
+ * (`frac_of_fill` next to `frac`).  No reference counterpart: the reference has no device. */
+int cvm_fill_probe(void *buf, size_t bytes, void *stream);
 
 /* Introspection for benchmarks/profiles: geometry chosen for a problem (info: int64[8]).
  * info[0]=row splits per fold of the off-diagonal 128x128 tiles, [6]=row splits of the diagonal
