@@ -27,7 +27,7 @@ EXPORTS = (
     "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_plan_fold",
     "cvm_timing_enable", "cvm_timing_read", "cvm_timing_read_kinds", "cvm_fill_probe",
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds", "cvm_sweep_fold_range", "cvm_sweep_all",
-    "cvm_partition_workspace_bytes", "cvm_partition_labels",
+    "cvm_partition_workspace_bytes", "cvm_partition_labels", "cvm_partition_periodic",
     "cvm_pls_workspace_bytes", "cvm_pls_fit", "cvm_pls_plan",
     "cvm_pls_sse_workspace_bytes", "cvm_pls_validation_sse",
 )
@@ -98,6 +98,8 @@ def load():
     lib.cvm_partition_workspace_bytes.argtypes = [i64, i64]
     lib.cvm_partition_labels.restype = C.c_int
     lib.cvm_partition_labels.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]
+    lib.cvm_partition_periodic.restype = C.c_int
+    lib.cvm_partition_periodic.argtypes = [vp, i64, i64, vp, C.c_int, vp, vp, vp, vp, vp]
     lib.cvm_pls_workspace_bytes.restype = sz
     lib.cvm_pls_workspace_bytes.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cvm_pls_fit.restype = C.c_int

@@ -257,6 +257,15 @@ int cvm_partition_labels(const int64_t *labels, int64_t N, int64_t n_labels, int
                         (hipStream_t)stream);
 }
 
+int cvm_partition_periodic(const int64_t *labels, int64_t N, int64_t n_labels, const void *w, int dtype,
+                           int64_t *idx_out, int64_t *offsets_out, int64_t *nz_out, int32_t *not_periodic, void *stream) {
+  if (!labels || !idx_out || !offsets_out || !not_periodic || N < 1)
+    return fail(CVM_EINVAL, "cvm_partition_periodic: bad argument%s");
+  if (dtype != CVM_F64 && dtype != CVM_F32) return fail(CVM_EINVAL, "cvm_partition_periodic: dtype must be CVM_F32 or CVM_F64%s");
+  return partition_periodic_impl(labels, N, n_labels, w, dtype, idx_out, offsets_out, nz_out, not_periodic,
+                                 (hipStream_t)stream);
+}
+
 size_t cvm_pls_workspace_bytes(int64_t n_folds, int K, int M, int A, int dtype) {
   if (n_folds < 0 || K <= 0 || M <= 0 || M > PLS_MAXM || A <= 0 || A > PLS_MAXA) return 0;
   return pls_workspace_bytes(n_folds, K, M, A, dtype == CVM_F64 ? 8 : 4, pls_cu_count());
@@ -353,7 +362,7 @@ int cvm_fill_probe(void *buf, size_t bytes, void *stream) {
   if (!buf || bytes % 16 || (uintptr_t)buf % 16) return fail(CVM_EINVAL, "cvm_fill_probe: 16-byte pieces%s");
   const size_t pieces = bytes / 16;
   if (!pieces) return CVM_OK;
-  hipLaunchKernelGGL(fill_probe_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (float *)buf, pieces);
+  hipLaunchKernelGGL(fill_probe_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float *)buf, pieces);
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }

@@ -21,12 +21,14 @@ template <typename V> __device__ __forceinline__ void out_store(V *p, V v) {
 #endif
 }
 
-// the write ceiling of the device with this kind of store (cvm_fill_probe): linear, 16 bytes per lane
+// the write ceiling of the device with this kind of store (cvm_fill_probe): one 16-byte piece per thread, one
+// workgroup per 4 KiB, in linear order.  (tools/fill_variants.hip: this shape reaches 6.7 TB/s where a
+// grid-stride loop of the same stores reaches 4.6-5.3 and 64 KiB per workgroup 5.2 -- the memory system wants
+// the stores that are in flight at one time to lie close together.)
 __global__ __launch_bounds__(256) void fill_probe_kernel(float *buf, size_t pieces) {
   typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 *p = reinterpret_cast<v4 *>(buf);
-  const v4 z = {0.f, 0.f, 0.f, 0.f};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (size_t)gridDim.x * 256) out_store(p + i, z);
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < pieces) out_store(reinterpret_cast<v4 *>(buf) + i, (v4){0.f, 0.f, 0.f, 0.f});
 }
 
 // Scaling by the training-set standard deviations (cvmatrix.py:1007-1010: XTX / (sd_a sd_b), XTY /
@@ -566,6 +568,12 @@ template <typename T, bool FOLD>
 __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void apply_kernel(const FinArgs a) {
   constexpr int NTHR = FOLD ? APPLY_THREADS : APPLY_THREADS_FIT;
   const Geom &g = a.g;
+  // ONE block of LDS for both kinds of workgroup (static arrays of different scopes are not overlaid by the
+  // compiler: the XTY workgroups' statistics buffers used to sit on top of the tile buffer and took every
+  // launch from four resident workgroups per CU to three): a tile workgroup uses [tile | its statistics], an
+  // XTY workgroup [xs_l | ys_l] in the same bytes
+  static_assert(2 * TILE + 2 * APPLY_INLINE_MAXM <= ST * (ST + 1) + 4 * ST, "the XTY workgroups' buffers fit the tile's");
+  __shared__ __attribute__((aligned(16))) double apply_lds[ST * (ST + 1) + 4 * ST];
   // fold mode: a 1-D launch of 8 * ceil(gx * gy / 8) workgroups; the 8 XCDs take workgroups
   // round-robin, so workgroup `lin` works on item (lin % 8) * per + lin / 8: every XCD gets a
   // contiguous range of (fold, sub-tile) -- neighbouring sub-tiles and the G tiles they read meet
@@ -613,8 +621,7 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     if (ti == tj && si > sj) return;                 // strictly lower: mirror of sub-tile (0,1)
     const int a0 = ti * TILE + si * ST, b0 = tj * TILE + sj * ST;
     if (a0 >= K || b0 >= K) return;
-    __shared__ __attribute__((aligned(16))) double sm[ST * (ST + 1)];
-    __shared__ double st_lds[4 * ST];
+    double *sm = apply_lds, *st_lds = apply_lds + ST * (ST + 1);
     double (*Ts)[ST + 1] = reinterpret_cast<double (*)[ST + 1]>(sm);
     constexpr int VW = 16 / sizeof(T);
     constexpr int LPR = ST / VW;
@@ -723,8 +730,7 @@ __global__ __launch_bounds__(FOLD ? APPLY_THREADS : APPLY_THREADS_FIT) void appl
     const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
     // inline_stats: this workgroup derives (and writes out) the X statistics of its 128 rows and, panel
     // 0, the Y statistics; M <= APPLY_INLINE_MAXM (the host checks)
-    __shared__ double xs_l[2 * TILE];
-    __shared__ double ys_l[2 * APPLY_INLINE_MAXM];
+    double *xs_l = apply_lds, *ys_l = apply_lds + 2 * TILE;
     if (inl) {
       const int tid = threadIdx.x;
       for (int q = tid; q < 2 * TILE; q += NTHR) {

@@ -8,6 +8,13 @@
 // ----------------------------------------------------------------------------------
 constexpr int TILE = 128;     // columns per panel; a workgroup owns a TILE x TILE output tile
 constexpr int STAGE_ROWS = 16;  // rows staged in LDS per pipeline stage (4 MFMA k-steps)
+#ifndef CVM_TWO_LEVEL
+#define CVM_TWO_LEVEL 1      // 0: the single-chain float32 accumulation of rounds 1-3 (comparisons)
+#endif
+#ifndef CVM_FOLD_STAGES
+#define CVM_FOLD_STAGES 64
+#endif
+constexpr int FOLD_STAGES = CVM_FOLD_STAGES;   // float32 Gram kernels: accumulator chains of at most FOLD_STAGES * 16 rows (a power of two)
 constexpr int PITCH = 144;    // LDS row pitch of a panel, in elements (see bank note below)
 constexpr int YT = 32;        // Y columns handled per diagonal work item (2 MFMA col tiles)
 constexpr int YPITCH = 48;    // LDS row pitch of the Y tile, in elements

@@ -208,3 +208,43 @@ inline int partition_impl(const int64_t *labels, int64_t N, int64_t L, int64_t *
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
+
+// Labels that are arange(N) % L -- the folds of the reference's benchmark (benchmarks/benchmark.py:232)
+// and, with L = N, leave-one-out -- need no sort: row r is the (r div L)-th row of fold r mod L.  ONE
+// launch checks that the labels are such (flag[0] = 1 otherwise: the caller then sorts), writes the
+// fold-major index array and the offsets by formula and counts every fold's non-zero weights
+// (integer atomics: order-independent).  partitioner.py:101-107 (first-seen order = 0 .. L-1 here).
+template <typename T>
+__global__ __launch_bounds__(256) void part_periodic_kernel(const int64_t *labels, int64_t N, int64_t L, const T *w,
+                                                            int64_t *idx_out, int64_t *offsets, int64_t *nz,
+                                                            int32_t *flag) {
+  const int64_t q = N / L, rem = N - q * L;       // folds f < rem have q + 1 rows, the others q
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (int64_t)gridDim.x * 256) {
+    const int64_t f = r % L, k = r / L;
+    if (labels[r] != f) { *flag = 1; continue; }
+    idx_out[f * q + (f < rem ? f : rem) + k] = r;
+    if (nz && (!w || w[r] != (T)0)) atomicAdd(reinterpret_cast<unsigned long long *>(nz + f), 1ull);
+    if (r <= L) offsets[r] = r * q + (r < rem ? r : rem);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && N <= L) {      // (N == L: offsets[L] has no row of its own)
+    for (int64_t f = N; f <= L; ++f) offsets[f] = f * q + (f < rem ? f : rem);
+  }
+}
+
+inline int partition_periodic_impl(const int64_t *labels, int64_t N, int64_t L, const void *w, int dtype,
+                                   int64_t *idx_out, int64_t *offsets, int64_t *nz, int32_t *flag, hipStream_t st) {
+  if (L < 1 || L > N) return fail(CVM_EINVAL, "cvm_partition_periodic: 1 <= n_labels <= N%s");
+  HIP_OK(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+  if (nz) HIP_OK(hipMemsetAsync(nz, 0, (size_t)L * sizeof(int64_t), st));
+  int64_t nb = (N + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (dtype == CVM_F64)
+    hipLaunchKernelGGL(part_periodic_kernel<double>, dim3((unsigned)nb), dim3(256), 0, st, labels, N, L, (const double *)w,
+                       idx_out, offsets, nz, flag);
+  else
+    hipLaunchKernelGGL(part_periodic_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, labels, N, L, (const float *)w,
+                       idx_out, offsets, nz, flag);
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+

@@ -38,6 +38,11 @@ struct PlsArgs {
   // copies of P^T and R^T ([fold][slice][2][A][K]), the folds' u exchange buffers ([fold][2][K])
   int nf, per_x;
   double *prw, *xu;
+  // the safe re-run behind a launch whose workgroups wait for each other (round 4): a kernel given
+  // run_if returns at once unless *run_if == 1 (a barrier of the launch before it timed out)
+  const int *run_if;
+  long spin_limit;                  // barrier spins before a slice gives up (1 << 21: seconds)
+  int skip_block;                   // tests only (CVM_PLS_TEST_TIMEOUT): this workgroup returns at once, -1: none
 };
 
 #ifdef CVM_STAMPS
@@ -121,7 +126,7 @@ template <bool SLICED> __device__ __forceinline__ double xget(const double *p) {
 // Every thread first waits for its own stores to be acknowledged, so the numbers are in place
 // before the arrival is counted.
 template <bool SLICED>
-__device__ __forceinline__ bool fold_barrier(unsigned *cnt, unsigned &target, int S, int *status, int *lflag) {
+__device__ __forceinline__ bool fold_barrier(unsigned *cnt, unsigned &target, int S, int *status, int *lflag, long spin_limit) {
   if constexpr (!SLICED) { __syncthreads(); return true; }
   target += (unsigned)S;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -139,7 +144,7 @@ __device__ __forceinline__ bool fold_barrier(unsigned *cnt, unsigned &target, in
     int ok = 1;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1L << 21)) { ok = 0; break; }      // seconds: the slices were not co-resident
+      if (++spins > spin_limit) { ok = 0; break; }      // (1 << 21: seconds) the slices were not co-resident
     }
     if (!ok) *status = 1;
     *lflag = ok;
@@ -499,6 +504,8 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
   unsigned long long stamp_ = __builtin_readcyclecounter();
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned char pls_smem[];
+  if (a.run_if && *a.run_if != 1) return;
+  if ((int)blockIdx.x == a.skip_block) return;
   const int K = a.K, M = a.M, A = a.A, S = SLICED ? a.S : 1;
   const int f = blockIdx.x / S, s = blockIdx.x - f * S;
   const int rows = a.rows;
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
       else if (M <= 48) pls_gram_phase_tri<3, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
       else pls_gram_phase_tri<4, SLICED>(Y, yst, n, M, ms, x_S + (size_t)s * MM, tid);
       PLS_STAMP(1);
-      if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+      if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag, a.spin_limit)) return;
       PLS_STAMP(2);
       // ---- 2a: dominant eigenvector q of the M x M sum, by repeated squaring -----------------
       // B_0 = S / trace; B_{t+1} = B_t^2 / trace(B_t^2): trace(B_t^2) = sum lambda^2 (trace 1
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
       }
     }
     PLS_STAMP(4);
-    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag, a.spin_limit)) return;
     PLS_STAMP(5);
     // ---- 3: normalise, r = w - R (P^T w) -----------------------------------------------------
     xreduce<SLICED>(x_2, 1 + c, S, cx, tid);
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
       if (a.R) ((T *)a.R)[((size_t)f * K + k0 + k) * A + c] = (T)r;
     }
     PLS_STAMP(6);
-    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag, a.spin_limit)) return;
     PLS_STAMP(7);
     // ---- 4: u = XTX[slice, :] r, partial r^T u and partial XTY^T r ---------------------------
     if constexpr (SLICED) {
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_kernel(const PlsArgs a) {
       if (lane == 0) xput<SLICED>(&x_4[(size_t)s * (1 + M) + 1 + j], acc);
     }
     PLS_STAMP(9);
-    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag)) return;
+    if (!fold_barrier<SLICED>(cnt, target, S, a.status, lflag, a.spin_limit)) return;
     PLS_STAMP(10);
     // ---- 5: p, q, deflation of the slice, B ---------------------------------------------------
     xreduce<SLICED>(x_4, 1 + M, S, qx, tid);
@@ -770,6 +777,7 @@ size_t pls_rep_lds_bytes(int K, int M, int A, int rows) {
 template <typename T>
 __global__ __launch_bounds__(PLS_THREADS) void pls_rep_kernel(const PlsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pls_smem[];
+  if ((int)blockIdx.x == a.skip_block) return;
   const int K = a.K, M = a.M, A = a.A, S = a.S;
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
   const int f = (bi / S) * 8 + xcd, s = bi - (bi / S) * S;      // fold g of the launch lives on XCD g % 8
@@ -906,7 +914,7 @@ __global__ __launch_bounds__(PLS_THREADS) void pls_rep_kernel(const PlsArgs a) {
         if (lane == 0) xput<true>(&xuc[k0 + i], acc);
       }
     }
-    if (!fold_barrier<true>(cnt, target, S, a.status, lflag)) return;
+    if (!fold_barrier<true>(cnt, target, S, a.status, lflag, a.spin_limit)) return;
     for (int k = tid; k < K; k += PLS_THREADS) ul[k] = xget<true>(&xuc[k]);
     __syncthreads();
     // ---- t^T t, q, p, deflation (all rows), B (the slice's rows) -------------------------------
@@ -1047,6 +1055,26 @@ int pls_cu_count() {
   return cus;
 }
 
+// After the safe re-run: status 1 (a barrier timed out) becomes 2 (timed out, every fold recomputed by one
+// workgroup each: the outputs are valid)
+__global__ void pls_recovered_kernel(int32_t *status) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *status == 1) *status = 2;
+}
+
+// The plan of the kernel that cannot wait for anybody: one workgroup per fold (S = 1).  False when a whole
+// fold's state does not fit the LDS budget (then a timed-out launch can only be poisoned).
+bool make_pls_plan_s1(int64_t F, int K, int M, int A, int esize, PlsPlan &p) {
+  if (pls_lds_bytes(K, M, A, K, 0, 0, 0, 0, esize) > PLS_LDS_BUDGET) return false;
+  const int64_t Fe = F > 0 ? F : 1;
+  p.S = 1; p.rows = K;
+  p.folds_per_launch = (int)(Fe < (1 << 20) ? Fe : (1 << 20));
+  p.xres = pls_lds_bytes(K, M, A, K, 0, 0, 0, 1, esize) <= PLS_LDS_BUDGET;
+  p.y_in_lds = pls_lds_bytes(K, M, A, K, 0, 1, 0, p.xres, esize) <= PLS_LDS_BUDGET;
+  p.pr_in_lds = pls_lds_bytes(K, M, A, K, 0, p.y_in_lds, 1, p.xres, esize) <= PLS_LDS_BUDGET;
+  p.lds = pls_lds_bytes(K, M, A, K, 0, p.y_in_lds, p.pr_in_lds, p.xres, esize);
+  return true;
+}
+
 // pls_rep_kernel's cut: few folds (at most 8 per XCD with at least 4 slices each), the whole deflated
 // XTY in LDS.  The slices of a fold sit on one XCD: per_x folds per XCD, S <= CUs-per-XCD / per_x.
 struct PlsRepPlan { int S, rows, per_x, folds_per_launch; size_t lds; };
@@ -1058,7 +1086,9 @@ bool make_pls_rep_plan(int64_t F, int K, int M, int A, int esize, int cus, PlsRe
   if (off || F < 1 || F > 64 || per_xcd < 8 || (size_t)K * K * esize > ((size_t)8 << 20)) return false;
   const int64_t Fl = F;                                             // folds per launch
   const int per_x = (int)((Fl + 7) / 8);
-  int S = per_xcd / per_x;
+  // (one CU per XCD is left out of the count: the slices spin on each other, and a CU that is busy with
+  //  something else -- another stream, a masked CU -- must not leave a slice without a place to run)
+  int S = (per_xcd - 1) / per_x;
   if (S > (K + 7) / 8) S = (K + 7) / 8;                             // >= 8 rows per slice
   if (S < 4) return false;                                          // many folds: one slice per fold is the better cut
   const int rows = (K + S - 1) / S;
@@ -1074,12 +1104,58 @@ size_t pls_workspace_bytes(int64_t F, int K, int M, int A, int esize, int cus) {
   if (!make_pls_plan(F, K, M, A, esize, cus, p)) return 0;
   const size_t per_fold = (2 * (size_t)K * M + 2 * (size_t)K * A + pls_xch_len(K, M, A, p.S)) * 8 + 16;
   size_t need = (size_t)F * per_fold + 256;
+  {   // the safe re-run's layout (S = 1) inside the same workspace
+    const size_t s1 = (size_t)F * ((2 * (size_t)K * M + 2 * (size_t)K * A + pls_xch_len(K, M, A, 1)) * 8 + 16) + 256;
+    if (s1 > need) need = s1;
+  }
   PlsRepPlan r;
   if (make_pls_rep_plan(F, K, M, A, esize, cus, r)) {
     const size_t rep = (size_t)F * ((size_t)r.S * 2 * A * K + 2 * (size_t)K) * 8 + (size_t)F * 16 + 256;
     if (rep > need) need = rep;
   }
   return need;
+}
+
+// CVM_PLS_TEST_TIMEOUT (tests only): workgroup 0 of the sliced launches returns at once and the others give
+// up after a few thousand spins, so that the safety net below is exercised
+inline bool pls_test_timeout() {
+  static const bool on = getenv("CVM_PLS_TEST_TIMEOUT") != nullptr;
+  return on;
+}
+
+// Behind a launch whose workgroups wait for each other: if a barrier timed out (status 1: a slice was not
+// resident -- another stream's kernel, a masked CU), every fold is recomputed by the kernel that waits for
+// nobody (one workgroup per fold; it returns at once when status is 0) and status becomes 2; where a whole
+// fold does not fit one workgroup's LDS the outputs are poisoned instead (NaN coefficients, n_fit -1).
+template <typename T>
+int pls_safety_net(const void *XTX, const void *XTY, int64_t F, int K, int M, int A, void *B, void *W, void *P, void *Q,
+                   void *R, int32_t *n_fit, int32_t *status, void *ws, hipStream_t st) {
+  PlsPlan p1;
+  if (make_pls_plan_s1(F, K, M, A, (int)sizeof(T), p1)) {
+    double *d = reinterpret_cast<double *>(ws);
+    PlsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.K = K; a.M = M; a.A = A; a.S = 1; a.rows = K; a.y_in_lds = p1.y_in_lds; a.pr_in_lds = p1.pr_in_lds;
+    a.Yw = d; d += (size_t)F * K * M;
+    a.Bw = d; d += (size_t)F * K * M;
+    a.Pw = d; d += (size_t)F * K * A;
+    a.Rw = d; d += (size_t)F * K * A;
+    a.xch = d; d += (size_t)F * pls_xch_len(K, M, A, 1);
+    a.cnt = reinterpret_cast<unsigned *>(d);
+    a.status = status; a.run_if = status; a.spin_limit = 1L << 21; a.skip_block = -1;
+    a.eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+    a.XTX = XTX; a.XTY = XTY; a.B = B; a.W = W; a.P = P; a.R = R; a.Q = Q; a.n_fit = n_fit;
+    void (*kern)(const PlsArgs) = p1.xres ? pls_kernel<T, true, false> : pls_kernel<T, false, false>;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p1.lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)F), dim3(PLS_THREADS), p1.lds, st, a);
+    hipLaunchKernelGGL(pls_recovered_kernel, dim3(1), dim3(64), 0, st, status);
+  } else {
+    hipLaunchKernelGGL((pls_poison_kernel<T>), dim3(256), dim3(256), 0, st, (const int *)status, (T *)B,
+                       (size_t)F * A * K * M, (T *)W, (T *)P, (T *)R, (size_t)F * K * A, (T *)Q, (size_t)F * M * A,
+                       (int *)n_fit, F);
+  }
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
 }
 
 template <typename T>
@@ -1101,6 +1177,8 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
     a.xu = d; d += (size_t)F * 2 * K;
     a.cnt = reinterpret_cast<unsigned *>(d);
     a.status = status;
+    a.spin_limit = pls_test_timeout() ? (1L << 12) : (1L << 21);
+    a.skip_block = pls_test_timeout() ? 0 : -1;
     a.eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
     hipLaunchKernelGGL(pls_zero_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, a.cnt, F, status);
     void (*kern)(const PlsArgs) = pls_rep_kernel<T>;
@@ -1127,11 +1205,7 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
       hipLaunchKernelGGL(kern, dim3((unsigned)(8 * rp.per_x * rp.S)), dim3(PLS_THREADS), rp.lds, st, b);
       HIP_OK(hipGetLastError());
     }
-    hipLaunchKernelGGL((pls_poison_kernel<T>), dim3(256), dim3(256), 0, st, (const int *)status, (T *)B,
-                       (size_t)F * A * K * M, (T *)W, (T *)P, (T *)R, (size_t)F * K * A, (T *)Q, (size_t)F * M * A,
-                       (int *)n_fit, F);
-    HIP_OK(hipGetLastError());
-    return CVM_OK;
+    return pls_safety_net<T>(XTX, XTY, F, K, M, A, B, W, P, Q, R, n_fit, status, ws, st);
   }
   double *d = reinterpret_cast<double *>(ws);
   PlsArgs a;
@@ -1144,6 +1218,8 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
   a.xch = d; d += (size_t)F * pls_xch_len(K, M, A, p.S);
   a.cnt = reinterpret_cast<unsigned *>(d);
   a.status = status;
+  a.spin_limit = pls_test_timeout() ? (1L << 12) : (1L << 21);
+  a.skip_block = (p.S > 1 && pls_test_timeout()) ? 0 : -1;
   a.eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
   // the barrier counters and the status word, zeroed by one small kernel (two runtime fills cost
   // two 5 us kernels in front of a 0.9 ms fit)
@@ -1181,12 +1257,7 @@ int pls_fit_impl(const void *XTX, const void *XTY, int64_t F, int K, int M, int 
     hipLaunchKernelGGL(kern, dim3((unsigned)(nf * p.S)), dim3(PLS_THREADS), p.lds, st, b);
     HIP_OK(hipGetLastError());
   }
-  if (p.S > 1) {
-    hipLaunchKernelGGL((pls_poison_kernel<T>), dim3(256), dim3(256), 0, st, (const int *)status, (T *)B,
-                       (size_t)F * A * K * M, (T *)W, (T *)P, (T *)R, (size_t)F * K * A, (T *)Q, (size_t)F * M * A,
-                       (int *)n_fit, F);
-    HIP_OK(hipGetLastError());
-  }
+  if (p.S > 1) return pls_safety_net<T>(XTX, XTY, F, K, M, A, B, W, P, Q, R, n_fit, status, ws, st);
   return CVM_OK;
 }
 

@@ -365,6 +365,21 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
   acc_t acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = (acc_t){0, 0, 0, 0};
+  // float32: two-level sums (round 4).  The MFMA accumulates a chain of float32 fmas over the rows; over
+  // thousands of rows that chain loses what a blocked GEMM keeps (the reference's sgemm sums in blocks:
+  // an unweighted, uncentred XTY of a 6000-row fold came out 8.7 roundings off against NumPy's 2.4).
+  // Every FOLD_STAGES stages (1024 rows) the accumulators are folded into a second set and restart from
+  // zero, so a chain is at most that long whatever the row-split plan; float64 keeps the single chain
+  // (1e-16 * rows is far below the bar).  Cost, same-box A/B at C5 (tools/exp_fold_stages.sh): a fold is 32
+  // packed adds + the moves that zero / carry the sets, in front of idle matrix cores -- every 256 rows
+  // +2.3 % on the Gram launch, every 1024 rows +0.5 %; a fold test INSIDE the stage loop cost 4 % by itself,
+  // hence the two nested loops below.
+  constexpr bool TWO_LEVEL = CVM_TWO_LEVEL && sizeof(T) == 4;
+  acc_t acc2[TWO_LEVEL ? 16 : 1];
+  if (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[i] = (acc_t){0, 0, 0, 0};
+  }
   double st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};
 
   const int lk = lane >> 4, lc = lane & 15;
@@ -456,8 +471,13 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
   // (unrolling this loop over the four LDS buffers to make every LDS address an immediate
   //  was tried: the role functions grow to 11-15 KB each, the instruction cache thrashes and
   //  the kernel loses 25 %)
+  // (two loops: the stage loop itself is the loop of rounds 1-3, untouched -- a fold test inside it cost
+  //  the float32 kernel 4 % whatever the fold interval -- and the float32 fold sits between two runs of it)
 #pragma unroll 1
-  for (int s = 0; s < nstages; ++s) {
+  for (int sb = 0; sb < nstages; sb += (TWO_LEVEL ? FOLD_STAGES : (1 << 30))) {
+  const int se = (TWO_LEVEL && sb + FOLD_STAGES < nstages) ? sb + FOLD_STAGES : nstages;
+#pragma unroll 1
+  for (int s = sb; s < se; ++s) {
 #ifdef CVM_STAMPS
     STAMP(t0);
     STAMP(t1);
@@ -522,6 +542,17 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
     STAMP(t3);
     t_a += t1 - t0; t_b += t2 - t1; t_c += t3 - t2;
 #endif
+  }
+  if constexpr (TWO_LEVEL) {
+    if (se < nstages) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc2[i] += acc[i]; acc[i] = (acc_t){0, 0, 0, 0}; }
+    }
+  }
+  }
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc2[i] + acc[i];
   }
 #ifdef CVM_STAMPS
   STAMP(c_loop1);
@@ -805,6 +836,14 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   for (int i = 0; i < NG; ++i) acc[i] = (acc_t){0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < NX * NBY; ++i) acch[i] = (acc_t){0, 0, 0, 0};
+  constexpr bool TWO_LEVEL = CVM_TWO_LEVEL && sizeof(T) == 4;      // float32: two-level sums, see wgram4_body
+  acc_t acc2[TWO_LEVEL ? NG : 1], acch2[TWO_LEVEL ? NX * NBY : 1];
+  if (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) acc2[i] = (acc_t){0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NX * NBY; ++i) acch2[i] = (acc_t){0, 0, 0, 0};
+  }
   double st_s[2] = {0, 0}, st_q[2] = {0, 0};
   double sy[NBY], qy[NBY], sw_ = 0, nz_ = 0, ng_ = 0;
 #pragma unroll
@@ -864,7 +903,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   read_frags(smem, 0, 0);
   prepare(0);
 #pragma unroll 1
-  for (int s = 0; s < nstages; ++s) {
+  for (int sb = 0; sb < nstages; sb += (TWO_LEVEL ? FOLD_STAGES : (1 << 30))) {
+  const int se = (TWO_LEVEL && sb + FOLD_STAGES < nstages) ? sb + FOLD_STAGES : nstages;
+#pragma unroll 1
+  for (int s = sb; s < se; ++s) {
     const T *buf = smem + (s % NBUF4) * BUF_ELEMS;
     const T *nbuf = smem + ((s + 1) % NBUF4) * BUF_ELEMS;
 #pragma unroll
@@ -904,6 +946,21 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
 #endif
     }
     __syncthreads();   // B_s
+  }
+  if constexpr (TWO_LEVEL) {
+    if (se < nstages) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) { acc2[i] += acc[i]; acc[i] = (acc_t){0, 0, 0, 0}; }
+#pragma unroll
+      for (int i = 0; i < NX * NBY; ++i) { acch2[i] += acch[i]; acch[i] = (acc_t){0, 0, 0, 0}; }
+    }
+  }
+  }
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) acc[i] = acc2[i] + acc[i];
+#pragma unroll
+    for (int i = 0; i < NX * NBY; ++i) acch[i] = acch2[i] + acch[i];
   }
 
   if constexpr (FUSEDR) {

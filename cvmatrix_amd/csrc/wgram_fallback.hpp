@@ -151,6 +151,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   acc_t acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = (acc_t){0, 0, 0, 0};
+  constexpr bool TWO_LEVEL = CVM_TWO_LEVEL && sizeof(T) == 4;      // float32: two-level sums, see wgram4_body (wgram4.hpp)
+  acc_t acc2[TWO_LEVEL ? 8 : 1];
+  if (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc2[i] = (acc_t){0, 0, 0, 0};
+  }
   // column-sum accumulators; meaning depends on the wave's role (see the k-step loop)
   double st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};
   const int stat_role = (h_wave && yc == 0) ? 1 : ((diag && ti == 0 && wave == 0) ? 2 : 0);
@@ -274,6 +280,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
 #ifdef CVM_STAMPS
     STAMP(t2);
 #endif
+    if constexpr (TWO_LEVEL) {
+      if (MFM && (s & (FOLD_STAGES - 1)) == FOLD_STAGES - 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc2[i] += acc[i]; acc[i] = (acc_t){0, 0, 0, 0}; }
+      }
+    }
     if (LD) write_lds((s + 1) & 1);
     ring_store(s + 3, ring_next);   // slot (s%3) was last read for stage s, one barrier ago
     __syncthreads();
@@ -294,6 +306,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgram_kernel(const WgramArgs<T> a
   else if (h_wave) { if (yc == 0) run(std::true_type{}, R1{}); else run(std::true_type{}, R0{}); }
   else if (stat_role == 2) { if (do_g) run(std::true_type{}, R2{}); else run(std::false_type{}, R2{}); }
   else { if (do_g) run(std::true_type{}, R0{}); else run(std::false_type{}, R0{}); }
+  if constexpr (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = acc2[i] + acc[i];
+  }
 #ifdef CVM_STAMPS
   if (lane == 0 && blockIdx.x < 1024) {
     unsigned long long *o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 4;

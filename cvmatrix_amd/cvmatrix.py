@@ -17,6 +17,7 @@ There is no CPU path in this module: it raises if the extension or a GPU is miss
 
 from __future__ import annotations
 
+import contextlib
 import os
 import weakref
 
@@ -173,6 +174,7 @@ class CVMatrix:
         lazy_fit: Optional[bool] = None,
         output: str = "torch",
         serve_loops: Optional[bool] = None,
+        reuse_outputs: bool = False,
     ) -> None:
         # ``lazy_fit=None`` (default): ``fit`` may defer its arithmetic to the first use only
         # when the object owns private copies of its inputs (``copy=True``, like the reference's
@@ -194,6 +196,15 @@ class CVMatrix:
         if serve_loops is None:
             serve_loops = os.environ.get("CVM_SERVE_LOOPS", "1") != "0"
         self.serve_loops = bool(serve_loops)
+        # ``reuse_outputs`` (default off: every call returns fresh tensors, like the reference returns fresh
+        # arrays): the full-data matrices and the batched outputs / statistics of a call are written into
+        # buffers the object keeps while shapes repeat, so a loop of fit + batched call allocates nothing --
+        # results of an earlier call (and the XTX / XTY attributes of an earlier fit) are OVERWRITTEN by the
+        # next one.  For loops that consume each step's results before the next step (a multi-GPU rank's
+        # step is shorter than the allocations it would otherwise issue).
+        self.reuse_outputs = bool(reuse_outputs)
+        self._arena = {}
+        self._fit_src = None
         # ``output="numpy"``: every result (matrices, statistics, the XTX/XTY/sum_* attributes)
         # is returned as a NumPy array like the reference's backend="numpy"; "torch" (default)
         # leaves results on the device, like the reference's backend="jax" returns jax.Array
@@ -502,6 +513,12 @@ class CVMatrix:
             t = t.clone()
         return t
 
+    def _on_device(self):
+        """Context in which ``self.device`` is current (nothing to switch when it already is)."""
+        if torch.cuda.current_device() == self.device.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(self.device)
+
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
@@ -541,28 +558,35 @@ class CVMatrix:
         self._auto_sweep_tried = None
         self._pending = False
         self._np_cache = {}
-        with torch.cuda.device(self.device):
-            Ku = self._cols_of(X)
-            Mu = self._cols_of(Y) if Y is not None else None
-            self._Kd, Md = self._device_dims(Ku, Mu or 0)
-            self.X = self._init_mat(X, self._Kd)         # (a view of the padded copy when padded)
-            self.N, self._Ku = self.X.shape
-            if Y is not None:
-                self.Y = self._init_mat(Y, Md)
-                self._Mu, self._Md = self.Y.shape[1], Md
-                if self.Y.shape[0] != self.N:
-                    raise ValueError("X and Y must have the same number of rows")
-            else:
-                self.Y, self._Mu, self._Md = None, None, None
-            if weights is not None:
-                self._check_weights_host(weights)
-                self.weights = self._init_mat(weights)
-                if self.weights.shape != (self.N, 1):
-                    raise ValueError("weights must have shape (N,) or (N, 1)")
-            else:
-                if self.weights is not None or self._w_host is not None:
-                    self._w_gen = _NO_WEIGHTS
-                self.weights, self._w_host, self._w_checked, self._w_checked_src = None, None, None, None
+        with self._on_device():
+            # the same device tensors as the last fit of this object, unmodified since (object identity +
+            # torch's version counter, which every in-place write through any view bumps): the device
+            # copies / aliases, the validated weights and the shapes of that fit are still right
+            same = self._same_fit_inputs(X, Y, weights)
+            if not same:
+                self._fit_src = None
+                Ku = self._cols_of(X)
+                Mu = self._cols_of(Y) if Y is not None else None
+                self._Kd, Md = self._device_dims(Ku, Mu or 0)
+                self.X = self._init_mat(X, self._Kd)         # (a view of the padded copy when padded)
+                self.N, self._Ku = self.X.shape
+                if Y is not None:
+                    self.Y = self._init_mat(Y, Md)
+                    self._Mu, self._Md = self.Y.shape[1], Md
+                    if self.Y.shape[0] != self.N:
+                        raise ValueError("X and Y must have the same number of rows")
+                else:
+                    self.Y, self._Mu, self._Md = None, None, None
+                if weights is not None:
+                    self._check_weights_host(weights)
+                    self.weights = self._init_mat(weights)
+                    if self.weights.shape != (self.N, 1):
+                        raise ValueError("weights must have shape (N,) or (N, 1)")
+                else:
+                    if self.weights is not None or self._w_host is not None:
+                        self._w_gen = _NO_WEIGHTS
+                    self.weights, self._w_host, self._w_checked, self._w_checked_src = None, None, None, None
+                self._remember_fit_inputs(X, Y, weights)
             M = self._Md or 0
             self._alloc_globals(lib.cvm_gstats_len(self._Kd, M))
             self._neg = None
@@ -578,6 +602,32 @@ class CVMatrix:
         if not self._pending:
             self._after_globals()
 
+    @staticmethod
+    def _tensor_key(t):
+        return None if t is None else (id(t), t._version, t.data_ptr())
+
+    def _remember_fit_inputs(self, X, Y, weights) -> None:
+        """What ``fit`` was given, if all of it is device tensors (kept referenced, so that an address cannot
+        be recycled by another tensor), with the version counters of that moment -- and the versions of the
+        device copies this object made of them."""
+        if self.serve_loops and all(t is None or (isinstance(t, torch.Tensor) and t.is_cuda) for t in (X, Y, weights)):
+            self._fit_src = ((X, Y, weights), tuple(self._tensor_key(t) for t in (X, Y, weights)),
+                             tuple(self._tensor_key(t) for t in (self.X, self.Y, self.weights)))
+        else:
+            self._fit_src = None
+
+    def _same_fit_inputs(self, X, Y, weights) -> bool:
+        src = self._fit_src
+        if src is None or self.X is None:
+            return False
+        (x0, y0, w0), keys, own = src
+        if X is not x0 or Y is not y0 or weights is not w0:
+            return False
+        if tuple(self._tensor_key(t) for t in (X, Y, weights)) != keys:
+            return False
+        # (the object's own copies may have been written through the public attributes)
+        return tuple(self._tensor_key(t) for t in (self.X, self.Y, self.weights)) == own
+
     def _alloc_globals(self, n_gstats: int) -> None:
         """``XTX``, ``XTY`` and the float64 statistics vector as views of ONE contiguous
         buffer ``[G | H | gstats]`` (float64 problems): the multi-GPU exchange is then a single
@@ -585,6 +635,11 @@ class CVMatrix:
         tensors (the statistics stay float64)."""
         K, M, dev = self._Kd, self._Md or 0, self.device
         hasY = self.Y is not None
+        if self.reuse_outputs:
+            key = (K, M, hasY, n_gstats, self._tdt, dev)
+            if self._arena.get("globals") == key:
+                return                                # (the buffers of the last fit: same shapes)
+            self._arena["globals"] = key
         if self._tdt == torch.float64:
             nG, nH = K * K, (K * M if hasY else 0)
             flat = torch.empty(nG + nH + n_gstats, dtype=torch.float64, device=dev)
@@ -951,10 +1006,15 @@ class CVMatrix:
                     codes = np.fromiter((seen.setdefault(v, len(seen)) for v in labels), dtype=np.int64, count=arr.size)
                     keys = list(seen)
                 else:
-                    import pandas as pd
-
-                    codes, uniq = pd.factorize(arr, sort=False, use_na_sentinel=False)
-                    keys = list(uniq)
+                    # sorted unique values with the index of their first appearance, re-ranked by
+                    # that index = codes in first-seen order.  equal_nan=False: every NaN is a label
+                    # of its own, like in the reference's dict (nan != nan) and in Partitioner
+                    uniq, first_idx, inv = np.unique(arr, return_index=True, return_inverse=True, equal_nan=False)
+                    seen_order = np.argsort(first_idx, kind="stable")
+                    rank = np.empty(uniq.size, dtype=np.int64)
+                    rank[seen_order] = np.arange(uniq.size, dtype=np.int64)
+                    codes = rank[np.asarray(inv).reshape(-1)]
+                    keys = list(uniq[seen_order])
                 labels, n_labels = np.asarray(codes, dtype=np.int64), len(keys)
         with torch.cuda.device(dev):
             if isinstance(labels, torch.Tensor):
@@ -973,23 +1033,23 @@ class CVMatrix:
                 raise ValueError(f"fold labels must be integers in [0, {L})")
             if 1 <= L <= self.N:
                 # the strided folds of the reference's benchmark (benchmarks/benchmark.py:232) and
-                # leave-one-out: row r is the (r // L)-th row of fold r % L -- no sort needed
-                r = torch.arange(self.N, dtype=torch.int64, device=dev)
-                f_of = r % L
-                if torch.equal(lab, f_of):
+                # leave-one-out: row r is the (r // L)-th row of fold r % L -- no sort needed.  One
+                # launch checks the labels, lays the folds out and counts their non-zero weights
+                # (cvm_partition_periodic); one read-back brings the verdict and the counts
+                d_idx = torch.empty(self.N, dtype=torch.int64, device=dev)
+                d_off = torch.empty(L + 1, dtype=torch.int64, device=dev)
+                tail = torch.empty(L + 1, dtype=torch.int64, device=dev)      # [nz of every fold | flag]
+                wt = self.weights
+                rc = lib.cvm_partition_periodic(lab.data_ptr(), self.N, L, _lib.ptr(wt), self._cdt, d_idx.data_ptr(),
+                                                d_off.data_ptr(), tail.data_ptr() if wt is not None else None,
+                                                tail.data_ptr() + 8 * L, self._stream())
+                _lib.check(rc, "cvm_partition_periodic")
+                h_tail = tail.cpu().numpy()
+                if int(h_tail[L:].view(np.int32)[0]) == 0:
                     sizes = (self.N - np.arange(L) + L - 1) // L
                     host_offsets = np.zeros(L + 1, dtype=np.int64)
                     np.cumsum(sizes, out=host_offsets[1:])
-                    d_off = torch.from_numpy(host_offsets).to(dev)
-                    d_idx = torch.empty(self.N, dtype=torch.int64, device=dev)
-                    d_idx[d_off[f_of] + torch.div(r, L, rounding_mode="floor")] = r
-                    if self.weights is not None:
-                        nzmask = (self.weights.reshape(-1) != 0).to(torch.int64)
-                        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
-                                          torch.cumsum(nzmask[d_idx], 0)])
-                        nz_val = (csum[d_off[1:]] - csum[d_off[:-1]]).cpu().numpy()
-                    else:
-                        nz_val = sizes.astype(np.int64)
+                    nz_val = h_tail[:L].copy() if wt is not None else sizes.astype(np.int64)
                     return FoldBatch(d_idx, d_off, host_offsets, nz_val,
                                      list(range(L)) if keys is None else [keys[i] for i in range(L)], None, self.N,
                                      w_gen=self._w_gen)
@@ -1088,24 +1148,35 @@ class CVMatrix:
                  | (_lib.CENTER_X if cX else 0) | (_lib.CENTER_Y if cY else 0)
                  | (_lib.SCALE_X if sX else 0) | (_lib.SCALE_Y if sY else 0))
         dev, dt = self.device, self._tdt
-        with torch.cuda.device(dev):
+        with self._on_device():
             mats = not stats_only
-            out_XTX = torch.empty((P, K, K), dtype=dt, device=dev) if (rXTX and mats) else None
-            out_XTY = torch.empty((P, K, M), dtype=dt, device=dev) if (rXTY and mats) else None
-            # the four statistics: one allocation [muX | sdX | muY | sdY], each block [P, 1, *]
-            stat = torch.empty(P * (2 * K + 2 * M), dtype=dt, device=dev)
-            muX, sdX = stat[:P * K].view(P, 1, K), stat[P * K:2 * P * K].view(P, 1, K)
-            muY = stat[2 * P * K:2 * P * K + P * M].view(P, 1, M) if M else None
-            sdY = stat[2 * P * K + P * M:].view(P, 1, M) if M else None
+            akey = ("run", P, K, M, bool(rXTX and mats), bool(rXTY and mats), dt, dev)
+            held = self._arena.get(akey) if self.reuse_outputs else None
+            if held is not None:
+                out_XTX, out_XTY, muX, sdX, muY, sdY, neg_held = held
+            else:
+                out_XTX = torch.empty((P, K, K), dtype=dt, device=dev) if (rXTX and mats) else None
+                out_XTY = torch.empty((P, K, M), dtype=dt, device=dev) if (rXTY and mats) else None
+                # the four statistics: one allocation [muX | sdX | muY | sdY], each block [P, 1, *]
+                stat = torch.empty(P * (2 * K + 2 * M), dtype=dt, device=dev)
+                muX, sdX = stat[:P * K].view(P, 1, K), stat[P * K:2 * P * K].view(P, 1, K)
+                muY = stat[2 * P * K:2 * P * K + P * M].view(P, 1, M) if M else None
+                sdY = stat[2 * P * K + P * M:].view(P, 1, M) if M else None
+                neg_held = None
+                if self.reuse_outputs:
+                    neg_held = torch.empty(1, dtype=torch.int32, device=dev)
+                    self._arena[akey] = (out_XTX, out_XTY, muX, sdX, muY, sdY, neg_held)
             out_fold = None       # (per-fold [sw_T, nz_T, sw_V, nz_V]: diagnostics, not requested)
             if sweep_all:
                 import ctypes as C
 
-                want = lib.cvm_sweep_workspace_bytes(P, int(batch.sizes.max()), K, M, self._cdt)
-                if (getattr(self, "_sweep_ws", None) is None or self._sweep_ws.numel() < want
-                        or self._sweep_ws.device != dev):
-                    self._sweep_ws = torch.empty(int(want), dtype=torch.uint8, device=dev)
-                neg = torch.empty(1, dtype=torch.int32, device=dev)
+                skey = (P, int(batch.sizes.max()), K, M, self._cdt)
+                if self._arena.get("sweep_ws_key") != skey or self._sweep_ws is None or self._sweep_ws.device != dev:
+                    want = lib.cvm_sweep_workspace_bytes(*skey)
+                    if self._sweep_ws is None or self._sweep_ws.numel() < want or self._sweep_ws.device != dev:
+                        self._sweep_ws = torch.empty(int(want), dtype=torch.uint8, device=dev)
+                    self._arena["sweep_ws_key"] = skey
+                neg = neg_held if neg_held is not None else torch.empty(1, dtype=torch.int32, device=dev)
                 token = C.c_int64(0)
                 self._pending = False
                 rc = lib.cvm_sweep_all(

@@ -49,9 +49,12 @@ def pls_fit_batched(XTX: torch.Tensor, XTY: torch.Tensor, A: int, *, return_fact
     """Fit A-component PLS models on ``XTX`` (F,K,K) / ``XTY`` (F,K,M) device tensors (the
     outputs of ``training_XTX_XTY_batched``; a single (K,K)/(K,M) pair is taken as F = 1).
 
-    ``check=True`` synchronises once to turn the kernel's status word into an exception;
-    with ``check=False`` a timed-out barrier (slices of a fold not co-resident) still cannot go
-    unnoticed: the library then overwrites every coefficient with NaN and every ``n_fit`` with -1."""
+    The routes that cut a fold into slices need an otherwise idle device (the slices of a fold wait for each
+    other; ``CVM_PLS_NO_REP`` opts out of the one-barrier route).  If a slice finds no place to run, the
+    barrier times out and the library recomputes every fold with one workgroup per fold in the same call;
+    only where a fold does not fit one workgroup's LDS are the outputs overwritten with NaN (``n_fit`` -1) --
+    ``check=True`` synchronises once to turn that case into an exception.  Nothing half-written is ever
+    returned."""
     if not (isinstance(XTX, torch.Tensor) and XTX.is_cuda and isinstance(XTY, torch.Tensor) and XTY.is_cuda):
         raise TypeError("pls_fit_batched takes device tensors (the batched training matrices).")
     if XTX.dim() == 2:
@@ -92,9 +95,19 @@ def pls_fit_batched(XTX: torch.Tensor, XTY: torch.Tensor, A: int, *, return_fact
                              _lib.ptr(ws), nbytes, stream)
         _lib.check(rc, "cvm_pls_fit")
         ws.record_stream(torch.cuda.current_stream(dev))
-        if check and int(status.item()) != 0:
-            raise RuntimeError("cvm_pls_fit: workgroups of a fold were not co-resident (barrier timed out).")
+        # status 0: fine; 2: a barrier of the sliced launch timed out (a slice was not resident: another
+        # stream's kernel on the device, a masked CU) and the library recomputed every fold with the kernel that
+        # waits for nobody -- the outputs are valid; 1: it could not (a fold does not fit one workgroup's LDS):
+        # the outputs are NaN / n_fit -1
+        if check:
+            st_ = int(status.item())
+            pls_fit_batched.last_status = st_          # (0 or 2 after a successful call: tests, diagnostics)
+            if st_ == 1:
+                raise RuntimeError("cvm_pls_fit: workgroups of a fold were not co-resident (barrier timed out).")
     return PLSFit(B, W, P, Q, R, n_fit)
+
+
+pls_fit_batched.last_status = None
 
 
 def pls_validation_sse(cvm, folds, stats, B: torch.Tensor):
@@ -114,10 +127,23 @@ def pls_validation_sse(cvm, folds, stats, B: torch.Tensor):
     if cvm._Kd != cvm._Ku or (cvm._Md or 0) != (cvm._Mu or 0) or cvm.output != "torch" or cvm._out_cast:
         raise ValueError("pls_validation_sse takes device results of an unpadded float32 / float64 model "
                          "(K even, float64: M even, or copy=False).")
+    # one element type and one device for everything the kernel reads: it reinterprets X, Y, the
+    # weights, the statistics and B at B's element size
+    dev = cvm.X.device
+    if B.dtype != cvm.X.dtype or B.device != dev:
+        raise ValueError(f"B is {B.dtype} on {B.device}, the model {cvm.X.dtype} on {dev}: pls_validation_sse "
+                         "takes the coefficients of THIS model's training matrices.")
+    for name, t, width in (("mean of X", muX, K), ("std of X", sdX, K), ("mean of Y", muY, M), ("std of Y", sdY, M)):
+        if t is None:
+            continue
+        if t.dtype != B.dtype or t.device != dev or t.numel() != F * width:
+            raise ValueError(f"the {name} is not the statistics output of these folds "
+                             f"({tuple(t.shape)} {t.dtype} on {t.device}; wanted {F} x {width} {B.dtype} on {dev}).")
     lib = _lib.load()
-    dev = B.device
     B = B.contiguous()
     code = _lib.CVM_F64 if B.dtype == torch.float64 else _lib.CVM_F32
+    # (the longest fold, from the batch's own host offsets -- never a caller's estimate: the kernel
+    #  cuts every fold into that many row chunks)
     max_rows = int(batch.sizes.max()) if batch.n_folds else 0
     with torch.cuda.device(dev):
         nbytes = lib.cvm_pls_sse_workspace_bytes(F, max_rows, M, A)

@@ -179,6 +179,17 @@ int cvm_partition_labels(const int64_t *labels, int64_t N, int64_t n_labels, int
                          int64_t *offsets_out, int64_t *first_out, int32_t *err_flag, void *ws,
                          size_t ws_bytes, void *stream);
 
+/* Labels that are arange(N) % n_labels (the reference benchmark's folds, benchmarks/benchmark.py:232;
+ * n_labels == N: leave-one-out) need no sort.  One launch: checks the labels (not_periodic[0] = 1 if
+ * they are anything else -- the outputs are then garbage and the caller runs cvm_partition_labels),
+ * writes idx_out int64[N] (fold-major, rows ascending inside a fold), offsets_out int64[n_labels + 1]
+ * and, if nz_out is not NULL, every fold's number of rows with a non-zero weight (w NULL: its row
+ * count) -- what cvm_fold_update's host-side checks need (cvmatrix.py:612-630).  Replaces
+ * Partitioner._init_folds_dict (partitioner.py:89-107) for such labels. */
+int cvm_partition_periodic(const int64_t *labels, int64_t N, int64_t n_labels, const void *w, int dtype,
+                           int64_t *idx_out, int64_t *offsets_out, int64_t *nz_out, int32_t *not_periodic,
+                           void *stream);
+
 /* The step after the path: Improved Kernel PLS, algorithm #2 of Dayal &
  * MacGregor (1997), on the training matrices of a batch of folds where cvm_fold_update left them.
  * It is what the out-of-tree consumer named by the reference runs per fold (reference
@@ -189,7 +200,11 @@ int cvm_partition_labels(const int64_t *labels, int64_t N, int64_t n_labels, int
  *   B   [n_folds][A][K][M]   B[f][a] = regression coefficients with a+1 components (required)
  *   W, P, R [n_folds][K][A], Q [n_folds][M][A]      weights / loadings / rotations (each may be NULL)
  *   n_fit  int32[n_folds]    components extracted (< A only if XTY deflated to zero: the rest stay 0)
- *   status int32[1]          0; 1 if the kernel gave up waiting for a co-resident workgroup
+ *   status int32[1]          0; the routes that cut a fold into slices need an otherwise idle device (the
+ *                            slices wait for each other): if a slice found no place to run, every fold is
+ *                            recomputed in the same call by one workgroup per fold and status is 2 (outputs
+ *                            valid); 1 only where a fold does not fit one workgroup's LDS -- the outputs are
+ *                            then NaN and n_fit -1, never half-written
  * Component signs are those of the dominant eigenvector found by repeated squaring of XTY^T XTY;
  * B does not depend on them.  Arithmetic in float64 for both dtypes. */
 size_t cvm_pls_workspace_bytes(int64_t n_folds, int K, int M, int A, int dtype);

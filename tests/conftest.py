@@ -17,6 +17,9 @@ STAT_NAMES = ("muX", "sdX", "muY", "sdY")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "serving: looks INSIDE the loop-serving short cuts (nothing to see under "
+                                       "CVM_SERVE_LOOPS=0: tools/route_matrix.sh deselects exactly these)")
+    config.addinivalue_line("markers", "planner_plan: asserts the planner's own row-split plan (moot under CVM_FORCE_SPLITS)")
 
 
 def load_npz(name):

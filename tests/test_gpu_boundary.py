@@ -91,6 +91,7 @@ def test_default_fit_is_eager_for_aliased_inputs_and_lazy_for_private_copies(amd
     assert torch.equal(eager.XTX, G)            # the eager one computed inside fit()
 
 
+@pytest.mark.serving
 def test_weights_are_validated_again_when_a_new_tensor_reuses_the_address(amd, hip_device):
     """the device-weights validation cache must not be fooled by a recycled address."""
     import torch
@@ -168,6 +169,7 @@ def test_fit_that_raises_leaves_no_pending_state(amd):
     assert not m._pending and m._sweep is None
 
 
+@pytest.mark.serving
 def test_reference_loop_is_served_from_one_sweep(amd, hip_device):
     """The reference's loop -- fit, then training_XTX_XTY(p.get_validation_indices(fold)) per fold --
     with the default (lazy, private copies) object: the first call recognises the Partitioner's
@@ -234,6 +236,7 @@ def test_reference_loop_is_served_from_one_sweep(amd, hip_device):
     assert m3._sweep is None and not m3._pending
 
 
+@pytest.mark.serving
 @pytest.mark.parametrize("N,K,M,labels_kind,dtype", [(700, 50, 3, "loo", np.float64), (6000, 36, 2, "mod150", np.float64),
                                                      (5000, 40, 0, "random400", np.float64), (900, 64, 1, "loo", np.float32)])
 def test_per_fold_loop_over_many_folds_is_read_ahead(amd, N, K, M, labels_kind, dtype):
@@ -332,6 +335,7 @@ def _oracle_fold(X, Y, w, v, dtype=np.float64):
     return o.training_XTX_XTY(np.array(v, copy=True))
 
 
+@pytest.mark.serving
 @pytest.mark.parametrize("route", ["sweep_loop", "sweep_loop_second_pass", "cached_batch", "read_ahead"])
 @pytest.mark.parametrize("change", ["one_interior_index", "sum_preserving_pair"])
 def test_indices_changed_in_place_are_never_served_stale(amd, route, change):
@@ -394,6 +398,7 @@ def test_indices_changed_in_place_are_never_served_stale(amd, route, change):
     assert_normwise(xtx, ox, 1e-10, "restored")
 
 
+@pytest.mark.serving
 def test_serve_loops_off_recomputes_every_call(amd, monkeypatch):
     """``CVMatrix(serve_loops=False)`` / CVM_SERVE_LOOPS=0: no sweep for the loop, no read-ahead, no
     kept batches, no weights identity cache -- every call launches its own kernels on what it is

@@ -97,17 +97,21 @@ def test_g3_leave_one_out_sweep(amd, chunk):
 # float32 where OpenBLAS blocks its sums), so the allowance is eight.  The 2e-5 / 2e-6 floors of
 # rounds 1-2 were never needed.
 FP32_EPS = float(np.finfo(np.float32).eps)
+# Round 4: the float32 Gram kernels fold their accumulators into a second set every 256 rows (two-level
+# sums, like the blocked sgemm of the reference's BLAS), whatever the row-split plan: the allowance on top
+# of twice the yardstick is back to two roundings (result and yardstick are both float32 arrays: where the
+# yardstick is itself one rounding, "twice" is below the resolution of the comparison).
 # float32 statistics against the float64 oracle on the same float32 inputs: the product sums in
 # float64 and rounds once, so means agree to a rounding; a standard deviation is the root of a
 # difference of sums and may lose a few more
 F32_STAT_RTOL = 2e-6
-FP32_FLOOR = 8 * FP32_EPS
+FP32_FLOOR = 2 * FP32_EPS
 
 
 def assert_fp32_like_reference(got, ref64, ref32, what, floor=FP32_FLOOR):
     """BASELINE.md section 4 for float32: the error against the float64 reference is at most
     twice the error of the reference's own float32 arithmetic (`ref32`: the oracle run in
-    float32 on the same float32 inputs), plus eight float32 roundings of the scale."""
+    float32 on the same float32 inputs), plus two float32 roundings of the scale."""
     got = to_np(got).astype(np.float64)
     ref64 = np.asarray(ref64, dtype=np.float64)
     ref32 = np.asarray(ref32, dtype=np.float64)
@@ -216,7 +220,7 @@ def test_g6_digest_fp64(amd, name):
 
 def test_g6_digest_fp32_c5_scaled(amd):
     """C5 shape (K=4096, M=1, fp32), N scaled to 8000: fp32 result vs the fp64 reference
-    must be no worse than 2x the reference's own fp32 error (+ eight float32 roundings of the scale)."""
+    must be no worse than 2x the reference's own fp32 error (+ two float32 roundings of the scale)."""
     name = "c5s"
     z = load_npz("g6_digest.npz")
     meta = load_json("g6_digest_meta.json")[name]
@@ -1082,7 +1086,7 @@ def test_device_partitioner_matches_host_partitioner(amd, N, L):
         m.prepare_folds_from_labels(bad, n_labels=L)
 
 
-@pytest.mark.parametrize("kind", ["str", "float", "object"])
+@pytest.mark.parametrize("kind", ["str", "float", "float_nan", "object"])
 def test_device_partitioner_takes_any_hashable_label(amd, kind):
     """partitioner.py:101-107 groups labels of any hashable kind: strings, floats and mixed objects go
     through ``prepare_folds_from_labels`` too (factorised on the host in first-seen order, grouped on
@@ -1094,6 +1098,10 @@ def test_device_partitioner_takes_any_hashable_label(amd, kind):
         labels = np.array([f"site-{c:02d}" for c in codes])
     elif kind == "float":
         labels = codes.astype(np.float64) * 0.5 - 3.25
+    elif kind == "float_nan":
+        # nan != nan: every NaN label is a fold of its own in the reference's dict (partitioner.py:101-107)
+        labels = codes.astype(np.float64) * 0.5 - 3.25
+        labels[[7, 1234, 4999]] = np.nan
     else:
         pool = [("a", 1), "b", 2.5, 7, None, frozenset({3})] + [f"k{i}" for i in range(17)]
         labels = [pool[c] for c in codes]
@@ -1102,7 +1110,12 @@ def test_device_partitioner_takes_any_hashable_label(amd, kind):
     part = amd.Partitioner(labels)
     hb = m.prepare_folds(part)
     db = m.prepare_folds_from_labels(labels)
-    assert db.labels == list(part.folds_dict)
+    if kind == "float_nan":
+        assert len(db.labels) == len(part.folds_dict)
+        assert sum(1 for v in db.labels if v != v) == 3            # three NaN rows, three folds of one row
+        assert all(a == b or (a != a and b != b) for a, b in zip(db.labels, part.folds_dict))
+    else:
+        assert db.labels == list(part.folds_dict)
     assert np.array_equal(db.host_offsets, hb.host_offsets)
     assert bool((db.idx == hb.idx).all()) and np.array_equal(db.nz_val, hb.nz_val)
     a, _ = m.training_XTX_batched(hb)
@@ -1316,6 +1329,24 @@ def test_bench_command_two_ranks_strong_scaling(amd, mode, path):
     assert line1["metric"] == line2["metric"]
     assert line1["config"]["workload"] == line2["config"]["workload"]
     assert line2["scaling_ceiling_vs_1gpu"] == 2.0 and line1["scaling_ceiling_vs_1gpu"] == 1.0
+
+
+def test_multi_gpu_smoke_two_ranks_on_one_gpu():
+    """``__graft_entry__.rccl_smoke`` -- what ``smoke()`` starts on a box with two GPUs, over RCCL -- run here by
+    two ranks that share cuda:0 over gloo: every fold of every rank against the oracle, row-sharded (one
+    all-reduce) and replicated (one broadcast)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200),
+                        os.path.join(root, "__graft_entry__.py"), "rccl_smoke"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rccl smoke ok (gloo, 2 ranks)" in r.stdout
 
 
 @pytest.mark.parametrize("K,M,route", [(4, 1, "units"), (64, 3, "units"), (132, 1, "units"), (260, 34, "units"),

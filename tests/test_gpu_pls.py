@@ -327,3 +327,43 @@ def test_randomised_shapes_against_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pls.py"), "120", "21"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("env", [{}, {"CVM_PLS_NO_REP": "1"}])
+def test_a_timed_out_sliced_launch_is_recomputed_not_poisoned(env):
+    """The routes that cut a fold into slices spin on each other; a slice that finds no place to run (another
+    stream's kernel, a masked CU) must cost time, not results.  ``CVM_PLS_TEST_TIMEOUT`` launches them one
+    workgroup short with a short spin limit: the barrier of one fold times out, the library recomputes every
+    fold with the one-workgroup-per-fold kernel in the same call (status 2) and the coefficients are the
+    oracle's."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from cvmatrix_amd import CVMatrix, Partitioner
+from cvmatrix_amd.pls import pls_fit_batched, pls_plan
+from oracle.ikpls_oracle import ikpls_fit
+rng = np.random.default_rng(5)
+N, K, M, P, A = 3000, 512, 4, 10, 6
+X, Y = rng.random((N, K)), rng.random((N, M))
+m = CVMatrix(); m.fit(X, Y)
+(xtx, xty), _ = m.training_XTX_XTY_batched(Partitioner(np.arange(N) %% P))
+assert pls_plan(P, K, M, A)["slices"] > 1, pls_plan(P, K, M, A)
+fit = pls_fit_batched(xtx, xty, A)
+assert pls_fit_batched.last_status == 2, pls_fit_batched.last_status
+for f in (0, 4, 9):
+    Bo, *_ = ikpls_fit(xtx[f].cpu().numpy(), xty[f].cpu().numpy(), A)
+    err = np.linalg.norm(fit.B[f].cpu().numpy() - Bo) / np.linalg.norm(Bo)
+    assert err <= 1e-9, (f, err)
+assert int(fit.n_fit.min()) == A
+print("recovered ok")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CVM_PLS_TEST_TIMEOUT="1", **env), cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "recovered ok" in r.stdout
+
