@@ -114,6 +114,18 @@ template <typename T> struct WgramArgs {
   const void *G, *H;    // full-data matrices
   void *out_XTX, *out_XTY;
   unsigned flags;
+  // fused route with the statistics formed INSIDE the launch (round 4; stat_flags != nullptr): the diagonal
+  // item of (fold, panel) sums the panel's columns while it streams the fold's rows anyway, derives the
+  // training means / reciprocal stds of its 128 columns (and of Y, and the fold's totals), writes them to
+  // fstats with device-coherent stores and raises stat_flags[fold * P + panel]; an off-diagonal item polls
+  // the flags of its two panels before its epilogue.  The diagonal items come FIRST in every XCD's list
+  // (diag_first), they wait for nobody: no deadlock.  No colstats_kernel / fold_stats_kernel pre-pass.
+  int *stat_flags;
+  int diag_first;
+  const double *gstats;
+  double ddof, resolution;
+  void *out_muX, *out_sdX, *out_muY, *out_sdY;
+  double *out_fold;
   int dbg;              // diagnostic ablations (env CVM_DEBUG): 1 no global loads after the
                         // first stage, 2 no MFMA, 4 no VALU column sums; results are wrong
 };
@@ -139,6 +151,12 @@ template <typename T> __device__ __forceinline__ double *unit_stats(char *ws, co
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+// Statistics another workgroup of the SAME launch may have written (WgramArgs::stat_flags): device-coherent
+// loads and stores (sc1: served by L2, never by this CU's L1), the hand-off form of MI355X_MICROARCH.md's
+// table "stores all sc1, loads all sc1, one lane signals behind every storing wave's vmcnt(0) + barrier"
+__device__ __forceinline__ double ldc(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ long long uni64(long long v) {
@@ -174,6 +192,10 @@ template <typename T> __device__ __forceinline__ WgramArgs<T> kernel_args(kargs_
   a.ws = r->ws; a.dbg = r->dbg;
   a.fstats = r->fstats; a.G = r->G; a.H = r->H;
   a.out_XTX = r->out_XTX; a.out_XTY = r->out_XTY; a.flags = r->flags;
+  a.stat_flags = r->stat_flags; a.diag_first = r->diag_first; a.gstats = r->gstats;
+  a.ddof = r->ddof; a.resolution = r->resolution;
+  a.out_muX = r->out_muX; a.out_sdX = r->out_sdX; a.out_muY = r->out_muY; a.out_sdY = r->out_sdY;
+  a.out_fold = r->out_fold;
   return a;
 }
 
@@ -203,6 +225,8 @@ template <typename T> __device__ __forceinline__ bool decode_slot(const WgramArg
   const Geom &g = a.g;
   long item, cu;   // cu: unit number within the class (seg * nsp + sp)
   int k;
+  // (diag_first: the list of an XCD is its class-1 items, then its class-0 items)
+  if (a.diag_first) q = q < a.ipx1 ? q + a.ipx0 : q - a.ipx1;
   if (q < a.ipx0) {
     item = (long)xcd * a.ipx0 + q;
     if (item >= a.n_items0) return false;

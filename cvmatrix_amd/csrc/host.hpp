@@ -398,7 +398,7 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     const dim3 grid((unsigned)wgs);
     const dim3 block4(NT4);
     // (the fused epilogue reuses the stage ring for its tiles: a little more than the ring in float32)
-    const size_t lds4 = fused && fused_lds_bytes<T>() > lds4_bytes<T>() ? fused_lds_bytes<T>() : lds4_bytes<T>();
+    const size_t lds4 = fused ? fused_launch_lds_bytes<T>() : lds4_bytes<T>();
 #define CVM_LAUNCH4(W, GA, FU)                                                              \
   do {                                                                                      \
     static std::atomic<unsigned long long> attr_done{0};                                    \
@@ -736,6 +736,32 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
       int64_t per_batch = (int64_t)(ws_bytes / per_fold);
       if (per_batch > 16384) per_batch = 16384;
+      // Statistics formed INSIDE the Gram launch (round 4): the diagonal item of (fold, panel) sums the
+      // panel's columns anyway-streamed rows and publishes the panel's training means / stds, the
+      // off-diagonal items wait for the two flags they need (wgram4.hpp).  No colstats_kernel +
+      // fold_stats_kernel pre-pass (70-90 us in front of a 0.5-1.2 ms launch at the C3 rows cut into 100 /
+      // 1000 folds).  One Y chunk (M <= 32); CVM_FUSED_PREPASS=1: the pre-pass route (tests, comparisons).
+      static const bool prepass_forced = getenv("CVM_FUSED_PREPASS") && atoi(getenv("CVM_FUSED_PREPASS")) != 0;
+      const bool ink = !prepass_forced && p.g.Yc == 1 && fst + (size_t)p.g.P * 4 + 256 <= per_fold;
+      for (int64_t f0 = 0; ink && f0 < n_folds; f0 += per_batch) {
+        const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
+        double *fstats = (double *)ws;
+        int *sflags = (int *)((char *)ws + align_up((size_t)nb * fst, 256));
+        HIP_OK(hipMemsetAsync(sflags, 0, align_up((size_t)nb * p.g.P * sizeof(int), 16), st));
+        WgramArgs<T> a;
+        memset(&a, 0, sizeof(a));
+        a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
+        a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
+        set_items(a, p, nb);               // (one unit per fold: p.s_off == p.s_diag == 1)
+        a.ws = nullptr;
+        a.fstats = fstats; a.G = G; a.H = H;
+        a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
+        a.stat_flags = sflags; a.diag_first = 1; a.gstats = gstats; a.ddof = ddof; a.resolution = resolution;
+        a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY; a.out_fold = out_fold;
+        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, wq.queue, true);
+        if (rc != CVM_OK) return rc;
+      }
+      if (ink) return CVM_OK;
       for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
         ColArgs c;

@@ -68,8 +68,14 @@ template <typename T> constexpr size_t wave_tile_bytes() { return ((size_t)64 * 
 template <typename T> constexpr size_t wave_lds_bytes() { return wave_tile_bytes<T>() + 256 * 8; }
 template <typename T> constexpr size_t diag_tile_bytes() { return ((size_t)TILE * (TILE + 1) * sizeof(T) + 7) / 8 * 8; }
 template <typename T> constexpr size_t fused_lds_bytes() {
-  return 4 * wave_lds_bytes<T>() > diag_tile_bytes<T>() + 3 * 256 * 8 ? 4 * wave_lds_bytes<T>()
-                                                                     : diag_tile_bytes<T>() + 3 * 256 * 8;
+  // (a diagonal item that forms its statistics itself keeps 324 more float64 behind its three blocks)
+  return 4 * wave_lds_bytes<T>() > diag_tile_bytes<T>() + (3 * 256 + 328) * 8 ? 4 * wave_lds_bytes<T>()
+                                                                             : diag_tile_bytes<T>() + (3 * 256 + 328) * 8;
+}
+// a fused launch's dynamic LDS: the stage ring or the epilogue's images, whichever is larger, and 16 bytes
+// behind them that neither touches (the mark of fused_wait_flag)
+template <typename T> constexpr size_t fused_launch_lds_bytes() {
+  return (fused_lds_bytes<T>() > lds4_bytes<T>() ? fused_lds_bytes<T>() : lds4_bytes<T>()) + 16;
 }
 
 // Fused epilogue of a DIAGONAL 128x128 tile, shared by all eight waves of the workgroup (the four
@@ -100,6 +106,30 @@ __device__ __forceinline__ void diag_tile_finish(T (*Td)[TP], double *rs0, int v
 // (the role functions are called once per work item from the persistent loop of wgram4_kernel)
 #define ROLE_EXIT() return
 #define ROLE_ATTR
+// Statistics formed inside a fused launch (WgramArgs::stat_flags).  fused_wait_flag: ONE lane of the first
+// loader wave waits until the diagonal items of its two panels have published (normally they did long ago:
+// they come first in every list); a wait that gives up -- it cannot, a diagonal item waits for nobody --
+// leaves a mark in the last word of the dynamic LDS and the epilogue then poisons its results (NaN).
+template <typename T> __device__ __forceinline__ void fused_wait_flag(const int *f0, const int *f1, char *smem_raw, int lane) {
+  if (lane != 0) return;
+  int ok = 1;
+  for (int w = 0; w < 2; ++w) {
+    const int *f = w ? f1 : f0;
+    long spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1L << 22)) { ok = 0; break; }
+    }
+  }
+  *reinterpret_cast<volatile int *>(smem_raw + fused_launch_lds_bytes<T>() - 16) = ok;
+}
+template <typename T> __device__ __forceinline__ double fused_swt(const double *p, const int *stat_flags, const char *smem_raw) {
+  const double v = ldc(p);
+  if (!stat_flags) return v;
+  const int ok = *reinterpret_cast<const volatile int *>(smem_raw + fused_launch_lds_bytes<T>() - 16);
+  return ok ? v : __builtin_nan("");
+}
+
 template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
 __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q, int slot_q) {
   typedef typename MF<T>::acc_t acc_t;
@@ -311,14 +341,47 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing in flight at wave exit
+    if constexpr (FUSEDR) {
+      // statistics formed inside the launch: an off-diagonal item needs those of its two panels, which the
+      // diagonal items of (fold, ti) and (fold, tj) publish (they come first in every list and wait for
+      // nobody).  The first loader wave -- idle by now -- polls the two flags before the barrier that ends
+      // the loop, so that every wave's (device-coherent) loads of the statistics come after the match.
+      if (a.stat_flags && do_g && !diag && d == 0) {
+        const int *fl = a.stat_flags + (size_t)seg * g.P;
+        fused_wait_flag<T>(fl + ti, fl + tj, smem_raw, lane);
+      }
+    }
     if (FUSEDR) __builtin_amdgcn_s_barrier();       // the compute waves reuse the ring in their epilogue
     if constexpr (FUSEDR) {
+      if (do_g && diag && a.stat_flags) {           // the diagonal item forms its statistics first: two more barriers
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        if (d == 0) {
+          // publish: the panel's statistics, the Y statistics, sw_T -> fstats (what the off-diagonal items of
+          // this fold read) with device-coherent stores, by ONE wave that waits for its own stores and then
+          // raises the flag
+          const int K = g.K, M = g.M;
+          double *fsw = const_cast<double *>(a.fstats) + (size_t)seg * fstat_len(K, M);
+          const double *stl = reinterpret_cast<const double *>(smem_raw + diag_tile_bytes<T>()) + 768;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int lcol = 64 * h + lane, col = ti * TILE + lcol;
+            if (col < K) { stc(fsw + col, stl[lcol]); stc(fsw + K + col, stl[128 + lcol]); }
+          }
+          if (lane < 32 && lane < M) { stc(fsw + 2 * K + lane, stl[256 + lane]); stc(fsw + 2 * K + M + lane, stl[288 + lane]); }
+          if (lane == 0) stc(fsw + 2 * K + 2 * M, stl[320]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0)
+            __hip_atomic_store(a.stat_flags + (size_t)seg * g.P + ti, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       if (do_g && diag && a.out_XTX) {
         // diagonal tile of the fused route: share the epilogue (diag_tile_finish), waves 4..7
         constexpr int TP = TILE + 1;
         const int K = g.K, M = g.M;
         const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
-        const double swt = fs[2 * K + 2 * M];
+        const double swt = a.stat_flags ? (reinterpret_cast<const double *>(smem_raw + diag_tile_bytes<T>()) + 768)[320]
+                                        : ldc(fs + 2 * K + 2 * M);
         const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
         T (*Td)[TP] = reinterpret_cast<T (*)[TP]>(smem_raw);
         double *rs0 = reinterpret_cast<double *>(smem_raw + diag_tile_bytes<T>());
@@ -333,7 +396,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         // 64x64 block (see the compute role's epilogue; same two barriers)
         const int K = g.K, M = g.M;
         const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
-        const double swt = fs[2 * K + 2 * M];
+        const double swt = fused_swt<T>(fs + 2 * K + 2 * M, a.stat_flags, smem_raw);
         const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
         const size_t fo = (size_t)(a.seg0 + seg);
         const int a0 = ti * TILE + 64 * (d >> 1), b0 = tj * TILE + 64 * (d & 1);
@@ -571,10 +634,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
     // The fold's statistics are already in a.fstats (colstats_kernel + fold_stats_kernel ran
     // first); every wave finishes its own block: total - update, rank-1 centring, outer-std
     // scaling (cvmatrix.py:1001-1010), mirrored store through the wave's slice of the ring.
-    __syncthreads();   // all loaders have drained their LDS-DMA
+    __syncthreads();   // all loaders have drained their LDS-DMA (and, statistics formed in the launch: polled the flags)
     const int K = g.K, M = g.M;
     const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
-    const double swt = fs[2 * K + 2 * M];
+    const double swt = h_wave ? ldc(fs + 2 * K + 2 * M) : fused_swt<T>(fs + 2 * K + 2 * M, a.stat_flags, smem_raw);
     const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
     const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
     const size_t fo = (size_t)(a.seg0 + seg);
@@ -591,10 +654,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
               const int row = ti * TILE + 16 * m + MF<T>::drow(lane, r), col = yc * YT + 16 * n + lc;
               if (row < K && col < M) {
                 double v = (double)Ht[(size_t)row * M + col] - (double)acc[m * 2 + n][r];
-                if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
-                if (sX && sY) v = v * (fs[K + row] * fs[2 * K + M + col]);
-                else if (sX) v = v * fs[K + row];
-                else if (sY) v = v * fs[2 * K + M + col];
+                if (cX || cY) v -= swt * (ldc(fs + row) * ldc(fs + 2 * K + col));
+                if (sX && sY) v = v * (ldc(fs + K + row) * ldc(fs + 2 * K + M + col));
+                else if (sX) v = v * ldc(fs + K + row);
+                else if (sY) v = v * ldc(fs + 2 * K + M + col);
                 out[(size_t)row * M + col] = (T)v;
               }
             }
@@ -614,10 +677,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       if (active) {
         // the statistics first, then the G pieces of this wave's 32 rows: both in flight while the
         // accumulators go to LDS (the statistics are waited for alone: they were issued first)
-        const double r0v = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
-        const double r1v = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
-        const double r2v = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
-        const double r3v = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
+        const double r0v = (cX && a0 + lane < K) ? ldc(fs + a0 + lane) : 0.0;
+        const double r1v = (sX && a0 + lane < K) ? ldc(fs + K + a0 + lane) : 1.0;
+        const double r2v = (cX && b0 + lane < K) ? ldc(fs + b0 + lane) : 0.0;
+        const double r3v = (sX && b0 + lane < K) ? ldc(fs + K + b0 + lane) : 1.0;
         fused_g_preload32<T>(gp, a0, b0, K, (const T *)a.G, lane, 0);
         rs[lane] = r0v; rs[64 + lane] = r1v; rs[128 + lane] = r2v; rs[192 + lane] = r3v;
 #pragma unroll
@@ -850,6 +913,20 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   for (int n = 0; n < NBY; ++n) sy[n] = qy[n] = 0;
 
   const int lk = lane >> 4, lc = lane & 15;
+  // statistics formed inside the launch (fused route, WgramArgs::stat_flags): this wave's two column tiles
+  // are summed like in the unfused kernel and finished in the epilogue; the full-data sums they are
+  // subtracted from are requested now and arrive during the loop
+  const bool ink = FUSEDR && a.stat_flags != nullptr;
+  double ink_gs[2] = {0, 0}, ink_gq[2] = {0, 0}, ink_tot[2] = {0, 0};
+  if (ink) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int col = ti * TILE + 16 * P.ft[P.at[P.ca[q]]] + lc;
+      if (col >= g.K) col = g.K - 1;
+      ink_gs[q] = a.gstats[col]; ink_gq[q] = a.gstats[g.K + col];
+    }
+    ink_tot[0] = a.gstats[2 * g.K + 2 * g.M]; ink_tot[1] = a.gstats[2 * g.K + 2 * g.M + 1];
+  }
 #ifdef CVM_COMPUTE_PRIO
   __builtin_amdgcn_s_setprio(CVM_COMPUTE_PRIO);
 #endif
@@ -873,14 +950,14 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
       const T x = bf[c][P.at[q]];
       aw[c][q] = WEIGHTED ? (T)(x * wv[c]) : x;
     }
-    if (!FUSEDR) {   // (the fused route gets its statistics from colstats_kernel)
+    if (!FUSEDR || ink) {   // (the fused route: from colstats_kernel, or -- ink -- formed here like everywhere else)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const T x = bf[c][P.at[P.ca[q]]], pv = aw[c][P.ca[q]];
         st_s[q] += pv; st_q[q] += (T)(pv * x);
       }
     }
-    if (YSTAT && !FUSEDR) {
+    if (YSTAT && (!FUSEDR || ink)) {
 #pragma unroll
       for (int n = 0; n < NBY; ++n) {
         const T yv = yf[c][n];
@@ -970,11 +1047,98 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
     // rows of its row-tiles itself.
     __syncthreads();   // all loaders have drained their LDS-DMA
     const int K = g.K, M = g.M;
-    const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
-    const double swt = fs[2 * K + 2 * M];
+    double *fsw = const_cast<double *>(a.fstats) + (size_t)seg * fstat_len(K, M);
+    const double *fs = fsw;
     const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
     const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
     const size_t fo = (size_t)(a.seg0 + seg);
+    // statistics in LDS (ink): [0,128) means of the panel's columns, [128,256) reciprocal stds, [256,288) /
+    // [288,320) the same for the Y chunk, [320] sw_T -- behind the tile image and its statistics blocks
+    double *stl = reinterpret_cast<double *>(smem_raw + diag_tile_bytes<T>()) + 768;
+    if (ink) {
+      // ---- the statistics of this panel (and, wave 3: of Y and the fold's totals), formed here ----------
+      // fold_stats_kernel's arithmetic (cvmatrix.py:612-620, 1020, 1043, 1079, 1119-1128) on the sums this
+      // item has just taken; every item of a fold sums the same rows in the same order, so every panel's
+      // statistics -- and the Y statistics and totals every diagonal item of the fold writes -- are the same
+      // bits whoever writes them.  They go to LDS for this item's own epilogue; the first loader wave then
+      // copies them to fstats with device-coherent stores, waits for ITS stores alone and raises the flag,
+      // while the other waves are already finishing the tile (wgram4_body, loader role).
+      auto comb = [&](double v) -> double {
+        const double v1 = __shfl(v, lc + 16), v2 = __shfl(v, lc + 32), v3 = __shfl(v, lc + 48);
+        return ((v + v1) + v2) + v3;
+      };
+      double *tot = stl + 322;                                      // [0] sw_V, [1] nz_V
+      if (YSTAT) {
+        const double swv = comb(sw_), nzv = comb(nz_);
+        if (lane == 0) { tot[0] = swv; tot[1] = nzv; }
+      }
+      lds_barrier();
+      const double swv = tot[0], nzv = tot[1];
+      const double swt_ = ink_tot[0] - swv, nzt = ink_tot[1] - nzv;
+      const double divisor = (nzt - a.ddof) * swt_ / nzt;
+      const bool rXTY = a.flags & CVM_RET_XTY;
+      const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
+      const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
+      auto finish_col = [&](double sv, double qv, double gs, double gq, bool want_sd, double &mu, double &isd, double &sd) {
+        const double st_ = gs - sv;          // cvmatrix.py:1020
+        mu = st_ / swt_;                     // cvmatrix.py:1043
+        sd = 1.0;
+        if (want_sd) {
+          const double qt = gq - qv;
+          double var = (-2 * mu * st_ + swt_ * (mu * mu) + qt) / divisor;   // 1119-1123
+          var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
+          sd = sqrt(var);
+          if (sd <= a.resolution) sd = 1.0;  // 1128
+        }
+        isd = 1.0 / sd;
+      };
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const double sv = comb(st_s[q]), qv = comb(st_q[q]);
+        const int lcol = 16 * P.ft[P.at[P.ca[q]]] + lc, col = ti * TILE + lcol;
+        if (lk == 0) {
+          double mu = 0.0, isd = 1.0, sd = 1.0;
+          if (col < K && want_muX) {
+            finish_col(sv, qv, ink_gs[q], ink_gq[q], want_sdX, mu, isd, sd);
+            const size_t o = fo * K + col;
+            if (a.out_muX) ((T *)a.out_muX)[o] = (T)mu;
+            if (a.out_sdX && want_sdX) ((T *)a.out_sdX)[o] = (T)sd;
+          }
+          stl[lcol] = mu; stl[128 + lcol] = isd;
+        }
+      }
+      if (YSTAT) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int col = 16 * n + lc;
+          double mu = 0.0, isd = 1.0, sd = 1.0;
+          if (n < NBY) {
+            const double sv = comb(sy[n < NBY ? n : 0]), qv = comb(qy[n < NBY ? n : 0]);
+            if (lk == 0 && col < M && want_muY) {
+              finish_col(sv, qv, a.gstats[2 * K + col], a.gstats[2 * K + M + col], want_sdY, mu, isd, sd);
+              if (ti == 0) {
+                const size_t o = fo * M + col;
+                if (a.out_muY) ((T *)a.out_muY)[o] = (T)mu;
+                if (a.out_sdY && want_sdY) ((T *)a.out_sdY)[o] = (T)sd;
+              }
+            }
+          }
+          if (lk == 0) { stl[256 + col] = mu; stl[288 + col] = isd; }
+        }
+        if (lane == 0) {
+          stl[320] = swt_;
+          if (a.out_fold && ti == 0) { double *o = a.out_fold + 4 * fo; o[0] = swt_; o[1] = nzt; o[2] = swv; o[3] = nzv; }
+        }
+      }
+      lds_barrier();
+      // (the first loader wave publishes them: it has half a compute wave's share of the tile finish)
+    }
+    // the statistics this item's own epilogue uses: from LDS when they were formed here, else from fstats
+    auto st_mu = [&](int col) -> double { return ink ? stl[col - ti * TILE] : ldc(fs + col); };
+    auto st_isd = [&](int col) -> double { return ink ? stl[128 + col - ti * TILE] : ldc(fs + K + col); };
+    auto st_muY = [&](int col) -> double { return ink ? stl[256 + col] : ldc(fs + 2 * K + col); };
+    auto st_isdY = [&](int col) -> double { return ink ? stl[288 + col] : ldc(fs + 2 * K + M + col); };
+    const double swt = ink ? stl[320] : ldc(fs + 2 * K + 2 * M);
     if (a.out_XTY && M > 0) {
       T *out = (T *)a.out_XTY + fo * (size_t)K * M;
       const T *Ht = (const T *)a.H;
@@ -987,10 +1151,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
             const int row = ti * TILE + 16 * P.ft[P.at[P.xa[i]]] + MF<T>::drow(lane, r), col = 16 * n + lc;
             if (row < K && col < M) {
               double v = (double)Ht[(size_t)row * M + col] - (double)acch[i * NBY + n][r];
-              if (cX || cY) v -= swt * (fs[row] * fs[2 * K + col]);
-              if (sX && sY) v = v * (fs[K + row] * fs[2 * K + M + col]);
-              else if (sX) v = v * fs[K + row];
-              else if (sY) v = v * fs[2 * K + M + col];
+              if (cX || cY) v -= swt * (st_mu(row) * st_muY(col));
+              if (sX && sY) v = v * (st_isd(row) * st_isdY(col));
+              else if (sX) v = v * st_isd(row);
+              else if (sY) v = v * st_isdY(col);
               out[(size_t)row * M + col] = (T)v;
             }
           }
@@ -1009,10 +1173,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
         const int bb = W == 3 ? 2 : W, si = bb == 2, sj = bb >= 1;
         const int a0 = ti * TILE + 64 * si, b0 = ti * TILE + 64 * sj;
         double *rs = rs0 + 256 * bb;
-        rs[lane] = (cX && a0 + lane < K) ? fs[a0 + lane] : 0.0;
-        rs[64 + lane] = (sX && a0 + lane < K) ? fs[K + a0 + lane] : 1.0;
-        rs[128 + lane] = (cX && b0 + lane < K) ? fs[b0 + lane] : 0.0;
-        rs[192 + lane] = (sX && b0 + lane < K) ? fs[K + b0 + lane] : 1.0;
+        rs[lane] = (cX && a0 + lane < K) ? st_mu(a0 + lane) : 0.0;
+        rs[64 + lane] = (sX && a0 + lane < K) ? st_isd(a0 + lane) : 1.0;
+        rs[128 + lane] = (cX && b0 + lane < K) ? st_mu(b0 + lane) : 0.0;
+        rs[192 + lane] = (sX && b0 + lane < K) ? st_isd(b0 + lane) : 1.0;
       }
       lds_barrier();     // B_dump: the tile and the statistics are in LDS (all eight waves)
       T *outp = (T *)a.out_XTX + fo * (size_t)K * K;
@@ -1089,7 +1253,9 @@ __device__ __forceinline__ void wgram4_item(const WgramArgs<T> &a, kargs_ptr<T> 
     if (wave == 0) CVM_DIAGF(0);
     else if (wave == 1) CVM_DIAGF(1);
     else if (wave == 2) CVM_DIAGF(2);
-    else CVM_DIAGF(3);
+    else if (!a.stat_flags) CVM_DIAGF(3);
+    else if (wide) wgram4_diag_body<T, WEIGHTED, GATHER, 3, 2, true, true>(kargs, xq, sq);     // (+ the Y columns, sw, nz)
+    else wgram4_diag_body<T, WEIGHTED, GATHER, 3, 1, true, true>(kargs, xq, sq);
 #undef CVM_DIAGF
     return;
   }
