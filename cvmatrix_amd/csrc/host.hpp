@@ -532,6 +532,8 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
   a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY;
   a.out_fold = out_fold; a.ddof = ddof; a.resolution = resolution; a.flags = flags;
   a.P64 = (K + ST - 1) / ST; a.nT64 = a.P64 * (a.P64 + 1) / 2;
+  static const int noremap_env = getenv("CVM_SMALL_NOREMAP") ? atoi(getenv("CVM_SMALL_NOREMAP")) : 0;   // (measurements)
+  a.noremap = noremap_env;
   a.inl_n = -1;
   if (flags & CVM_IDX_HOST) {            // one fold, indices on the host: into the kernel arguments
     a.inl_n = (int)(offsets[1] - offsets[0]);

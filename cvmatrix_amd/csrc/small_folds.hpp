@@ -43,6 +43,7 @@ struct SmallArgs {
   char *rec;                           // nullptr: no records
   unsigned rec_stride, rec_mu, rec_isd, rec_rows, rec_w;
   int tsteps;                          // k-steps one operand buffer holds
+  int noremap;                         // 1: workgroup b works on item b (no XCD-contiguous ranges)
   int dbg;                             // small_tile_kernel, measurements only (CVM_TILE_DEBUG; results are wrong): 1 no MFMA
                                        // loop, 2 no operand DMAs, 4 no transpose before the stores
 };
@@ -170,7 +171,7 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
   // (a 1-D launch of 8 * ceil(gx * gy / 8) workgroups; gx tiles and panels, gy fold groups)
   const unsigned lin = blockIdx.x, tot = (unsigned)a.gx * (unsigned)a.gy;
   const unsigned per = (tot + 7) / 8;
-  const unsigned item = (lin & 7) * per + (lin >> 3);
+  const unsigned item = a.noremap ? lin : (lin & 7) * per + (lin >> 3);
   if (item >= tot) return;
   const int x = a.x0 + (int)(item % (unsigned)a.gx), by = (int)(item / (unsigned)a.gx);
   const int K = a.K, M = a.M;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   // XCD-contiguous ranges of (fold group, panel), as in small_apply_kernel
   const unsigned lin = blockIdx.x, tot = (unsigned)a.gx * (unsigned)a.gy;
   const unsigned per = (tot + 7) / 8;
-  const unsigned item = (lin & 7) * per + (lin >> 3);
+  const unsigned item = a.noremap ? lin : (lin & 7) * per + (lin >> 3);
   if (item >= tot) return;
   const int bx = (int)(item % (unsigned)a.gx), by = (int)(item / (unsigned)a.gx);
   const int ncc = (K + TC - 1) / TC;               // column chunks

@@ -25,13 +25,14 @@ for W in C2 C4 C5; do
   grep "^{" $O/st_$W.out | tail -1 > $D/bench_stats_$W.json
   cp $(ls $O/stats_$W/*/*_kernel_stats.csv | head -1) $D/kernel_stats_$W.csv 2>/dev/null
 done
-# the HBM-bound regime (small folds) and the statistics-only call: --stats and FETCH / WRITE passes
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/small -- python3 $ROOT/tools/bench_small.py > $D/bench_small.txt 2> $O/small.log
+# the HBM-bound regime (small folds): --stats and FETCH / WRITE passes over tools/bench_hbm.py (back-to-back timing, as bench.py)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/small -- python3 $ROOT/tools/bench_hbm.py quick > $D/bench_hbm.txt 2> $O/small.log
 cp $(ls $O/small/*/*_kernel_stats.csv | head -1) $D/small_folds_kernel_stats.csv 2>/dev/null
 mkdir -p $O/smallpmc
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/smallpmc/pmc_fetch -- python3 $ROOT/tools/bench_small.py > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/smallpmc/pmc_write -- python3 $ROOT/tools/bench_small.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/smallpmc/pmc_fetch -- python3 $ROOT/tools/bench_hbm.py quick > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/smallpmc/pmc_write -- python3 $ROOT/tools/bench_hbm.py quick > /dev/null 2>&1
 mkdir -p $D/small_tmp; python3 $ROOT/tools/summarize_rocprof.py $O/smallpmc $D/small_tmp > /dev/null; mv $D/small_tmp/pmc_summary.json $D/small_folds_pmc_summary.json; rm -rf $D/small_tmp
+python3 $ROOT/tools/bench_hbm.py > $D/bench_hbm_full.txt 2>/dev/null
 # the statistics-only call and the float32 mid-size folds
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_only -- python3 $ROOT/tools/bench_stats.py > $D/bench_statistics.txt 2> $O/stats_only.log
 cp $(ls $O/stats_only/*/*_kernel_stats.csv | head -1) $D/statistics_kernel_stats.csv 2>/dev/null
@@ -42,6 +43,12 @@ cp $(ls $O/pls/*/*_kernel_stats.csv | head -1) $D/pls_kernel_stats.csv 2>/dev/nu
 cd $ROOT
 python3 bench.py > $O/plain.out 2>&1; grep "^{" $O/plain.out | tail -1 > $D/bench_bench_plain.json
 python3 tools/bench_foldsizes.py > $D/fold_size_sweep.txt 2>/dev/null
+# mid-size folds (P = 1000) under the counters: the fused route with the statistics formed in the launch
+FOLD_PS=1000 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/mid_fetch -- python3 $ROOT/tools/bench_foldsizes.py > /dev/null 2>&1
+FOLD_PS=1000 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/mid_write -- python3 $ROOT/tools/bench_foldsizes.py > /dev/null 2>&1
+mkdir -p $O/midpmc; mv $O/mid_fetch $O/midpmc/pmc_fetch; mv $O/mid_write $O/midpmc/pmc_write
+mkdir -p $D/mid_tmp; python3 $ROOT/tools/summarize_rocprof.py $O/midpmc $D/mid_tmp > /dev/null; mv $D/mid_tmp/pmc_summary.json $D/midsize_P1000_pmc_summary.json; rm -rf $D/mid_tmp
+python3 tools/emulate_scaling.py --workloads C3 --out $D/emulated_scaling_C3 > $O/emu_C3.log 2>&1; python3 tools/emulate_scaling.py --workloads C4 --comm-us 0,60 --out $D/emulated_scaling_C4 > $O/emu_C4.log 2>&1
 rm -f $D/benchmark_protocol_hip.csv; python3 tools/benchmark_protocol.py --csv $D/benchmark_protocol_hip.csv > $D/benchmark_protocol.log 2>&1
 python3 tools/power_probe.py C3 C3fit C3fold C3two C4 C4fit C5 2>/dev/null > $D/power_probe.txt
 for p in "500:250" "240:280,280:120" "240:280,240:135" "480:145,560:65"; do ./tools/dispatch_probe "$p" > /tmp/dp.txt; python3 tools/dispatch_analyze.py /tmp/dp.txt | sed -n 1,7p | cut -c1-400; echo; done > $D/dispatch_probe.txt 2>&1
