@@ -612,13 +612,16 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         t.dbg = tile_dbg;
         t.fpb = fpt; t.x0 = 0;
         t.gx = (int)tiles; t.gy = (int)((nb + fpt - 1) / fpt);
-        const size_t lds = small_tile_lds<T>(t.tsteps, fpt);
+        static const int nbuf_env = getenv("CVM_TILE_NBUF") ? atoi(getenv("CVM_TILE_NBUF")) : 0;
+        t.nbuf = nbuf_env >= 2 && nbuf_env <= 3 ? nbuf_env : 2;      // (three buffers: measured no faster in float32, slower in float64)
+        if (small_tile_lds<T>(t.tsteps, fpt, t.nbuf) > 150 * 1024) t.nbuf = 2;
+        const size_t lds = small_tile_lds<T>(t.tsteps, fpt, t.nbuf);
         if (lds > 64 * 1024) {
           int dev = 0;
           HIP_OK(hipGetDevice(&dev));
           static std::atomic<unsigned long long> attr_done{0};   // one bit per device
           if (attr_needed(attr_done, dev)) {
-            HIP_OK(hipFuncSetAttribute((const void *)small_tile_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_OK(hipFuncSetAttribute((const void *)small_tile_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
             attr_set(attr_done, dev);
           }
         }

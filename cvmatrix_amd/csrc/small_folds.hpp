@@ -43,6 +43,7 @@ struct SmallArgs {
   char *rec;                           // nullptr: no records
   unsigned rec_stride, rec_mu, rec_isd, rec_rows, rec_w;
   int tsteps;                          // k-steps one operand buffer holds
+  int nbuf;                            // operand buffers (2 or 3): the DMAs of fold f + nbuf - 1 are issued at the top of fold f
   int noremap;                         // 1: workgroup b works on item b (no XCD-contiguous ranges)
   int dbg;                             // small_tile_kernel, measurements only (CVM_TILE_DEBUG; results are wrong): 1 no MFMA
                                        // loop, 2 no operand DMAs, 4 no transpose before the stores

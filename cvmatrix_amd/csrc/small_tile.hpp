@@ -60,19 +60,15 @@ template <> struct TileCfg<double> { static constexpr int V = 2, GRP = 2, WPE = 
 constexpr int TL_FPB = 16;                 // folds per workgroup at most
 constexpr int TL_MAXSTEPS = 10;            // k-steps a buffer holds at most: 32 rows + the means -> 9, + the isd step
 
-// all but the n youngest vector-memory operations of this wave are done (n wave-uniform, 0..8)
+// all but the n youngest vector-memory operations of this wave are done (n wave-uniform, 0..16)
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define CVM_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
   switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    CVM_W(0) CVM_W(1) CVM_W(2) CVM_W(3) CVM_W(4) CVM_W(5) CVM_W(6) CVM_W(7) CVM_W(8)
+    CVM_W(9) CVM_W(10) CVM_W(11) CVM_W(12) CVM_W(13) CVM_W(14) CVM_W(15)
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
   }
+#undef CVM_W
 }
 
 // one LDS-DMA instruction: lane l copies 16 bytes from its own `src` to LDS byte address lds_addr + 16 l
@@ -209,10 +205,13 @@ __device__ __forceinline__ void small_tile_folds(const SmallArgs &a, TileLane<T>
       const bool ok = !(p & 3ull) && col < K;
       // (bit 0: a row of zeros, bit 1: a row of ones -- both without a column offset)
       const char *src = ok ? reinterpret_cast<const char *>(p) + (size_t)col * ES : ((p & 2ull) ? ones : zero) + Pi * ES;
-      dma16_lanes(src, lds0 + (unsigned)((((bb * 2 + sl) * TM + s) * GRP + g) << 10));
+      dma16_lanes(src, lds0 + (unsigned)((((bb * 2 + sl) * TM + s) * GRP + g) << 10));      // (bb: buffer of fold fn)
     }
   };
-  issue(0, 0);
+  // NB operand buffers: fold f's operands are issued NB - 1 folds ahead (two buffers: one fold -- at K = 4096 the
+  // DMA's latency under a saturated memory system was just longer than a fold's own work; three: two folds)
+  const int NB = a.nbuf;
+  for (int f = 0; f < NB - 1 && f < nf; ++f) issue(f, f);
   // every load so far (the tile of G, the tables) has landed before the loop starts: nothing the
   // compiler knows of is in flight there, so it places no vector-memory wait inside the loop
 #pragma unroll
@@ -221,16 +220,19 @@ __device__ __forceinline__ void small_tile_folds(const SmallArgs &a, TileLane<T>
     for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(gt[g][r]));
   const size_t obase = (size_t)(a0 + 16 * wave + (j & 3)) * K + b0 + V * pi;
   for (int ff = 0; ff < nf; ++ff) {
-    const int b = ff & 1;
+    const int b = ff % NB;
     if (!(a.dbg & 8)) {
+      // this wave's DMAs of fold ff have landed: they are older than the stores of the last NB - 1 folds (and
+      // than the DMAs issued in between, which may be forced to land with them: never more than a fold's)
+      // (the folds issued before the loop all landed with the first wait)
       if (ff == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else wait_vmcnt_le(nst);                     // all but the previous fold's stores: this wave's DMAs of fold ff
+      else if (ff >= NB - 1) wait_vmcnt_le((NB - 1) * nst);
     }
-    if (!(a.dbg & 16)) lds_barrier();              // ... and everybody else's; buffer b ^ 1 is free
-    if (ff + 1 < nf) issue(ff + 1, b ^ 1);
+    if (!(a.dbg & 16)) lds_barrier();              // ... and everybody else's; the buffer of fold ff - 1 is free
+    if (ff + NB - 1 < nf) issue(ff + NB - 1, (ff + NB - 1) % NB);
     const int n = uni(n_all[ff]);
     const int S = (n + (cX ? 1 : 0) + 3) >> 2;
-    const char *imgR = img + (size_t)((b * 2 + 0) * TM) * GRP * 1024;
+    const char *imgR = img + (size_t)((b * 2 + 0) * TM) * GRP * 1024;      // (b: this fold's buffer)
     const char *imgC = DIAG ? imgR : img + (size_t)((b * 2 + 1) * TM) * GRP * 1024;
     acc_t acc[4], acc2[DIAG ? 4 : 1];
 #pragma unroll
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(256, TileCfg<T>::WPE) void small_tile_kernel(const 
   const int tid = threadIdx.x;
   const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
   const int TM = a.tsteps, NS = 4 * TM;
-  char *img = tl_smem;                                                  // [2 buffers][2 slabs][TM][GRP][1 KiB]
-  unsigned long long *ptab = reinterpret_cast<unsigned long long *>(tl_smem + (size_t)4 * TM * GRP * 1024);
+  char *img = tl_smem;                                                  // [nbuf buffers][2 slabs][TM][GRP][1 KiB]
+  unsigned long long *ptab = reinterpret_cast<unsigned long long *>(tl_smem + (size_t)2 * a.nbuf * TM * GRP * 1024);
   T *wtab = reinterpret_cast<T *>(ptab + (size_t)a.fpb * NS);
   int *n_all = reinterpret_cast<int *>(wtab + (size_t)a.fpb * NS);
   const int f_first = by * a.fpb;
@@ -374,6 +376,6 @@ __global__ __launch_bounds__(256, TileCfg<T>::WPE) void small_tile_kernel(const 
 }
 
 // bytes of dynamic LDS of a small_tile_kernel launch
-template <typename T> inline size_t small_tile_lds(int tsteps, int fpb) {
-  return (size_t)4 * tsteps * TileCfg<T>::GRP * 1024 + (size_t)fpb * 4 * tsteps * (8 + sizeof(T)) + (size_t)fpb * 4 + 16;
+template <typename T> inline size_t small_tile_lds(int tsteps, int fpb, int nbuf) {
+  return (size_t)2 * nbuf * tsteps * TileCfg<T>::GRP * 1024 + (size_t)fpb * 4 * tsteps * (8 + sizeof(T)) + (size_t)fpb * 4 + 16;
 }
