@@ -1590,8 +1590,14 @@ int pls_sse_impl(const void *X, const void *Y, const void *w, const int64_t *idx
   if (F > 65535) return fail(CVM_EINVAL, "cvm_pls_validation_sse: at most 65535 folds per call%s");
   // 16 NT columns per wave: as few column groups as possible (every group stages the rows again),
   // then as little padding as possible
+  constexpr int VW = 16 / (int)sizeof(T);
+  const bool vec = K % VW == 0 && M % VW == 0 && K >= 4 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
+                   (!muX || (uintptr_t)muX % 16 == 0) && (!sdX || (uintptr_t)sdX % 16 == 0);
+  // (float64 takes five column tiles per wave at most, four without 16-byte pieces: the wider variants of
+  //  those combinations spill -- 33 / 90 registers at six tiles, 3 at five scalar ones)
+  const int max_nt = sizeof(T) == 8 ? (vec ? 5 : 4) : SSE_MAXNT;
   int nt = 1, best = 1 << 30;
-  for (int c = 1; c <= SSE_MAXNT; ++c) {
+  for (int c = 1; c <= max_nt; ++c) {
     const int groups = (C + 64 * c - 1) / (64 * c);
     const int cost = groups * (4 * c + 1);
     if (cost < best) { best = cost; nt = c; }
@@ -1601,9 +1607,6 @@ int pls_sse_impl(const void *X, const void *Y, const void *w, const int64_t *idx
   // (statistics in LDS only where they do not cost residency: one workgroup per CU anyway, or a short K)
   a.st_in_lds = (lds + (size_t)K * 16 + 2048 <= PLS_LDS_BUDGET && (lds > 80 * 1024 || K <= 512)) ? 1 : 0;
   if (a.st_in_lds) lds += (size_t)K * 16;
-  constexpr int VW = 16 / (int)sizeof(T);
-  const bool vec = K % VW == 0 && M % VW == 0 && K >= 4 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
-                   (!muX || (uintptr_t)muX % 16 == 0) && (!sdX || (uintptr_t)sdX % 16 == 0);
   void (*kern)(const SseArgs) = nullptr;
 #define CVM_SSE_PICK(N) kern = vec ? pls_sse_kernel<T, N, VW> : pls_sse_kernel<T, N, 1>
   switch (nt) {
@@ -1611,9 +1614,15 @@ int pls_sse_impl(const void *X, const void *Y, const void *w, const int64_t *idx
     case 2: CVM_SSE_PICK(2); break;
     case 3: CVM_SSE_PICK(3); break;
     case 4: CVM_SSE_PICK(4); break;
-    case 5: CVM_SSE_PICK(5); break;
-    default: CVM_SSE_PICK(6); break;
+    case 5:
+      if constexpr (sizeof(T) == 8) kern = pls_sse_kernel<T, 5, VW>;      // (vec only: see max_nt)
+      else CVM_SSE_PICK(5);
+      break;
+    default:
+      if constexpr (sizeof(T) == 4) CVM_SSE_PICK(6);
+      break;
   }
+  if (!kern) return fail(CVM_EINVAL, "cvm_pls_validation_sse: no kernel for this shape%s");
 #undef CVM_SSE_PICK
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)chunks, groups, (unsigned)F), dim3(256), lds, st, a);

@@ -435,7 +435,10 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
 // (tools/write_pattern.hip).  G is read for both triangles, so this kernel is for matrices that
 // stay in L2 / MALL across the folds of a batch.  One barrier per fold; the column data (x of the
 // validation rows, means, stds) goes straight from global memory to registers.
-constexpr int SR_ROWS = 8;
+#ifndef CVM_SR_ROWS
+#define CVM_SR_ROWS 8
+#endif
+constexpr int SR_ROWS = CVM_SR_ROWS;
 // LPR: 16-byte pieces per output row handled by a workgroup (64, 128 or 256: the smallest that
 // covers K keeps the threads busy); 256 / LPR rows go in one pass, SR_ROWS rows per workgroup.
 template <typename T, bool WEIGHTED, int LPR>
