@@ -40,6 +40,7 @@ namespace {
 #include "colstats.hpp"
 #include "small_folds.hpp"
 #include "small_tile.hpp"
+#include "mid_tile.hpp"
 #include "host.hpp"
 #include "partition.hpp"
 #include "pls.hpp"

@@ -649,6 +649,39 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
   return CVM_OK;
 }
 
+// mid_tile_kernel over the folds of one batch (their statistics are in m.fstats)
+// Where mid_tile_kernel is the route (float64; tools/exp_mid_small.sh, profiles/r4/exp_mid_small.txt): for K = 512 it
+// beats the direct small-fold kernels from 8 rows per fold up (16 rows: 1.60 against 1.84 ms for 2774 folds, 32
+// rows: 1.93 / 2.40) and the fused Gram route up to ~250 rows (100 rows: 1.02 / 1.25 ms, 256: 0.80 / 0.84); for
+// K = 1024 from 16 rows (1.33 / 1.47 ms) to ~200 (2.71 / 2.78); for K = 4096 never (G no longer fits the L2: its
+// tile reads come from HBM row by row, 3.0 against 1.1 ms at 8 rows) -- no mid route above K = 1024.
+inline int mid_default_minn(int K) { return K < 768 ? 8 : (K <= 1024 ? 16 : (1 << 30)); }
+inline int mid_default_maxn(int K) { return K < 768 ? 256 : (K <= 1024 ? 200 : 0); }
+template <typename T> int launch_mid(MidArgs m, bool weighted, int64_t nb, int64_t max_rows, hipStream_t st) {
+  m.nt = (m.K + 63) / 64;
+  m.n_xtx = m.nt * (m.nt + 1) / 2;
+  m.yextra = (m.out_XTY && m.M > 16) ? (m.M - 16 + 63) / 64 : 0;
+  m.ipf = m.n_xtx + m.nt * m.yextra;
+  m.n_items = (long long)nb * m.ipf;
+  m.per_xcd = (m.n_items + 7) / 8;
+  m.maxn = (int)((max_rows + 15) / 16 * 16);
+  if (m.maxn < 16) m.maxn = 16;
+  const size_t lds = mid_lds_bytes<T>(m.maxn);
+  if (m.per_xcd * 8 > 0x7fffffffLL) return fail(CVM_EINVAL, "launch_mid: too many work items%s");
+  const dim3 grid((unsigned)(m.per_xcd * 8));
+  if (lds > 64 * 1024) return fail(CVM_EINVAL, "launch_mid: folds too long for the LDS lists%s");
+  if constexpr (sizeof(T) == 8) {
+    TimedLaunch *tl = timed_begin(KIND_FOLD, st);
+    if (weighted) hipLaunchKernelGGL((mid_tile_kernel<T, true>), grid, dim3(MID_THREADS), lds, st, m);
+    else hipLaunchKernelGGL((mid_tile_kernel<T, false>), grid, dim3(MID_THREADS), lds, st, m);
+    timed_end(tl, st);
+  } else {
+    return fail(CVM_EINVAL, "launch_mid: float64 only%s");
+  }
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+
 // statistics-only fold stage: colstats_kernel + fold_stats_kernel, no Gram launch
 template <typename T>
 int fold_statistics_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
@@ -710,7 +743,21 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   }
   const WsCarve wq = carve_queue(ws, ws_bytes);
   ws_bytes = wq.usable;
-  if (max_rows <= small_route_limit(K, (int)sizeof(T)))
+  // (CVM_MID_MINN: folds of at least so many rows skip the direct small-fold kernels -- measurement switch
+  //  for where mid_tile_kernel takes over; float64 only, like that kernel)
+  static const int mid_minn_env = getenv("CVM_MID_MINN") ? atoi(getenv("CVM_MID_MINN")) : 0;
+  static const bool mid_off = getenv("CVM_MID_TILE") && atoi(getenv("CVM_MID_TILE")) == 0;
+  const int mid_minn = mid_off ? (1 << 30) : (mid_minn_env > 0 ? mid_minn_env : mid_default_minn(K));
+  static const int mid_maxn_env0 = getenv("CVM_MID_MAXN") ? atoi(getenv("CVM_MID_MAXN")) : 0;
+  static const bool force_fallback0 = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
+  static const bool no_fused0 = getenv("CVM_NO_FUSED") && atoi(getenv("CVM_NO_FUSED")) != 0;
+  // (... and only where that kernel can run: the conditions of the fused route below)
+  // (a fold whose indices come inside the call -- CVM_IDX_HOST, one fold of at most 32 rows -- is the small route's)
+  const bool skip_small = sizeof(T) == 8 && !(flags & CVM_IDX_HOST) && max_rows >= mid_minn && ((flags & CVM_RET_XTX) && out_XTX) &&
+                          max_rows <= (mid_maxn_env0 > 0 ? mid_maxn_env0 : mid_default_maxn(K)) && N <= 0x7fffffffLL &&
+                          K >= 2 && rows_aligned(X, K, sizeof(T)) && M % 2 == 0 && (uintptr_t)Y % 16 == 0 &&
+                          (uintptr_t)w % 8 == 0 && !force_fallback0 && !no_fused0;
+  if (max_rows <= small_route_limit(K, (int)sizeof(T)) && !skip_small)
     return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
   const bool want_xtx = (flags & CVM_RET_XTX) && out_XTX, want_xty = (flags & CVM_RET_XTY) && out_XTY;
@@ -747,7 +794,14 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       // fold_stats_kernel pre-pass (70-90 us in front of a 0.5-1.2 ms launch at the C3 rows cut into 100 /
       // 1000 folds).  One Y chunk (M <= 32); CVM_FUSED_PREPASS=1: the pre-pass route (tests, comparisons).
       static const bool prepass_forced = getenv("CVM_FUSED_PREPASS") && atoi(getenv("CVM_FUSED_PREPASS")) != 0;
-      const bool ink = !prepass_forced && p.g.Yc == 1 && fst + (size_t)p.g.P * 4 + 256 <= per_fold;
+      // Folds of up to a few hundred rows: mid_tile_kernel (mid_tile.hpp) -- small work items, four
+      // workgroups per CU, so that one item's stores overlap another's MFMAs -- behind the statistics pre-pass.
+      // CVM_MID_TILE=0: the fused route for them too (tests, comparisons); CVM_MID_MAXN: the row limit.
+      static const int mid_env = getenv("CVM_MID_TILE") ? atoi(getenv("CVM_MID_TILE")) : 1;
+      static const int mid_maxn_env = getenv("CVM_MID_MAXN") ? atoi(getenv("CVM_MID_MAXN")) : 0;
+      const int mid_maxn = mid_maxn_env > 0 ? mid_maxn_env : mid_default_maxn(K);
+      const bool mid = mid_env != 0 && max_rows <= mid_maxn && N <= 0x7fffffffLL && K >= 2 && sizeof(T) == 8;
+      const bool ink = !mid && !prepass_forced && p.g.Yc == 1 && fst + (size_t)p.g.P * 4 + 256 <= per_fold;
       for (int64_t f0 = 0; ink && f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
         double *fstats = (double *)ws;
@@ -786,6 +840,17 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
         f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
         hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)),
                            dim3(256), 0, st, f);
+        if (mid) {
+          MidArgs m;
+          memset(&m, 0, sizeof(m));
+          m.X = X; m.Y = Y; m.w = w; m.idx = idx; m.offs = offsets; m.seg0 = f0;
+          m.fstats = f.fstats; m.G = G; m.H = H;
+          m.out_XTX = out_XTX; m.out_XTY = want_xty ? out_XTY : nullptr;
+          m.K = K; m.M = M; m.flags = flags;
+          rc = launch_mid<T>(m, w != nullptr, nb, max_rows, st);
+          if (rc != CVM_OK) return rc;
+          continue;
+        }
         WgramArgs<T> a;
         memset(&a, 0, sizeof(a));
         a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;

@@ -1489,7 +1489,7 @@ class CVMatrix:
         """One fold of at most 32 rows given as an int64 index array -- the call of the reference's
         leave-one-out loop (one ``training_XTX_XTY(validation_indices)`` per sample,
         benchmarks/benchmark.py:153-158): same checks, same library call (``cvm_fold_update`` with
-        the indices inside the kernel arguments, CVM_IDX_HOST) and same bits as the general route,
+        the indices inside the kernel arguments, CVM_IDX_HOST) and same results as the general route,
         without building a ``FoldBatch``, without a fold axis, with three allocations."""
         lib = _lib.load()
         self._ensure_fit()

@@ -1652,8 +1652,8 @@ def test_lazy_fit_raises_on_negative_device_weights_in_fit(amd):
 
 def test_one_small_fold_per_call_sends_indices_with_the_launch(amd):
     """The reference's call pattern with tiny folds (leave-one-out): the indices of the single fold
-    travel in the kernel arguments (CVM_IDX_HOST), no device index array is made; same bits as the
-    same fold inside a batch that uploads its indices."""
+    travel in the kernel arguments (CVM_IDX_HOST), no device index array is made; same XTX bits and
+    statistics as the same fold inside a batch that uploads its indices."""
     import ctypes as C
 
     import torch
@@ -1671,7 +1671,13 @@ def test_one_small_fold_per_call_sends_indices_with_the_launch(amd):
         b2 = m.prepare_folds([v, np.array([0, 1])])
         assert not b2.inline
         (c, d), sc = m.training_XTX_XTY_batched(b2)
-        assert torch.equal(a[0], c[0]) and torch.equal(b[0], d[0])
+        assert torch.equal(a[0], c[0])
+        if v.size < 8:
+            assert torch.equal(b[0], d[0])
+        else:
+            # (a batch of folds of eight rows or more takes mid_tile_kernel, whose XTY sums run on the matrix
+            #  cores like its XTX sums; the one-fold call keeps the small-fold kernels' scalar XTY sums)
+            assert float((b[0] - d[0]).norm() / d[0].norm()) < 1e-13
         for s, t in zip(sa, sc):
             assert torch.equal(s[0], t[0])
         st = m.training_statistics_batched(b1)             # statistics-only: uploads on demand

@@ -16,7 +16,10 @@ PS = [int(p) for p in os.environ["FOLD_PS"].split(",")] if os.environ.get("FOLD_
 for P in PS:
     nv = N // P
     nf = min(P, max(1, int(8e9 // (K * (K + M) * 8))))      # cap the output at 8 GB
-    folds = [np.arange(f, N, P)[:nv] for f in range(nf)]
+    if os.environ.get("FOLD_CONTIG"):      # diagnostic: contiguous validation rows instead of the reference's f, f + P, ...
+        folds = [np.arange(f * nv, (f + 1) * nv) for f in range(nf)]
+    else:
+        folds = [np.arange(f, N, P)[:nv] for f in range(nf)]
     b = m.prepare_folds(folds)
     o = m.training_XTX_XTY_batched(b); del o; torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

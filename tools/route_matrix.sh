@@ -3,12 +3,13 @@
 # forced row-split plans in both orders, the two-stage route instead of the fused epilogue, the
 # general Gram kernel instead of the LDS-DMA one, the separate finalize kernels instead of the
 # one-call sweep's, the tile kernel instead of the whole-rows kernel for tiny folds, no compaction /
-# inline statistics, no loop serving, the direct kernels for folds of up to 64 / 128 rows.
+# inline statistics, no loop serving, the direct kernels for folds of up to 64 / 128 rows, the mid-size tile
+# kernel off / from one row per fold / up to 1000 rows per fold.
 #   bash tools/route_matrix.sh        (on the GPU box; about two minutes per switch)
 cd "$(dirname "$0")/.."
 for e in "CVM_FORCE_SPLITS=3,5" "CVM_FORCE_SPLITS=7,2" "CVM_NO_FUSED=1" "CVM_FORCE_FALLBACK=1" \
          "CVM_NO_SWEEP_MERGE=1" "CVM_NO_DIRECT=1" "CVM_PAD=0" "CVM_NO_COMPACT=1" "CVM_NO_INLINE_STATS=1" \
-         "CVM_SERVE_LOOPS=0" "CVM_SMALL_MAXN=128" "CVM_SMALL_MAXN=64" "CVM_SMALL_TILE=1" "CVM_SMALL_TILE=2"; do
+         "CVM_SERVE_LOOPS=0" "CVM_SMALL_MAXN=128" "CVM_SMALL_MAXN=64" "CVM_SMALL_TILE=1" "CVM_SMALL_TILE=2" "CVM_MID_TILE=0" "CVM_MID_MINN=1" "CVM_MID_MAXN=1000"; do
   echo "== $e"
   mark="gpu"
   # (with loop serving off, the tests that look INSIDE the serving have nothing to see: they carry the
