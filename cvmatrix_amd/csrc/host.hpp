@@ -650,13 +650,29 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
 }
 
 // mid_tile_kernel over the folds of one batch (their statistics are in m.fstats)
-// Where mid_tile_kernel is the route (float64; tools/exp_mid_small.sh, profiles/r4/exp_mid_small.txt): for K = 512 it
-// beats the direct small-fold kernels from 8 rows per fold up (16 rows: 1.60 against 1.84 ms for 2774 folds, 32
-// rows: 1.93 / 2.40) and the fused Gram route up to ~250 rows (100 rows: 1.02 / 1.25 ms, 256: 0.80 / 0.84); for
-// K = 1024 from 16 rows (1.33 / 1.47 ms) to ~200 (2.71 / 2.78); for K = 4096 never (G no longer fits the L2: its
-// tile reads come from HBM row by row, 3.0 against 1.1 ms at 8 rows) -- no mid route above K = 1024.
-inline int mid_default_minn(int K) { return K < 768 ? 8 : (K <= 1024 ? 16 : (1 << 30)); }
-inline int mid_default_maxn(int K) { return K < 768 ? 256 : (K <= 1024 ? 200 : 0); }
+// Where mid_tile_kernel is the route (tools/exp_mid_small.sh; profiles/r4/mid_tile/exp_mid_small*.txt), rows per fold:
+//   float64  K = 512: from 8 (1.32 against 1.46 ms for 2774 folds; 32 rows 1.93 / 2.40) to 256 (0.79 / 0.81; 320: 0.79 / 0.75)
+//            K = 1024, 2048: from 16 (1.33 / 1.40 ms, 1.32 / 1.32) to 200 (2.76 / 2.84, 3.63 / 3.71)
+//            K = 4096: never (3.0 against 1.1 ms at 8 rows: 2080 tiles per fold, G's tile rows come from HBM one by one)
+//   float32  K = 512, 1024: from 8 (1.60 / 1.87 ms for 5548 folds; 100 rows 0.55 / 0.81) to 320 (0.44 / 0.48; 1.51 / 1.51)
+//            K = 2048: from 16 (1.43 / 1.51) to 256 (4.70 / 5.06)
+// below: the direct small-fold kernels; above: the fused epilogue of the Gram kernel.
+inline int mid_default_minn(int K, int esize) {
+  if (K > 2048) return 1 << 30;
+  if (esize == 4) return K <= 1024 ? 8 : 16;
+  return K < 768 ? 8 : 16;
+}
+inline int mid_default_maxn(int K, int esize) {
+  if (K > 2048) return 0;
+  if (esize == 4) return K <= 1024 ? 320 : 256;
+  return K < 768 ? 256 : 200;
+}
+// what the kernel needs of the operands: rows of X, Y in whole 16-byte pieces, 32-bit row numbers
+template <typename T> bool mid_operands_ok(const void *X, const void *Y, const void *w, int64_t N, int K, int M) {
+  constexpr int EPL = 16 / (int)sizeof(T);
+  return N <= 0x7fffffffLL && K >= EPL && rows_aligned(X, K, sizeof(T)) && M % EPL == 0 && (uintptr_t)Y % 16 == 0 &&
+         (uintptr_t)w % sizeof(T) == 0;
+}
 template <typename T> int launch_mid(MidArgs m, bool weighted, int64_t nb, int64_t max_rows, hipStream_t st) {
   m.nt = (m.K + 63) / 64;
   m.n_xtx = m.nt * (m.nt + 1) / 2;
@@ -670,14 +686,10 @@ template <typename T> int launch_mid(MidArgs m, bool weighted, int64_t nb, int64
   if (m.per_xcd * 8 > 0x7fffffffLL) return fail(CVM_EINVAL, "launch_mid: too many work items%s");
   const dim3 grid((unsigned)(m.per_xcd * 8));
   if (lds > 64 * 1024) return fail(CVM_EINVAL, "launch_mid: folds too long for the LDS lists%s");
-  if constexpr (sizeof(T) == 8) {
-    TimedLaunch *tl = timed_begin(KIND_FOLD, st);
-    if (weighted) hipLaunchKernelGGL((mid_tile_kernel<T, true>), grid, dim3(MID_THREADS), lds, st, m);
-    else hipLaunchKernelGGL((mid_tile_kernel<T, false>), grid, dim3(MID_THREADS), lds, st, m);
-    timed_end(tl, st);
-  } else {
-    return fail(CVM_EINVAL, "launch_mid: float64 only%s");
-  }
+  TimedLaunch *tl = timed_begin(KIND_FOLD, st);
+  if (weighted) hipLaunchKernelGGL((mid_tile_kernel<T, true>), grid, dim3(MID_THREADS), lds, st, m);
+  else hipLaunchKernelGGL((mid_tile_kernel<T, false>), grid, dim3(MID_THREADS), lds, st, m);
+  timed_end(tl, st);
   HIP_OK(hipGetLastError());
   return CVM_OK;
 }
@@ -747,16 +759,15 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   //  for where mid_tile_kernel takes over; float64 only, like that kernel)
   static const int mid_minn_env = getenv("CVM_MID_MINN") ? atoi(getenv("CVM_MID_MINN")) : 0;
   static const bool mid_off = getenv("CVM_MID_TILE") && atoi(getenv("CVM_MID_TILE")) == 0;
-  const int mid_minn = mid_off ? (1 << 30) : (mid_minn_env > 0 ? mid_minn_env : mid_default_minn(K));
+  const int mid_minn = mid_off ? (1 << 30) : (mid_minn_env > 0 ? mid_minn_env : mid_default_minn(K, (int)sizeof(T)));
   static const int mid_maxn_env0 = getenv("CVM_MID_MAXN") ? atoi(getenv("CVM_MID_MAXN")) : 0;
   static const bool force_fallback0 = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
   static const bool no_fused0 = getenv("CVM_NO_FUSED") && atoi(getenv("CVM_NO_FUSED")) != 0;
-  // (... and only where that kernel can run: the conditions of the fused route below)
-  // (a fold whose indices come inside the call -- CVM_IDX_HOST, one fold of at most 32 rows -- is the small route's)
-  const bool skip_small = sizeof(T) == 8 && !(flags & CVM_IDX_HOST) && max_rows >= mid_minn && ((flags & CVM_RET_XTX) && out_XTX) &&
-                          max_rows <= (mid_maxn_env0 > 0 ? mid_maxn_env0 : mid_default_maxn(K)) && N <= 0x7fffffffLL &&
-                          K >= 2 && rows_aligned(X, K, sizeof(T)) && M % 2 == 0 && (uintptr_t)Y % 16 == 0 &&
-                          (uintptr_t)w % 8 == 0 && !force_fallback0 && !no_fused0;
+  // (... only where that kernel can run -- the conditions of the fused route below; a fold whose indices come
+  //  inside the call -- CVM_IDX_HOST, one fold of at most 32 rows -- is the small route's)
+  const bool skip_small = !(flags & CVM_IDX_HOST) && max_rows >= mid_minn && ((flags & CVM_RET_XTX) && out_XTX) &&
+                          max_rows <= (mid_maxn_env0 > 0 ? mid_maxn_env0 : mid_default_maxn(K, (int)sizeof(T))) &&
+                          mid_operands_ok<T>(X, Y, w, N, K, M) && !force_fallback0 && !no_fused0;
   if (max_rows <= small_route_limit(K, (int)sizeof(T)) && !skip_small)
     return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
@@ -799,8 +810,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       // CVM_MID_TILE=0: the fused route for them too (tests, comparisons); CVM_MID_MAXN: the row limit.
       static const int mid_env = getenv("CVM_MID_TILE") ? atoi(getenv("CVM_MID_TILE")) : 1;
       static const int mid_maxn_env = getenv("CVM_MID_MAXN") ? atoi(getenv("CVM_MID_MAXN")) : 0;
-      const int mid_maxn = mid_maxn_env > 0 ? mid_maxn_env : mid_default_maxn(K);
-      const bool mid = mid_env != 0 && max_rows <= mid_maxn && N <= 0x7fffffffLL && K >= 2 && sizeof(T) == 8;
+      const int mid_maxn = mid_maxn_env > 0 ? mid_maxn_env : mid_default_maxn(K, (int)sizeof(T));
+      const bool mid = mid_env != 0 && max_rows <= mid_maxn && mid_operands_ok<T>(X, Y, w, N, K, M);
       const bool ink = !mid && !prepass_forced && p.g.Yc == 1 && fst + (size_t)p.g.P * 4 + 256 <= per_fold;
       for (int64_t f0 = 0; ink && f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;

@@ -70,7 +70,12 @@ for c in range(cases):
     tc = (64 if Kd <= 64 * vw else (128 if Kd <= 128 * vw else 256)) * vw
     rows_kernel = (max(len(v) for v in folds) <= 2 and P >= 8 and Kd <= tc and 2 * Kd > tc
                    and Kd * Kd * es <= (2 << 20) + (64 << 10) and (Kd * es) % 16 == 0 and (Kd * es) % 128 != 0)
-    if rows_kernel or max(len(v) for v in folds) > 32:      # (beyond 32 rows batch and single call may take different routes)
+    # (a batch of folds of 8 / 16 rows or more takes mid_tile_kernel -- host.hpp: mid_default_minn -- whose sums
+    #  run in the order of the Gram kernel's; the one-fold call keeps the small-fold kernels)
+    nmax_rows = max(len(v) for v in folds)
+    minn = int(os.environ["CVM_MID_MINN"]) if os.environ.get("CVM_MID_MINN") else (8 if (Kd < 768 or (es == 4 and Kd <= 1024)) else 16)
+    mid_route = os.environ.get("CVM_MID_TILE", "1") != "0" and Kd <= 2048 and nmax_rows >= minn
+    if rows_kernel or mid_route or nmax_rows > 32:      # (beyond 32 rows batch and single call may take different routes)
         assert float((one - bx[0]).abs().max()) <= (1e-12 if dt is np.float64 else 1e-5) * float(bx[0].abs().max()), (c, "per-call vs batch")
     else:
         assert torch.equal(one, bx[0]), (c, "per-call vs batch", K, M, nmax, P, dt)
