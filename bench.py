@@ -959,8 +959,9 @@ def main():
                              "unit": "GB/s", "frac": round(bts / ms1 / 1e6 / PEAK_HBM_GBS, 4),
                              "bytes_per_fold": "s*n*(K+M+1) + 8n"}}
         # mid-size folds (between the HBM regime and the headline's ten big folds): the same rows cut
-        # into 100 and 1000 folds, the batched fold stage of the eager object (one unit per fold:
-        # the Gram kernel with the fused epilogue).  Roofline time = the larger of the algorithmic
+        # into 100 and 1000 folds, the batched fold stage of the eager object (one unit per fold: folds of
+        # 1000 rows finish in the Gram kernel's fused epilogue, folds of 100 rows take mid_tile_kernel --
+        # host.hpp: mid_default_maxn).  Roofline time = the larger of the algorithmic
         # flops at the MFMA peak and the bytes that must move (outputs, G once per fold, rows) at
         # the HBM peak; `frac` = that time / the measured time.
         if supp is not None and batch is not None and args.workload in ("C2", "C3") and X is not None:
@@ -979,6 +980,9 @@ def main():
                 supp[f"mid-size folds ({args.workload} rows, P={Pm}, n_val={nvm})"] = {
                     "folds": Pm, "ms": round(ms1, 4), "folds_per_s": round(Pm / ms1 * 1e3, 1),
                     "timing": "6 calls back to back per sample, 3 samples, after 40 ms of the same calls",
+                    "route": ("mid_tile_kernel (64x64 tiles, four workgroups per CU) behind the statistics pre-pass"
+                              if nvm <= (256 if dtype == "f64" else 320) and K < 768 else
+                              "wgram4_kernel<.., FUSED> (statistics formed inside the launch)"),
                     "roofline": {"bound": "mfma" if t_fl >= t_bt else "hbm", "flops_ms_at_peak": round(t_fl, 4),
                                  "bytes_ms_at_peak": round(t_bt, 4), "frac": round(max(t_fl, t_bt) / ms1, 4),
                                  "flops": "n*(K(K+1) + 2KM) per fold", "bytes": "s*n*(K+M+1) + 8n + 2*s*K*(K+M) per fold"}}
