@@ -813,6 +813,27 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       const int mid_maxn = mid_maxn_env > 0 ? mid_maxn_env : mid_default_maxn(K, (int)sizeof(T));
       const bool mid = mid_env != 0 && max_rows <= mid_maxn && mid_operands_ok<T>(X, Y, w, N, K, M);
       const bool ink = !mid && !prepass_forced && p.g.Yc == 1 && fst + (size_t)p.g.P * 4 + 256 <= per_fold;
+      // (CVM_MID_OWNSTATS=1: its items form the statistics of their own columns from the rows they stage -- no
+      //  pre-pass, no workspace, the same bits.  Measured and NOT the default: every one of a fold's 36 tiles sums
+      //  its 128 columns again, in row order on the vector units -- the C3 rows in 1000 folds 1.11 -> 1.36 ms, in
+      //  3000 folds 2.09 -> 2.22 ms, where the pre-pass costs 0.095 ms; profiles/r4/mid_tile/own_statistics.txt)
+      static const bool mid_own = getenv("CVM_MID_OWNSTATS") && atoi(getenv("CVM_MID_OWNSTATS")) != 0;
+      if (mid && mid_own) {
+        for (int64_t f0 = 0; f0 < n_folds; f0 += 16384) {
+          const int64_t nb = (n_folds - f0 < 16384) ? n_folds - f0 : 16384;
+          MidArgs m;
+          memset(&m, 0, sizeof(m));
+          m.X = X; m.Y = Y; m.w = w; m.idx = idx; m.offs = offsets; m.seg0 = f0;
+          m.fstats = nullptr; m.gstats = gstats; m.ddof = ddof; m.resolution = resolution;
+          m.out_muX = out_muX; m.out_sdX = out_sdX; m.out_muY = out_muY; m.out_sdY = out_sdY; m.out_fold = out_fold;
+          m.G = G; m.H = H;
+          m.out_XTX = out_XTX; m.out_XTY = want_xty ? out_XTY : nullptr;
+          m.K = K; m.M = M; m.flags = flags;
+          rc = launch_mid<T>(m, w != nullptr, nb, max_rows, st);
+          if (rc != CVM_OK) return rc;
+        }
+        return CVM_OK;
+      }
       for (int64_t f0 = 0; ink && f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
         double *fstats = (double *)ws;

@@ -39,7 +39,12 @@ struct MidArgs {
   const void *X, *Y, *w;
   const int64_t *idx, *offs;
   int64_t seg0;                  // first fold of this batch in offs / the outputs
-  const double *fstats;          // [fold of batch][fstat_len]
+  const double *fstats;          // [fold of batch][fstat_len] from the pre-pass, or nullptr: every item forms the
+                                 // statistics of its own columns (below) from the rows it stages anyway
+  const double *gstats;          // (then:) the full-data sums, cvm_gstats_len entries
+  double ddof, resolution;
+  void *out_muX, *out_sdX, *out_muY, *out_sdY;
+  double *out_fold;
   const void *G, *H;
   void *out_XTX, *out_XTY;
   long long n_items, per_xcd;    // work items; workgroups per XCD
@@ -68,7 +73,7 @@ template <typename T> constexpr size_t mid_region_bytes() {
   return tile > ring ? tile : ring;
 }
 template <typename T> inline size_t mid_lds_bytes(int maxn) {
-  return mid_region_bytes<T>() + 256 * 8 + (size_t)maxn * sizeof(T) + (size_t)maxn * 4;
+  return mid_region_bytes<T>() + 2 * 256 * 8 + (size_t)maxn * sizeof(T) + (size_t)maxn * 4;
 }
 
 template <typename T, bool WEIGHTED>
@@ -123,30 +128,52 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
   const int n = (int)(a.offs[a.seg0 + f + 1] - rbeg);
   const int nks = (n + 3) >> 2, nst = (nks + KPS - 1) / KPS;
   T *ring = reinterpret_cast<T *>(smem_raw);
+  // statistics blocks: rs = fused_finish_direct's ([0,64) row means, [64,128) row reciprocal stds, [128,256) the
+  // same for the columns); sq = the column sums while they are being formed, then the XTY block:
+  // [0,64) row means for XTY, [64,128) response means, [128,192) response reciprocal stds
   double *rs = reinterpret_cast<double *>(smem_raw + mid_region_bytes<T>());
-  T *wl = reinterpret_cast<T *>(rs + 256);
+  double *sq = rs + 256;
+  T *wl = reinterpret_cast<T *>(sq + 256);
   int *rowl = reinterpret_cast<int *>(wl + a.maxn);
   T (*Ts)[65] = reinterpret_cast<T (*)[65]>(smem_raw);
-  const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+  const bool own = a.fstats == nullptr;
+  const double *fs = own ? nullptr : a.fstats + (size_t)f * fstat_len(K, M);
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const bool rXTY = a.flags & CVM_RET_XTY;
+  const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
+  const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
   const size_t fo = (size_t)(a.seg0 + f);
   const bool finish_xtx = kind == 0 && a.out_XTX != nullptr;
+  // the response columns this item holds in LDS: a diagonal tile the first sixteen, an XTY-only item up to 64
+  const int ybase = kind == 2 ? 16 + 64 * yc : 0;
+  const int ny = !want_xty ? 0 : (kind == 2 ? (M - ybase < 64 ? M - ybase : 64) : (diag ? (M < 16 ? M : 16) : 0));
+  const int which = tid >> 6, wc64 = tid & 63;
 
   // ---- the fold's row numbers, the tile's statistics (the weights: behind the first stages' DMAs) ----
   const int npad = nst * SR;
   for (int r = tid; r < npad; r += MID_THREADS) rowl[r] = r < n ? (int)a.idx[rbeg + r] : 0;
-  if (kind == 0) {
-    const int which = tid >> 6, c = tid & 63;
-    const int col = ((which < 2) ? a0 : b0) + c;
+  double swt = 0.0;
+  // (own statistics) the full-data sums of this thread's column of the blocks: X column and response column
+  double gsx = 0, gqx = 0, gsy = 0, gqy = 0, gsw = 0, gnz = 0;
+  const int xcol = ((which < 2) ? a0 : b0) + wc64;        // (diagonal tile: b0 == a0)
+  const int ycol = ybase + wc64;
+  if (!own) {
     double v = (which & 1) ? 1.0 : 0.0;
-    if (col < K) {
-      if (!(which & 1) && cX) v = fs[col];
-      if ((which & 1) && sX) v = fs[K + col];
+    if (xcol < K && (kind == 0 || which < 2)) {
+      if (!(which & 1) && cX) v = fs[xcol];
+      if ((which & 1) && sX) v = fs[K + xcol];
     }
     rs[tid] = v;
+    if (which == 0) sq[wc64] = ((cX || cY) && xcol < K) ? fs[xcol] : 0.0;
+    if (which == 2) sq[64 + wc64] = ((cX || cY) && wc64 < ny) ? fs[2 * K + ycol] : 0.0;
+    if (which == 3) sq[128 + wc64] = (sY && wc64 < ny) ? fs[2 * K + M + ycol] : 1.0;
+    swt = fs[2 * K + 2 * M];
+  } else {
+    if (xcol < K && (kind == 0 || which < 2)) { gsx = a.gstats[xcol]; gqx = a.gstats[K + xcol]; }
+    if (which >= 2 && wc64 < ny) { gsy = a.gstats[2 * K + ycol]; gqy = a.gstats[2 * K + M + ycol]; }
+    gsw = a.gstats[2 * K + 2 * M]; gnz = a.gstats[2 * K + 2 * M + 1];
   }
-  const double swt = fs[2 * K + 2 * M];
   __syncthreads();
 
   // ---- LDS-DMA of one stage; returns the number of instructions this wave issued ---------------------
@@ -231,6 +258,93 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
     lds_barrier();
     cnt[(s + NBUF - 1) % NBUF] = (s + NBUF - 1 < nst) ? issue(s + NBUF - 1) : 0;
   };
+  // ---- own statistics: lane (c, half) of wave w sums column 32 w + c of the 128 staged columns over the
+  // fold's rows IN ROW ORDER -- half 0: s += w x, half 1: q += (w x) x, in float64 like colstats_kernel, so the
+  // statistics are the pre-pass's (and small_stats_kernel's) bit for bit; thread 0 sums the weights.
+  const int scol = 32 * wave + (lane & 31);
+  const bool is_q = lane >= 32;
+  const bool sB = scol >= 64;
+  const bool svalid = own && (sB ? (loadB ? true : (scol - 64 < ny)) : true);
+  const int soff = !sB ? scol : (loadB ? SR * 64 + (scol - 64) : SR * 64 + ((scol - 64) >> 4) * SR * 16 + ((scol - 64) & 15));
+  const int srs = (!sB || loadB) ? 64 : 16;
+  double sacc = 0.0, swv = 0.0, nzv = 0.0;
+  auto stage_stats = [&](int s) {
+    if (!own) return;
+    const T *buf = ring + (s % NBUF) * MID_STAGE_ELEMS;
+    const T *wst = wl + SR * s;
+    const int rows_here = n - SR * s < SR ? n - SR * s : SR;
+    if (svalid) {
+#pragma unroll 4
+      for (int r = 0; r < rows_here; ++r) {
+        const T x = buf[soff + r * srs];
+        const T pv = WEIGHTED ? (T)(x * wst[r]) : x;
+        sacc += is_q ? (double)(T)(pv * x) : (double)pv;
+      }
+    }
+    if (WEIGHTED && tid == 0) {
+      for (int r = 0; r < rows_here; ++r) { swv += (double)wst[r]; nzv += (wst[r] != (T)0) ? 1.0 : 0.0; }
+    }
+  };
+  // one column: mean, reciprocal std and std of the training set (fold_column_finish's formulas, finalize.hpp)
+  auto finish_col = [&](double sv, double qv, double gs, double gq, double swt_, double divisor, bool want_sd,
+                        double &mu, double &isd, double &sd) {
+    const double st_ = gs - sv;          // cvmatrix.py:1020
+    mu = st_ / swt_;                     // cvmatrix.py:1043
+    sd = 1.0;
+    if (want_sd) {
+      const double qt = gq - qv;
+      double var = (-2 * mu * st_ + swt_ * (mu * mu) + qt) / divisor;   // 1119-1123
+      var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
+      sd = sqrt(var);
+      if (sd <= a.resolution) sd = 1.0;  // 1128
+    }
+    isd = 1.0 / sd;
+  };
+  // after the stage loop (every wave): the sums meet in LDS, every thread derives its entries of the blocks;
+  // a diagonal tile (and the XTY items of panel 0) also write the statistics the call returns
+  auto stats_phase = [&]() {
+    if (!own) return;
+    if (svalid) sq[scol + (is_q ? 128 : 0)] = sacc;
+    if (tid == 0) { rs[0] = WEIGHTED ? swv : (double)n; rs[1] = WEIGHTED ? nzv : (double)n; }
+    lds_barrier();
+    const double swv_ = rs[0], nzv_ = rs[1];
+    const double swt_ = gsw - swv_, nzt = gnz - nzv_;
+    const double divisor = (nzt - a.ddof) * swt_ / nzt;
+    swt = swt_;
+    double v_rs = (which & 1) ? 1.0 : 0.0, v_y = (which == 3) ? 1.0 : 0.0;
+    const int xi = (which < 2 || diag) ? wc64 : 64 + wc64;           // this thread's X column among the staged sums
+    if (xcol < K && (kind == 0 || which < 2) && want_muX) {
+      double mu, isd, sd;
+      finish_col(sq[xi], sq[128 + xi], gsx, gqx, swt_, divisor, want_sdX, mu, isd, sd);
+      if (which & 1) { if (sX) v_rs = isd; }
+      else { if (cX) v_rs = mu; if (which == 0 && (cX || cY)) v_y = mu; }
+      if (diag && which == 0) {
+        const size_t o = fo * K + xcol;
+        if (a.out_muX) reinterpret_cast<T *>(a.out_muX)[o] = (T)mu;
+        if (a.out_sdX && want_sdX) reinterpret_cast<T *>(a.out_sdX)[o] = (T)sd;
+      }
+    }
+    if (which >= 2 && wc64 < ny && want_muY) {
+      double mu, isd, sd;
+      finish_col(sq[64 + wc64], sq[192 + wc64], gsy, gqy, swt_, divisor, want_sdY, mu, isd, sd);
+      if (which == 2) { if (cX || cY) v_y = mu; }
+      else if (sY) v_y = isd;
+      if (ti == 0 && which == 2) {
+        const size_t o = fo * M + ycol;
+        if (a.out_muY) reinterpret_cast<T *>(a.out_muY)[o] = (T)mu;
+        if (a.out_sdY && want_sdY) reinterpret_cast<T *>(a.out_sdY)[o] = (T)sd;
+      }
+    }
+    if (tid == 0 && diag && ti == 0 && a.out_fold) {
+      double *o = a.out_fold + 4 * fo;
+      o[0] = swt_; o[1] = nzt; o[2] = swv_; o[3] = nzv_;
+    }
+    lds_barrier();                                       // everybody has read the sums
+    rs[tid] = v_rs;
+    if (which == 0) sq[wc64] = v_y;
+    if (which == 2) sq[64 + wc64] = v_y;
+    if (which == 3) sq[128 + wc64] = v_y;
+  };
   if (role == 2) {
     acc_t acc[4];
 #pragma unroll
@@ -260,27 +374,29 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
     for (int s = 0; s < nst; ++s) {
       stage_head(s);
       ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
+      stage_stats(s);
     }
+    g_preload();
+    stats_phase();
+    lds_barrier();                                       // the blocks are in LDS; the ring is free
     // XTY piece straight from the accumulators (cvmatrix.py:1001-1010 for XTY)
     T *out = reinterpret_cast<T *>(a.out_XTY) + fo * (size_t)K * M;
     const T *Ht = reinterpret_cast<const T *>(a.H);
-    const int col = ycol0 + lc;
+    const int col = ycol0 + lc, yl = col - ybase;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = a0 + 16 * m + MF<T>::drow(lane, r);
+        const int lr = 16 * m + MF<T>::drow(lane, r), row = a0 + lr;
         if (row < K && col < M) {
           double vv = (double)Ht[(size_t)row * M + col] - (double)acc[m][r];
-          if (cX || cY) vv -= swt * (fs[row] * fs[2 * K + col]);
-          if (sX && sY) vv = vv * (fs[K + row] * fs[2 * K + M + col]);
-          else if (sX) vv = vv * fs[K + row];
-          else if (sY) vv = vv * fs[2 * K + M + col];
+          if (cX || cY) vv -= swt * (sq[lr] * sq[64 + yl]);
+          if (sX && sY) vv = vv * (rs[64 + lr] * sq[128 + yl]);
+          else if (sX) vv = vv * rs[64 + lr];
+          else if (sY) vv = vv * sq[128 + yl];
           out[(size_t)row * M + col] = (T)vv;
         }
       }
-    g_preload();
-    if (finish_xtx) lds_barrier();                       // the ring is free: the tile goes over it
   } else {
     acc_t acc[4];
 #pragma unroll
@@ -312,10 +428,12 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
     for (int s = 0; s < nst; ++s) {
       stage_head(s);
       if (role == 1) ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
+      stage_stats(s);
     }
     g_preload();
+    stats_phase();
+    lds_barrier();                                       // the blocks are in LDS; the ring is free: the tile goes over it
     if (finish_xtx) {
-      lds_barrier();                                     // the ring is free: the tile goes over it
       if (role == 1) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
