@@ -89,7 +89,12 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
   (void)n_idx;
   if (max_fold_rows <= SMALL_ROWS) {   // direct path: only the per-fold statistics live in ws
     const int64_t nb = n_folds < 32768 ? (n_folds > 0 ? n_folds : 1) : 32768;
-    return (size_t)nb * small_ws_per_fold(K, M, dtype == CVM_F64 ? 8 : 4) + 512 + QUEUE_RESERVE;
+    const size_t small = (size_t)nb * small_ws_per_fold(K, M, dtype == CVM_F64 ? 8 : 4) + 512;
+    // (batches of folds of 8 rows or more may take mid_tile_kernel behind the statistics pre-pass: one
+    //  statistics unit and one statistics vector per fold)
+    const Geom gs = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 1);
+    const size_t pre = (size_t)nb * (align_up(gs.stat_len * 8, 256) + align_up(fstat_len(K, M) * 8, 256));
+    return (small > pre ? small : pre) + QUEUE_RESERVE;
   }
   const Geom g = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, !(flags & CVM_RET_XTX));
   const int splits = plan_stride(n_folds, max_fold_rows, g, dtype == CVM_F64 ? 8 : 4);

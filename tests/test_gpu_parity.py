@@ -1522,12 +1522,13 @@ def test_forced_split_plans(plan):
 
 @pytest.mark.parametrize("switch", ["CVM_NO_FUSED=1", "CVM_FORCE_FALLBACK=1", "CVM_NO_SWEEP_MERGE=1", "CVM_NO_DIRECT=1",
                                     "CVM_NO_COMPACT=1", "CVM_NO_INLINE_STATS=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0",
-                                    "CVM_SMALL_MAXN=128"])
+                                    "CVM_SMALL_MAXN=128", "CVM_MID_TILE=0", "CVM_MID_MINN=1", "CVM_MID_MAXN=1000",
+                                    "CVM_MID_OWNSTATS=1"])
 def test_route_forcing_switches(switch):
     """One pass of tools/route_matrix.sh inside the suite: every route-forcing switch of the library
     (read once per process, hence a subprocess each) over tests/forced_plan_check.py -- two-stage
-    path, sweep, per-fold calls, mid-size folds (fused epilogue / two-stage), folds of a few rows
-    (tile kernel / whole-rows kernel) -- against the oracle at 1e-10."""
+    path, sweep, per-fold calls, mid-size folds (tile kernel with either source of statistics / fused epilogue
+    / two-stage), folds of a few rows (tile kernel / whole-rows kernel) -- against the oracle at 1e-10."""
     import subprocess
 
     k, v = switch.split("=")
