@@ -43,7 +43,7 @@ cp $(ls $O/pls/*/*_kernel_stats.csv | head -1) $D/pls_kernel_stats.csv 2>/dev/nu
 cd $ROOT
 python3 bench.py > $O/plain.out 2>&1; grep "^{" $O/plain.out | tail -1 > $D/bench_bench_plain.json
 python3 tools/bench_foldsizes.py > $D/fold_size_sweep.txt 2>/dev/null
-# mid-size folds (P = 1000) under the counters: the fused route with the statistics formed in the launch
+# mid-size folds (P = 1000) under the counters: mid_tile_kernel behind the statistics pre-pass
 FOLD_PS=1000 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/mid_fetch -- python3 $ROOT/tools/bench_foldsizes.py > /dev/null 2>&1
 FOLD_PS=1000 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/mid_write -- python3 $ROOT/tools/bench_foldsizes.py > /dev/null 2>&1
 mkdir -p $O/midpmc; mv $O/mid_fetch $O/midpmc/pmc_fetch; mv $O/mid_write $O/midpmc/pmc_write
