@@ -1592,6 +1592,53 @@ def test_direct_route_beyond_one_chunk_by_the_default_table(amd, dtype, K, M, nv
         assert bool((bx[f] == bx[f].T).all())
 
 
+@pytest.mark.parametrize("dtype,K,M,sizes", [
+    (np.float64, 512, 16, (100, 8, 9, 255, 256, 17)),      # the bench's mid-size shape; the route's edges at K = 512
+    (np.float64, 66, 2, (40, 12, 64, 65)),                 # one tile column past the first panel
+    (np.float64, 130, 40, (33, 48, 100, 16)),              # M > 16: XTY-only items; K just past two panels
+    (np.float64, 1030, 4, (16, 60, 200, 31)),              # K = 1024 + one piece: 17 panels, from 16 rows
+    (np.float64, 2048, 2, (16, 120)),                      # the widest shape of the route
+    (np.float64, 384, 0, (90, 10, 130)),                   # no Y
+    (np.float32, 512, 16, (100, 8, 320, 47)),
+    (np.float32, 260, 20, (64, 9, 150)),
+    (np.float32, 1024, 4, (8, 100, 319)),
+])
+def test_mid_tile_route_shapes(amd, dtype, K, M, sizes):
+    """Batches of folds of 8 / 16 to a few hundred rows take mid_tile_kernel (host.hpp: mid_default_minn /
+    _maxn): every flag set that changes its finish, weights with zeros and none, ragged folds incl. the
+    sizes at the route's limits and partial last k-steps, against the oracle (float32: the oracle's own
+    float32 run as the yardstick); exact symmetry of every XTX."""
+    rng = np.random.default_rng(K * 7 + M)
+    N = sum(sizes) + 57
+    X = (rng.standard_normal((N, K)) + 0.25).astype(dtype)
+    Y = rng.random((N, M)).astype(dtype) if M else None
+    w = rng.random(N).astype(dtype)
+    w[rng.choice(N, N // 12, replace=False)] = 0
+    perm = rng.permutation(N)
+    folds, o_ = [], 0
+    for n in sizes:
+        folds.append(np.sort(perm[o_:o_ + n])); o_ += n
+    for flags, wt in (((True,) * 4, w), ((False,) * 4, w), ((True, False, False, True), None), ((False, True, True, False), w)):
+        if dtype is np.float64:
+            m, _ = _compare_with_oracle(amd, X, Y, wt, folds, flags)
+            bx = (m.training_XTX_XTY_batched(folds)[0][0] if M else m.training_XTX_batched(folds)[0])
+        else:
+            m = amd.CVMatrix(*flags, dtype=np.float32)
+            m.fit(X, Y, wt)
+            o = OracleCVMatrix(*flags)
+            o.fit(X.astype(np.float64), None if Y is None else Y.astype(np.float64), None if wt is None else wt.astype(np.float64))
+            o32 = OracleCVMatrix(*flags, dtype=np.float32)
+            o32.fit(X, Y, wt)
+            (bx, by), _ = m.training_XTX_XTY_batched(folds)
+            for f, v in enumerate(folds):
+                (rx, ry), _ = o.training_XTX_XTY(v)
+                (sx, sy), _ = o32.training_XTX_XTY(v)
+                assert_fp32_like_reference(bx[f], rx, sx, f"fold{f} XTX")
+                assert_fp32_like_reference(by[f], ry, sy, f"fold{f} XTY")
+        for f in range(len(folds)):
+            assert bool((bx[f] == bx[f].T).all())
+
+
 @pytest.mark.parametrize("tool,args,env", [("fuzz_all.py", ["300", "101"], {}), ("fuzz_small.py", ["500", "102"], {}),
                                            ("fuzz_small.py", ["250", "103"], {"CVM_SMALL_MAXN": "128"})])
 def test_randomised_routes_against_the_oracle(tool, args, env):
