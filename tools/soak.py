@@ -16,7 +16,10 @@ for (N, K, M, P, dt, lazy) in ((100000, 512, 16, 10, torch.float64, False), (600
                                # sweep with 16 folds and in float32, two folds
                                (60000, 516, 5, 600, torch.float32, False), (3000, 500, 10, 3000, torch.float32, False),
                                (64000, 388, 34, 16, torch.float64, True), (80000, 516, 3, 5, torch.float32, True),
-                               (50000, 1028, 2, 2, torch.float64, True)):
+                               (50000, 1028, 2, 2, torch.float64, True),
+                               # round 4: mid_tile_kernel (folds of 100 / 33 / 12 rows), float64 and float32
+                               (100000, 512, 16, 1000, torch.float64, False), (100000, 512, 16, 3000, torch.float32, False),
+                               (24000, 1024, 4, 2000, torch.float64, False)):
     g = torch.Generator(device=dev); g.manual_seed(K)
     X = torch.rand((N, K), dtype=dt, device=dev, generator=g)
     Y = torch.rand((N, M), dtype=dt, device=dev, generator=g) if M else None
