@@ -1,5 +1,5 @@
 // mid_tile.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
-// mid_tile_kernel (round 4): training matrices of MID-SIZE folds (a few dozen to ~200 validation rows) with
+// mid_tile_kernel (round 4): training matrices of MID-SIZE folds (8 to ~300 validation rows, float64 and float32) with
 // the Gram stage and the finishing step of DIFFERENT work items overlapping on every CU.
 //
 // Why another kernel.  The fused route of wgram4_kernel (one persistent 8-wave workgroup per CU, 128 x 128
@@ -7,9 +7,9 @@
 // (4.7 k per 16 rows), then an epilogue that reads G and stores the tile twice (22 k cycles) while the
 // matrix cores idle -- profiles/r3/fused_epilogue_stamps.txt.  With folds of 100 rows the loop is half of
 // an item's 64 k cycles, and nothing else is resident on the CU to fill the gaps (248 registers, 148 KB of
-// LDS).  Here a work item is small -- one 64 x 64 tile of one fold, four waves, 84 registers, ~37 KB of LDS
-// -- so that FOUR workgroups share a CU and the hardware interleaves one item's stores and G loads with
-// another's MFMAs.  (What bounds it -- measured with three structures of this kernel, tools/README.md -- is the
+// LDS).  Here a work item is small -- one 64 x 64 tile of one fold, four waves, 85-127 registers, ~39 KB of LDS
+// (float32: 93 / 21 KB) -- so that FOUR (float32: five) workgroups share a CU and the hardware interleaves one item's stores and G loads with
+// another's MFMAs.  (What bounds it -- measured with five structures of this kernel, DESIGN.md section 4.4 -- is the
 // CU's vector-memory pipe: X panels, G and both halves of the output, ~196 KB per tile at 100 rows, pass through it
 // at ~27 GB/s per CU whatever issues them.)
 //
@@ -32,7 +32,9 @@
 //     tile with fused_finish_direct's arithmetic (finalize.hpp: total - update, rank-1 centring,
 //     reciprocal-std scaling, 16-byte nontemporal stores) and fused_finish_mirror -- the same arithmetic on
 //     the same MFMA sums as the fused route.
-//   * The per-fold statistics come from colstats_kernel + fold_stats_kernel (the pre-pass of host.hpp).
+//   * The per-fold statistics come from colstats_kernel + fold_stats_kernel (the pre-pass of host.hpp) -- or,
+//     MidArgs::fstats == nullptr (CVM_MID_OWNSTATS=1), every item sums its own 128 staged columns in row order
+//     on the vector units and derives them itself: the same bits, no pre-pass, and measured slower (host.hpp).
 #pragma once
 
 struct MidArgs {
