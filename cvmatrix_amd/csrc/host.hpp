@@ -578,7 +578,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     TimedLaunch *t_up = (a.out_XTX || a.out_XTY) ? timed_begin(3, st) : nullptr;
     if (a.out_XTX || a.out_XTY) {
       if (direct) {
-        const int panels = ((K + SR_ROWS - 1) / SR_ROWS) * ((K + tc - 1) / tc);
+        const int panels = ((K + sr_rows<T>(lpr) - 1) / sr_rows<T>(lpr)) * ((K + tc - 1) / tc);
         int fpr = (int)((int64_t)panels * nb / (16 * 256));
         if (fpr < 1) fpr = 1;
         if (fpr > 8) fpr = 8;   // (measured flat from 8 to 16, worse at 32: too few workgroups)

@@ -435,10 +435,17 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256, CVM_SMALL
 // (tools/write_pattern.hip).  G is read for both triangles, so this kernel is for matrices that
 // stay in L2 / MALL across the folds of a batch.  One barrier per fold; the column data (x of the
 // validation rows, means, stds) goes straight from global memory to registers.
+// Rows of the output a workgroup takes per fold (the panel): 32 KB of output either way -- 8 rows of float64, 16
+// rows of float32 (round 4, same box: K = 500 float32 one-row folds 1.305 -> 0.990 ms with 16 rows; float64
+// with 16 rows 0.845 -> 1.225 ms, with 4 rows the same as 8; tools/exp_rows_panel.sh).
 #ifndef CVM_SR_ROWS
 #define CVM_SR_ROWS 8
 #endif
-constexpr int SR_ROWS = CVM_SR_ROWS;
+#ifndef CVM_SR_ROWS_F32
+#define CVM_SR_ROWS_F32 16
+#endif
+// (float32 rows of more than 128 pieces -- K > 512 -- keep 8: sixteen passes per thread leave one workgroup per CU)
+template <typename T> constexpr int sr_rows(int lpr) { return (sizeof(T) == 4 && lpr <= 128) ? CVM_SR_ROWS_F32 : CVM_SR_ROWS; }
 // LPR: 16-byte pieces per output row handled by a workgroup (64, 128 or 256: the smallest that
 // covers K keeps the threads busy); 256 / LPR rows go in one pass, SR_ROWS rows per workgroup.
 template <typename T, bool WEIGHTED, int LPR>
@@ -452,6 +459,7 @@ __global__ __launch_bounds__(256) void small_rows_kernel(const SmallArgs a) {
   typedef typename std::conditional<sizeof(T) == 8, double, float>::type TS;
   constexpr int VW = 16 / (int)sizeof(T);
   constexpr int TC = LPR * VW;
+  constexpr int SR_ROWS = sr_rows<T>(LPR);
   constexpr int RSTEP = 256 / LPR;                 // rows per pass
   constexpr int NP = SR_ROWS / RSTEP;              // passes = pieces per thread
   constexpr int NV = 2;                            // validation rows per fold this kernel takes
