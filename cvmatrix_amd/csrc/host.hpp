@@ -768,7 +768,13 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   const bool skip_small = !(flags & CVM_IDX_HOST) && max_rows >= mid_minn && ((flags & CVM_RET_XTX) && out_XTX) &&
                           max_rows <= (mid_maxn_env0 > 0 ? mid_maxn_env0 : mid_default_maxn(K, (int)sizeof(T))) &&
                           mid_operands_ok<T>(X, Y, w, N, K, M) && !force_fallback0 && !no_fused0;
-  if (max_rows <= small_route_limit(K, (int)sizeof(T)) && !skip_small)
+  // (... and only if the fold stage is planned with one unit per fold -- always, unless a test forces a split plan)
+  bool skip_small_ok = skip_small;
+  if (skip_small_ok) {
+    Plan pp;
+    if (make_plan(n_folds, max_rows, K, M, dtype, flags, (size_t)1 << 60, true, pp) != CVM_OK || pp.splits != 1) skip_small_ok = false;
+  }
+  if (max_rows <= small_route_limit(K, (int)sizeof(T)) && !skip_small_ok)
     return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
   const bool want_xtx = (flags & CVM_RET_XTX) && out_XTX, want_xty = (flags & CVM_RET_XTY) && out_XTY;

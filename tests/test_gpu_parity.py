@@ -1719,7 +1719,10 @@ def test_one_small_fold_per_call_sends_indices_with_the_launch(amd):
         b2 = m.prepare_folds([v, np.array([0, 1])])
         assert not b2.inline
         (c, d), sc = m.training_XTX_XTY_batched(b2)
-        assert torch.equal(a[0], c[0])
+        if v.size < 8 or not os.environ.get("CVM_SMALL_TILE"):
+            assert torch.equal(a[0], c[0])
+        else:      # (the opt-in experimental tile kernel of the one-fold call sums in another order than mid_tile_kernel)
+            assert float((a[0] - c[0]).norm() / c[0].norm()) < 1e-13
         if v.size < 8:
             assert torch.equal(b[0], d[0])
         else:
