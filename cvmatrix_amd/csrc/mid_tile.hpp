@@ -17,7 +17,7 @@
 //     share the row panel are neighbours), then -- only when M > 16 -- XTY-only items for the response
 //     columns past the first sixteen.  Workgroup b takes item (b % 8) * per_xcd + b / 8: the hardware deals
 //     workgroups to the XCDs round-robin, so an XCD works on a contiguous range of folds and its L2 serves
-//     the 2 nt panel reads of every validation row and the re-reads of G (measured: 0.53 GB fetched from HBM
+//     the 2 nt panel reads of every validation row and the re-reads of G (measured: 0.45 GB fetched from HBM
 //     at P = 1000 where the fused route fetches 1.59 GB).
 //   * Off-diagonal tile: the four waves form a 2 x 2 grid of 32 x 32 blocks (four MFMA tiles each).
 //     Diagonal tile: the waves of blocks (0,0), (0,1), (1,1) do the same with the row panel on both sides;
