@@ -24,7 +24,7 @@ IDX_HOST = 0x40
 
 EXPORTS = (
     "cvm_version", "cvm_source_hash", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
-    "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_plan_fold",
+    "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_fold_update_ex", "cvm_plan_fold",
     "cvm_timing_enable", "cvm_timing_read", "cvm_timing_read_kinds", "cvm_fill_probe",
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds", "cvm_sweep_fold_range", "cvm_sweep_all",
     "cvm_partition_workspace_bytes", "cvm_partition_labels", "cvm_partition_periodic",
@@ -80,6 +80,8 @@ def load():
     lib.cvm_fold_update.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int,
                                     C.c_int, u32, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp,
                                     vp, vp, vp, sz, vp]
+    lib.cvm_fold_update_ex.restype = C.c_int
+    lib.cvm_fold_update_ex.argtypes = lib.cvm_fold_update.argtypes + [vp]
     lib.cvm_sweep_workspace_bytes.restype = sz
     lib.cvm_sweep_workspace_bytes.argtypes = [i64, i64, C.c_int, C.c_int, C.c_int]
     lib.cvm_sweep_fit.restype = C.c_int

@@ -105,12 +105,12 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
   return want + QUEUE_RESERVE;
 }
 
-int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *idx,
-                    const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
-                    int K, int M, int dtype, unsigned flags, double ddof, double resolution,
-                    const void *G, const void *H, const double *gstats, void *out_XTX,
-                    void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
-                    double *out_fold, void *ws, size_t ws_bytes, void *stream) {
+int cvm_fold_update_ex(const void *X, const void *Y, const void *w, const int64_t *idx,
+                       const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                       int K, int M, int dtype, unsigned flags, double ddof, double resolution,
+                       const void *G, const void *H, const double *gstats, void *out_XTX,
+                       void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                       double *out_fold, void *ws, size_t ws_bytes, void *stream, int32_t *status) {
   if (!X || !offsets || !host_offsets || !G || !gstats || !ws)
     return fail(CVM_EINVAL, "cvm_fold_update: null pointer%s");
   if (n_folds < 0 || N < 0 || K <= 0 || M < 0 || (M > 0 && !Y))
@@ -126,13 +126,24 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
     return fold_update_impl<double>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype,
                                     flags, ddof, resolution, G, H, gstats, out_XTX, out_XTY, out_muX,
                                     out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, status);
   if (dtype == CVM_F32)
     return fold_update_impl<float>(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype,
                                    flags, ddof, resolution, G, H, gstats, out_XTX, out_XTY, out_muX,
                                    out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, status);
   return fail(CVM_EINVAL, "cvm_fold_update: dtype must be CVM_F32 or CVM_F64%s");
+}
+
+int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *idx,
+                    const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
+                    int K, int M, int dtype, unsigned flags, double ddof, double resolution,
+                    const void *G, const void *H, const double *gstats, void *out_XTX,
+                    void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
+                    double *out_fold, void *ws, size_t ws_bytes, void *stream) {
+  return cvm_fold_update_ex(X, Y, w, idx, offsets, host_offsets, n_folds, N, K, M, dtype, flags, ddof, resolution,
+                            G, H, gstats, out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws,
+                            ws_bytes, stream, nullptr);
 }
 
 #ifdef CVM_STAMPS

@@ -121,7 +121,20 @@ template <typename T> struct WgramArgs {
   // the flags of its two panels before its epilogue.  The diagonal items come FIRST in every XCD's list
   // (diag_first), they wait for nobody: no deadlock.  No colstats_kernel / fold_stats_kernel pre-pass.
   int *stat_flags;
-  int diag_first;
+  int diag_first;       // list order of an XCD: 0 = class-0 items then class-1 items, 1 = class 1 first, 2 = FOLD-MAJOR
+                        // (whole folds per XCD; per fold its class-1 items, then its class-0 items: see decode_slot)
+  int fpx;              // (fold-major) folds per XCD's list
+  // The wait of an off-diagonal item for its two flags is bounded (fused_wait_flag).  An item whose wait gave up
+  // writes nothing and appends its list position to retry_items (count in fused_status[0]); the host then runs the
+  // kernel once more over that list (retry_mode = 1: every diagonal item of the first launch has finished, all flags
+  // are up).  A wait that gives up in THAT launch counts in fused_status[1] and poisons the item's outputs with NaN.
+  // The last workgroup of the retry launch folds both into *status_out (1 = poisoned outputs, 2 = items recomputed).
+  int *fused_status;
+  unsigned long long *retry_items;
+  int retry_mode;
+  int test_mode;        // CVM_FUSED_TEST_TIMEOUT (tests): 1 = off-diagonal items of every third fold give up at once,
+                        // 2 = a spin limit of a few polls, 3 = like 1 and the retry launch gives up too
+  int32_t *status_out;
   const double *gstats;
   double ddof, resolution;
   void *out_muX, *out_sdX, *out_muY, *out_sdY;
@@ -193,6 +206,8 @@ template <typename T> __device__ __forceinline__ WgramArgs<T> kernel_args(kargs_
   a.fstats = r->fstats; a.G = r->G; a.H = r->H;
   a.out_XTX = r->out_XTX; a.out_XTY = r->out_XTY; a.flags = r->flags;
   a.stat_flags = r->stat_flags; a.diag_first = r->diag_first; a.gstats = r->gstats;
+  a.fpx = r->fpx; a.fused_status = r->fused_status; a.retry_items = r->retry_items;
+  a.retry_mode = r->retry_mode; a.test_mode = r->test_mode; a.status_out = r->status_out;
   a.ddof = r->ddof; a.resolution = r->resolution;
   a.out_muX = r->out_muX; a.out_sdX = r->out_sdX; a.out_muY = r->out_muY; a.out_sdY = r->out_sdY;
   a.out_fold = r->out_fold;
@@ -225,6 +240,33 @@ template <typename T> __device__ __forceinline__ bool decode_slot(const WgramArg
   const Geom &g = a.g;
   long item, cu;   // cu: unit number within the class (seg * nsp + sp)
   int k;
+  if (a.diag_first == 2) {
+    // FOLD-MAJOR lists (one unit per fold: the fused route): XCD x owns the folds [x fpx, (x + 1) fpx) whole; per
+    // fold first its class-1 items (the diagonal tiles: they publish the fold's statistics and wait for nobody),
+    // then its class-0 items.  Every item an off-diagonal item waits for precedes it in ITS OWN list, so it was
+    // taken -- and is being computed, or done -- before the waiter was; and the fold's rows are gathered by all
+    // its items while they are in that XCD's L2.
+    const int per = g.nT;
+    const long fl = q / per;
+    k = (int)(q - fl * per);
+    const long sg = (long)xcd * a.fpx + fl;
+    if (fl >= a.fpx || sg >= a.n_seg) return false;
+    const int n1 = g.P * g.Yc;
+    if (k < n1) {
+      if (g.diag_only) { o.ti = o.tj = k / g.Yc; o.yc = k - o.ti * g.Yc; }
+      else if (k < g.P) { o.ti = o.tj = k; o.yc = 0; }
+      else { const int e = k - g.P; o.ti = o.tj = e / (g.Yc - 1); o.yc = 1 + e - o.ti * (g.Yc - 1); }
+      o.it = tile_id(o.ti, o.ti, g.P);
+    } else {
+      decode_off_tile(k - n1, g.P, o.ti, o.tj);
+      o.yc = 0;
+      o.it = tile_id(o.ti, o.tj, g.P);
+    }
+    o.seg = uni((int)sg); o.sp = 0; o.nsp = 1; o.it = uni(o.it);
+    o.ti = uni(o.ti); o.tj = uni(o.tj); o.yc = uni(o.yc);
+    o.u = (long)o.seg * a.splits;
+    return true;
+  }
   // (diag_first: the list of an XCD is its class-1 items, then its class-0 items)
   if (a.diag_first) q = q < a.ipx1 ? q + a.ipx0 : q - a.ipx1;
   if (q < a.ipx0) {

@@ -307,28 +307,62 @@ constexpr size_t QUEUE_RESERVE = QUEUE_BYTES + 256;   // what the workspace-size
 // launches on different streams may overlap and never share a block).  (The heads used to live in
 // the caller's workspace and were zeroed on the stream before every launch: a 5 us kernel in front
 // of every Gram launch.)
-constexpr unsigned QUEUE_POOL = 1024;       // streams per device that can run Gram launches
+// The pool is BOUNDED and recycled: a process may create and destroy any number of streams.  When all
+// QUEUE_POOL blocks have owners, the block whose stream has gone longest without a Gram launch and has
+// nothing in flight (hipStreamQuery: idle, or no longer a stream at all) changes hands -- a block is all
+// zero whenever no launch of its stream is running.  Only QUEUE_POOL streams with Gram launches IN FLIGHT
+// at the same moment exhaust it.
+constexpr unsigned QUEUE_POOL = 1024;       // streams per device that can have Gram launches in flight at once
+struct QueuePool {
+  unsigned *mem = nullptr;
+  std::map<hipStream_t, unsigned> block_of;
+  std::vector<hipStream_t> owner;           // by block
+  std::vector<unsigned long long> last;     // by block: tick of its last hand-out
+  unsigned long long tick = 0;
+};
 unsigned *acquire_queue(int dev, hipStream_t st) {
   static std::mutex mu;
-  static unsigned *pool[64];
-  static std::map<hipStream_t, unsigned> block_of[64];
-  const int d = dev & 63;
+  static QueuePool pools[64];
+  QueuePool &p = pools[dev & 63];
   std::lock_guard<std::mutex> lock(mu);
-  if (!pool[d]) {
+  if (!p.mem) {
     void *mem = nullptr;
     if (hipMalloc(&mem, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess) return nullptr;
     if (hipMemset(mem, 0, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       (void)hipFree(mem);
       return nullptr;
     }
-    pool[d] = (unsigned *)mem;
+    p.mem = (unsigned *)mem;
   }
-  auto it = block_of[d].find(st);
-  if (it == block_of[d].end()) {
-    if (block_of[d].size() >= QUEUE_POOL) return nullptr;
-    it = block_of[d].emplace(st, (unsigned)block_of[d].size()).first;
+  ++p.tick;
+  auto it = p.block_of.find(st);
+  if (it == p.block_of.end()) {
+    unsigned b;
+    if (p.owner.size() < QUEUE_POOL) {
+      b = (unsigned)p.owner.size();
+      p.owner.push_back(st);
+      p.last.push_back(0);
+    } else {
+      // least recently used first; take the first one with nothing in flight
+      std::vector<unsigned> order(QUEUE_POOL);
+      for (unsigned i = 0; i < QUEUE_POOL; ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](unsigned a, unsigned c) { return p.last[a] < p.last[c]; });
+      b = QUEUE_POOL;
+      for (unsigned cand : order) {
+        const hipError_t q = hipStreamQuery(p.owner[cand]);
+        if (q == hipErrorNotReady) continue;          // that stream still has work queued: its block may be in use
+        if (q != hipSuccess) (void)hipGetLastError(); // (a destroyed stream's handle: clear the sticky error)
+        b = cand;
+        break;
+      }
+      if (b == QUEUE_POOL) return nullptr;
+      p.block_of.erase(p.owner[b]);
+      p.owner[b] = st;
+    }
+    it = p.block_of.emplace(st, b).first;
   }
-  return pool[d] + (size_t)it->second * (QUEUE_BYTES / sizeof(unsigned));
+  p.last[it->second] = p.tick;
+  return p.mem + (size_t)it->second * (QUEUE_BYTES / sizeof(unsigned));
 }
 
 int device_cu_count(int dev) {
@@ -346,9 +380,11 @@ int current_cu_count() {
   return device_cu_count(dev);
 }
 
+// kind: KIND_FIT / KIND_FOLD for the timing recorder, -1 = not recorded; grid_cap: at most so many persistent
+// workgroups (0: one per CU -- the retry launch of the fused route takes a few)
 template <typename T>
 int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned, hipStream_t st,
-                 int kind, unsigned *queue, bool fused = false) {
+                 int kind, unsigned *queue, bool fused = false, int grid_cap = 0) {
   WgramArgs<T> args = a;
   args.queue = queue;
   // CVM_FORCE_FALLBACK=1 sends float64 problems through the general (register-staged)
@@ -375,7 +411,7 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     hipLaunchKernelGGL((wgram_kernel<T, W, GA, AL>), grid, block, lds, st, args);          \
   } while (0)
   TimedLaunch *tl = nullptr;
-  if (g_timing.load(std::memory_order_relaxed)) {
+  if (kind >= 0 && g_timing.load(std::memory_order_relaxed)) {
     std::lock_guard<std::mutex> lk(g_timing_mu);
     if (g_ntimed < MAX_TIMED) {
       tl = &g_timed[g_ntimed++];
@@ -390,24 +426,33 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
   if (fast) {
     (void)queue;
     args.queue = acquire_queue(dev, st);
-    if (!args.queue) return fail(CVM_ELAUNCH, "launch_wgram: no work-queue block (allocation failed, or more than 1024 streams)%s");
-    // persistent workgroups: one per CU (fewer when the lists are shorter than that)
+    if (!args.queue) return fail(CVM_ELAUNCH, "launch_wgram: no work-queue block (allocation failed, or 1024 streams with Gram launches in flight at once)%s");
+    // persistent workgroups: as many as the device keeps resident at once -- one per CU by the kernel's LDS,
+    // asked of the occupancy API once per kernel and device -- and no more than the lists are long.  (Results
+    // never depend on the number: the workgroups PULL items; what does is that no workgroup of the grid waits
+    // in the dispatcher while resident ones spin on a flag.)
     long wgs = 8 * (a.ipx0 + a.ipx1);
     const long cus = device_cu_count(dev);
-    if (wgs > cus) wgs = cus;
-    const dim3 grid((unsigned)wgs);
     const dim3 block4(NT4);
     // (the fused epilogue reuses the stage ring for its tiles: a little more than the ring in float32)
     const size_t lds4 = fused ? fused_launch_lds_bytes<T>() : lds4_bytes<T>();
 #define CVM_LAUNCH4(W, GA, FU)                                                              \
   do {                                                                                      \
     static std::atomic<unsigned long long> attr_done{0};                                    \
+    static std::atomic<int> per_cu[64];                                                     \
     if (attr_needed(attr_done, dev)) {                                                      \
       HIP_OK(hipFuncSetAttribute((const void *)wgram4_kernel<T, W, GA, FU>,                 \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));   \
+      int occ = 0;                                                                          \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)wgram4_kernel<T, W, GA, FU>, NT4, lds4) != hipSuccess || occ < 1) \
+        return fail(CVM_ELAUNCH, "launch_wgram: the Gram kernel does not fit a compute unit%s"); \
+      per_cu[dev & 63].store(occ > 1 ? 1 : occ, std::memory_order_relaxed);   /* (LDS: one) */ \
       attr_set(attr_done, dev);                                                             \
     }                                                                                       \
-    hipLaunchKernelGGL((wgram4_kernel<T, W, GA, FU>), grid, block4, lds4, st, args);        \
+    const long resident = cus * per_cu[dev & 63].load(std::memory_order_relaxed);           \
+    if (wgs > resident) wgs = resident;                                                     \
+    if (grid_cap > 0 && wgs > grid_cap) wgs = grid_cap;                                     \
+    hipLaunchKernelGGL((wgram4_kernel<T, W, GA, FU>), dim3((unsigned)wgs), block4, lds4, st, args); \
   } while (0)
     if (fused) {
       if (weighted) CVM_LAUNCH4(true, true, true); else CVM_LAUNCH4(false, true, true);
@@ -740,13 +785,116 @@ int fold_statistics_impl(const void *X, const void *Y, const void *w, const int6
   return CVM_OK;
 }
 
+// Route switches of the fold stage: read from the environment ONCE, in one place (tests, tools/route_matrix.sh
+// and the experiment scripts set them; none is needed in production).
+struct FoldSwitches {
+  int mid_minn, mid_maxn;      // CVM_MID_MINN / CVM_MID_MAXN: row limits of mid_tile_kernel (0: the measured table)
+  bool mid_off;                // CVM_MID_TILE=0: never mid_tile_kernel
+  bool mid_own;                // CVM_MID_OWNSTATS=1: its items sum their own columns (no pre-pass; measured slower)
+  bool force_fallback;         // CVM_FORCE_FALLBACK=1: the general Gram kernel
+  bool no_fused;               // CVM_NO_FUSED=1: partials + apply_kernel for one-unit folds too
+  bool prepass;                // CVM_FUSED_PREPASS=1: statistics by colstats_kernel + fold_stats_kernel, not in the launch
+  int fused_order;             // CVM_FUSED_ORDER: 2 = fold-major lists (default), 1 = every list's diagonal items first
+  int fused_test;              // CVM_FUSED_TEST_TIMEOUT: WgramArgs::test_mode
+};
+const FoldSwitches &fold_switches() {
+  static const FoldSwitches sw = [] {
+    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    FoldSwitches f;
+    f.mid_minn = num("CVM_MID_MINN", 0); f.mid_maxn = num("CVM_MID_MAXN", 0);
+    f.mid_off = num("CVM_MID_TILE", 1) == 0;
+    f.mid_own = num("CVM_MID_OWNSTATS", 0) != 0;
+    f.force_fallback = num("CVM_FORCE_FALLBACK", 0) != 0;
+    f.no_fused = num("CVM_NO_FUSED", 0) != 0;
+    f.prepass = num("CVM_FUSED_PREPASS", 0) != 0;
+    f.fused_order = num("CVM_FUSED_ORDER", 2) == 1 ? 1 : 2;
+    f.fused_test = num("CVM_FUSED_TEST_TIMEOUT", 0);
+    return f;
+  }();
+  return sw;
+}
+
+// what every kernel of one cvm_fold_update call is handed (the call's own arguments, typed once)
+struct FoldCall {
+  const void *X, *Y, *w;
+  const int64_t *idx, *offsets;
+  int64_t N;
+  int K, M;
+  unsigned flags;
+  double ddof, resolution;
+  const void *G, *H;
+  const double *gstats;
+  void *out_XTX, *out_XTY, *out_muX, *out_sdX, *out_muY, *out_sdY;
+  double *out_fold;
+  bool want_xty;
+  int32_t *status;
+};
+
+// the statistics pre-pass over the folds [f0, f0 + nb): colstats_kernel + fold_stats_kernel; returns where the
+// folds' statistics vectors lie in ws
+template <typename T>
+double *launch_prepass(const FoldCall &c, const Geom &gs, int64_t csplits, int64_t f0, int64_t nb, void *ws, hipStream_t st) {
+  ColArgs ca;
+  ca.X = c.X; ca.Y = c.Y; ca.w = c.w; ca.idx = c.idx; ca.offs = c.offsets; ca.seg0 = f0;
+  ca.g = gs; ca.ws = (char *)ws;
+  colstats_shape<T>(ca, c.K, c.M, nb, (int)csplits);
+  const dim3 cgrid = colstats_grid(ca, nb);
+  if (c.w) hipLaunchKernelGGL((colstats_kernel<T, true, true>), cgrid, dim3(COL_THREADS), 0, st, ca);
+  else hipLaunchKernelGGL((colstats_kernel<T, false, true>), cgrid, dim3(COL_THREADS), 0, st, ca);
+  FinArgs f;
+  memset(&f, 0, sizeof(f));
+  f.g = gs; f.splits = f.s_off = f.s_diag = (int)csplits; f.n_sum = 1;
+  f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
+  f.fstats = (double *)((char *)ws + (size_t)nb * csplits * gs.unit_bytes);
+  f.offs = c.offsets; f.w = c.w; f.gstats = c.gstats;
+  f.out_muX = c.out_muX; f.out_sdX = c.out_sdX; f.out_muY = c.out_muY; f.out_sdY = c.out_sdY;
+  f.out_fold = c.out_fold; f.ddof = c.ddof; f.resolution = c.resolution; f.flags = c.flags;
+  hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(c.K, c.M, nb)),
+                     dim3(256), 0, st, f);
+  return f.fstats;
+}
+
+// arguments of mid_tile_kernel over the folds [f0, ...) (fstats: from the pre-pass, or nullptr = own statistics)
+inline MidArgs mid_args(const FoldCall &c, int64_t f0, const double *fstats) {
+  MidArgs m;
+  memset(&m, 0, sizeof(m));
+  m.X = c.X; m.Y = c.Y; m.w = c.w; m.idx = c.idx; m.offs = c.offsets; m.seg0 = f0;
+  m.fstats = fstats; m.gstats = c.gstats; m.ddof = c.ddof; m.resolution = c.resolution;
+  m.out_muX = c.out_muX; m.out_sdX = c.out_sdX; m.out_muY = c.out_muY; m.out_sdY = c.out_sdY; m.out_fold = c.out_fold;
+  m.G = c.G; m.H = c.H;
+  m.out_XTX = c.out_XTX; m.out_XTY = c.want_xty ? c.out_XTY : nullptr;
+  m.K = c.K; m.M = c.M; m.flags = c.flags;
+  return m;
+}
+
+// arguments of a fused launch (wgram4_kernel<.., FUSED>, one unit per fold) over the folds [f0, f0 + nb)
+template <typename T>
+WgramArgs<T> fused_args(const FoldCall &c, const Plan &p, int64_t f0, int64_t nb, const double *fstats) {
+  WgramArgs<T> a;
+  memset(&a, 0, sizeof(a));
+  a.X = (const T *)c.X; a.Y = (const T *)c.Y; a.w = (const T *)c.w;
+  a.idx = c.idx; a.offs = c.offsets; a.N = c.N; a.seg0 = f0;
+  set_items(a, p, nb);               // (one unit per fold: p.s_off == p.s_diag == 1)
+  a.ws = nullptr;
+  a.fstats = fstats; a.G = c.G; a.H = c.H;
+  a.out_XTX = c.out_XTX; a.out_XTY = c.want_xty ? c.out_XTY : nullptr; a.flags = c.flags;
+  if (fold_switches().fused_order == 2) {
+    // fold-major lists (decode_slot): whole folds per XCD, a fold's diagonal items in front of its others
+    a.diag_first = 2;
+    a.fpx = (int)((nb + 7) / 8);
+    const int per0 = p.g.diag_only ? 0 : p.g.nTiles - p.g.P, per1 = p.g.P * p.g.Yc;
+    a.ipx0 = (long)a.fpx * per0; a.ipx1 = (long)a.fpx * per1;
+  }
+  return a;
+}
+
 template <typename T>
 int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t *idx,
                      const int64_t *offsets, const int64_t *host_offsets, int64_t n_folds, int64_t N,
                      int K, int M, int dtype, unsigned flags, double ddof, double resolution,
                      const void *G, const void *H, const double *gstats, void *out_XTX,
                      void *out_XTY, void *out_muX, void *out_sdX, void *out_muY, void *out_sdY,
-                     double *out_fold, void *ws, size_t ws_bytes, hipStream_t st) {
+                     double *out_fold, void *ws, size_t ws_bytes, hipStream_t st, int32_t *status) {
   int64_t max_rows = 0;
   for (int64_t f = 0; f < n_folds; ++f) {
     const int64_t n = host_offsets[f + 1] - host_offsets[f];
@@ -755,32 +903,30 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   }
   const WsCarve wq = carve_queue(ws, ws_bytes);
   ws_bytes = wq.usable;
-  // (CVM_MID_MINN: folds of at least so many rows skip the direct small-fold kernels -- measurement switch
-  //  for where mid_tile_kernel takes over; float64 only, like that kernel)
-  static const int mid_minn_env = getenv("CVM_MID_MINN") ? atoi(getenv("CVM_MID_MINN")) : 0;
-  static const bool mid_off = getenv("CVM_MID_TILE") && atoi(getenv("CVM_MID_TILE")) == 0;
-  const int mid_minn = mid_off ? (1 << 30) : (mid_minn_env > 0 ? mid_minn_env : mid_default_minn(K, (int)sizeof(T)));
-  static const int mid_maxn_env0 = getenv("CVM_MID_MAXN") ? atoi(getenv("CVM_MID_MAXN")) : 0;
-  static const bool force_fallback0 = getenv("CVM_FORCE_FALLBACK") && atoi(getenv("CVM_FORCE_FALLBACK")) != 0;
-  static const bool no_fused0 = getenv("CVM_NO_FUSED") && atoi(getenv("CVM_NO_FUSED")) != 0;
+  const FoldSwitches &sw = fold_switches();
+  const int esize = (int)sizeof(T);
+  // where mid_tile_kernel is the route: rows per fold between the measured limits (CVM_MID_MINN / _MAXN override)
+  const int mid_minn = sw.mid_off ? (1 << 30) : (sw.mid_minn > 0 ? sw.mid_minn : mid_default_minn(K, esize));
+  const int mid_maxn = sw.mid_maxn > 0 ? sw.mid_maxn : mid_default_maxn(K, esize);
   // (... only where that kernel can run -- the conditions of the fused route below; a fold whose indices come
   //  inside the call -- CVM_IDX_HOST, one fold of at most 32 rows -- is the small route's)
   const bool skip_small = !(flags & CVM_IDX_HOST) && max_rows >= mid_minn && ((flags & CVM_RET_XTX) && out_XTX) &&
-                          max_rows <= (mid_maxn_env0 > 0 ? mid_maxn_env0 : mid_default_maxn(K, (int)sizeof(T))) &&
-                          mid_operands_ok<T>(X, Y, w, N, K, M) && !force_fallback0 && !no_fused0;
+                          max_rows <= mid_maxn && mid_operands_ok<T>(X, Y, w, N, K, M) && !sw.force_fallback && !sw.no_fused;
   // (... and only if the fold stage is planned with one unit per fold -- always, unless a test forces a split plan)
   bool skip_small_ok = skip_small;
   if (skip_small_ok) {
     Plan pp;
     if (make_plan(n_folds, max_rows, K, M, dtype, flags, (size_t)1 << 60, true, pp) != CVM_OK || pp.splits != 1) skip_small_ok = false;
   }
-  if (max_rows <= small_route_limit(K, (int)sizeof(T)) && !skip_small_ok)
+  if (max_rows <= small_route_limit(K, esize) && !skip_small_ok)
     return small_fold_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution, G, H, gstats,
                               out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
   const bool want_xtx = (flags & CVM_RET_XTX) && out_XTX, want_xty = (flags & CVM_RET_XTY) && out_XTY;
   if (!want_xtx && !want_xty)   // statistics only: stream the rows once, no Gram launch
     return fold_statistics_impl<T>(X, Y, w, idx, offsets, n_folds, max_rows, K, M, flags, ddof, resolution,
                                    gstats, out_muX, out_sdX, out_muY, out_sdY, out_fold, ws, ws_bytes, st);
+  const FoldCall c{X, Y, w, idx, offsets, N, K, M, flags, ddof, resolution, G, H, gstats,
+                   out_XTX, out_XTY, out_muX, out_sdX, out_muY, out_sdY, out_fold, want_xty, status};
   Plan p;
   // (planned against an unlimited workspace first: the fused route below needs far less than
   //  the partials the general route plans for)
@@ -788,13 +934,11 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   const bool aligned = rows_aligned(X, K, sizeof(T));
   {
     // Folds too small to be split over workgroups (one unit per fold): finish in the Gram
-    // kernel's epilogue instead of writing partials for apply_kernel to read back.  The fold
-    // statistics the epilogue needs come from the streaming kernel first.
-    static const bool no_fused = getenv("CVM_NO_FUSED") && atoi(getenv("CVM_NO_FUSED")) != 0;
+    // kernel's epilogue instead of writing partials for apply_kernel to read back.
     WgramArgs<T> probe;
     memset(&probe, 0, sizeof(probe));
     probe.Y = (const T *)Y; probe.w = (const T *)w; probe.g = p.g;
-    if (p.splits == 1 && want_xtx && !no_fused && wgram4_ok<T>(probe, aligned)) {
+    if (p.splits == 1 && want_xtx && !sw.no_fused && wgram4_ok<T>(probe, aligned)) {
       Geom gs = make_geom(K, M, sizeof(T), 1);
       gs.tile_elems = 0; gs.h_elems = 0;
       gs.unit_bytes = align_up(gs.stat_len * 8, 256);
@@ -805,99 +949,55 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       if (per_fold > ws_bytes) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
       int64_t per_batch = (int64_t)(ws_bytes / per_fold);
       if (per_batch > 16384) per_batch = 16384;
-      // Statistics formed INSIDE the Gram launch (round 4): the diagonal item of (fold, panel) sums the
-      // panel's columns anyway-streamed rows and publishes the panel's training means / stds, the
-      // off-diagonal items wait for the two flags they need (wgram4.hpp).  No colstats_kernel +
-      // fold_stats_kernel pre-pass (70-90 us in front of a 0.5-1.2 ms launch at the C3 rows cut into 100 /
-      // 1000 folds).  One Y chunk (M <= 32); CVM_FUSED_PREPASS=1: the pre-pass route (tests, comparisons).
-      static const bool prepass_forced = getenv("CVM_FUSED_PREPASS") && atoi(getenv("CVM_FUSED_PREPASS")) != 0;
       // Folds of up to a few hundred rows: mid_tile_kernel (mid_tile.hpp) -- small work items, four
-      // workgroups per CU, so that one item's stores overlap another's MFMAs -- behind the statistics pre-pass.
-      // CVM_MID_TILE=0: the fused route for them too (tests, comparisons); CVM_MID_MAXN: the row limit.
-      static const int mid_env = getenv("CVM_MID_TILE") ? atoi(getenv("CVM_MID_TILE")) : 1;
-      static const int mid_maxn_env = getenv("CVM_MID_MAXN") ? atoi(getenv("CVM_MID_MAXN")) : 0;
-      const int mid_maxn = mid_maxn_env > 0 ? mid_maxn_env : mid_default_maxn(K, (int)sizeof(T));
-      const bool mid = mid_env != 0 && max_rows <= mid_maxn && mid_operands_ok<T>(X, Y, w, N, K, M);
-      const bool ink = !mid && !prepass_forced && p.g.Yc == 1 && fst + (size_t)p.g.P * 4 + 256 <= per_fold;
-      // (CVM_MID_OWNSTATS=1: its items form the statistics of their own columns from the rows they stage -- no
-      //  pre-pass, no workspace, the same bits.  Measured and NOT the default: every one of a fold's 36 tiles sums
-      //  its 128 columns again, in row order on the vector units -- the C3 rows in 1000 folds 1.11 -> 1.36 ms, in
-      //  3000 folds 2.09 -> 2.22 ms, where the pre-pass costs 0.095 ms; profiles/r4/mid_tile/own_statistics.txt)
-      static const bool mid_own = getenv("CVM_MID_OWNSTATS") && atoi(getenv("CVM_MID_OWNSTATS")) != 0;
-      if (mid && mid_own) {
+      // workgroups per CU, so that one item's stores overlap another's MFMAs -- behind the statistics pre-pass
+      // (or, CVM_MID_OWNSTATS=1, with every item summing its own columns: the C3 rows in 1000 folds 1.11 -> 1.36 ms,
+      // where the pre-pass costs 0.095 ms; profiles/r4/mid_tile/own_statistics.txt).
+      const bool mid = !sw.mid_off && max_rows <= mid_maxn && mid_operands_ok<T>(X, Y, w, N, K, M);
+      if (mid && sw.mid_own) {
         for (int64_t f0 = 0; f0 < n_folds; f0 += 16384) {
           const int64_t nb = (n_folds - f0 < 16384) ? n_folds - f0 : 16384;
-          MidArgs m;
-          memset(&m, 0, sizeof(m));
-          m.X = X; m.Y = Y; m.w = w; m.idx = idx; m.offs = offsets; m.seg0 = f0;
-          m.fstats = nullptr; m.gstats = gstats; m.ddof = ddof; m.resolution = resolution;
-          m.out_muX = out_muX; m.out_sdX = out_sdX; m.out_muY = out_muY; m.out_sdY = out_sdY; m.out_fold = out_fold;
-          m.G = G; m.H = H;
-          m.out_XTX = out_XTX; m.out_XTY = want_xty ? out_XTY : nullptr;
-          m.K = K; m.M = M; m.flags = flags;
-          rc = launch_mid<T>(m, w != nullptr, nb, max_rows, st);
+          rc = launch_mid<T>(mid_args(c, f0, nullptr), w != nullptr, nb, max_rows, st);
           if (rc != CVM_OK) return rc;
         }
         return CVM_OK;
       }
-      for (int64_t f0 = 0; ink && f0 < n_folds; f0 += per_batch) {
-        const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
-        double *fstats = (double *)ws;
-        int *sflags = (int *)((char *)ws + align_up((size_t)nb * fst, 256));
-        HIP_OK(hipMemsetAsync(sflags, 0, align_up((size_t)nb * p.g.P * sizeof(int), 16), st));
-        WgramArgs<T> a;
-        memset(&a, 0, sizeof(a));
-        a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
-        a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
-        set_items(a, p, nb);               // (one unit per fold: p.s_off == p.s_diag == 1)
-        a.ws = nullptr;
-        a.fstats = fstats; a.G = G; a.H = H;
-        a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
-        a.stat_flags = sflags; a.diag_first = 1; a.gstats = gstats; a.ddof = ddof; a.resolution = resolution;
-        a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY; a.out_fold = out_fold;
-        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, wq.queue, true);
-        if (rc != CVM_OK) return rc;
-      }
-      if (ink) return CVM_OK;
+      // Statistics formed INSIDE the Gram launch (round 4): the diagonal item of (fold, panel) sums the panel's
+      // columns while it streams the fold's rows anyway and publishes the panel's training means / stds, the
+      // off-diagonal items wait for the two flags they need (wgram4.hpp).  No colstats_kernel + fold_stats_kernel
+      // pre-pass (70-90 us in front of a 0.5-1.2 ms launch at the C3 rows cut into 100 / 1000 folds).  One Y chunk
+      // (M <= 32); CVM_FUSED_PREPASS=1: the pre-pass route (tests, comparisons).
+      // Workspace of a batch: [fstats nb x fst | flags nb x P | status 4 ints | retry list nb x off-diagonal tiles]
+      const int per0 = p.g.nTiles - p.g.P;
+      const bool ink = !mid && !sw.prepass && p.g.Yc == 1 &&
+                       fst + (size_t)p.g.P * 4 + (size_t)per0 * 8 + 512 <= per_fold;
       for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
-        ColArgs c;
-        c.X = X; c.Y = Y; c.w = w; c.idx = idx; c.offs = offsets; c.seg0 = f0;
-        c.g = gs; c.ws = (char *)ws;
-        colstats_shape<T>(c, K, M, nb, (int)csplits);
-        const dim3 cgrid = colstats_grid(c, nb);
-        if (w) hipLaunchKernelGGL((colstats_kernel<T, true, true>), cgrid, dim3(COL_THREADS), 0, st, c);
-        else hipLaunchKernelGGL((colstats_kernel<T, false, true>), cgrid, dim3(COL_THREADS), 0, st, c);
-        FinArgs f;
-        memset(&f, 0, sizeof(f));
-        f.g = gs; f.splits = f.s_off = f.s_diag = (int)csplits; f.n_sum = 1;
-        f.n_seg = (int)nb; f.seg0 = f0; f.ws = (const char *)ws;
-        f.fstats = (double *)((char *)ws + (size_t)nb * csplits * gs.unit_bytes);
-        f.offs = offsets; f.w = w; f.gstats = gstats;
-        f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
-        f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
-        hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)),
-                           dim3(256), 0, st, f);
-        if (mid) {
-          MidArgs m;
-          memset(&m, 0, sizeof(m));
-          m.X = X; m.Y = Y; m.w = w; m.idx = idx; m.offs = offsets; m.seg0 = f0;
-          m.fstats = f.fstats; m.G = G; m.H = H;
-          m.out_XTX = out_XTX; m.out_XTY = want_xty ? out_XTY : nullptr;
-          m.K = K; m.M = M; m.flags = flags;
-          rc = launch_mid<T>(m, w != nullptr, nb, max_rows, st);
+        if (ink) {
+          double *fstats = (double *)ws;
+          int *sflags = (int *)((char *)ws + align_up((size_t)nb * fst, 256));
+          const size_t flag_bytes = align_up((size_t)nb * p.g.P * sizeof(int), 16);
+          int *fstatus = (int *)((char *)sflags + flag_bytes);
+          HIP_OK(hipMemsetAsync(sflags, 0, flag_bytes + 16, st));      // the flags and the two status words
+          WgramArgs<T> a = fused_args<T>(c, p, f0, nb, fstats);
+          a.stat_flags = sflags; if (!a.diag_first) a.diag_first = 1;
+          a.gstats = gstats; a.ddof = ddof; a.resolution = resolution;
+          a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY; a.out_fold = out_fold;
+          a.fused_status = fstatus;
+          a.retry_items = (unsigned long long *)((char *)fstatus + 16);
+          a.test_mode = sw.fused_test;
+          rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, wq.queue, true);
+          if (rc != CVM_OK) return rc;
+          // the items whose wait for a flag gave up (none, unless the device is shared in a way that breaks the
+          // kernel's progress argument): once more, behind the launch that has raised every flag
+          a.retry_mode = 1; a.status_out = status;
+          rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, -1, wq.queue, true, 64);
           if (rc != CVM_OK) return rc;
           continue;
         }
-        WgramArgs<T> a;
-        memset(&a, 0, sizeof(a));
-        a.X = (const T *)X; a.Y = (const T *)Y; a.w = (const T *)w;
-        a.idx = idx; a.offs = offsets; a.N = N; a.seg0 = f0;
-        set_items(a, p, nb);               // (one unit per fold: p.s_off == p.s_diag == 1)
-        a.ws = nullptr;
-        a.fstats = f.fstats; a.G = G; a.H = H;
-        a.out_XTX = out_XTX; a.out_XTY = want_xty ? out_XTY : nullptr; a.flags = flags;
-        rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, wq.queue, true);
+        const double *fstats = launch_prepass<T>(c, gs, csplits, f0, nb, ws, st);
+        if (mid) rc = launch_mid<T>(mid_args(c, f0, fstats), w != nullptr, nb, max_rows, st);
+        else rc = launch_wgram<T>(fused_args<T>(c, p, f0, nb, fstats), w != nullptr, true, aligned, st, KIND_FOLD, wq.queue, true);
         if (rc != CVM_OK) return rc;
       }
       return CVM_OK;
@@ -926,7 +1026,6 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
     f.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
     f.out_muX = out_muX; f.out_sdX = out_sdX; f.out_muY = out_muY; f.out_sdY = out_sdY;
     f.out_fold = out_fold; f.ddof = ddof; f.resolution = resolution; f.flags = flags;
-    // fstats rows are fstat_len doubles apart inside the 256-byte aligned slots? keep dense
     hipLaunchKernelGGL((fold_stats_kernel<T>), dim3((unsigned)nb, (unsigned)fold_stats_chunks(K, M, nb)), dim3(256), 0, st, f);
     if (f.out_XTX || f.out_XTY) {
       f.gx = p.g.nTiles * APPLY_SUB + p.g.P; f.gy = (int)nb;

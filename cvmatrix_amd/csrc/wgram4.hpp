@@ -107,27 +107,51 @@ __device__ __forceinline__ void diag_tile_finish(T (*Td)[TP], double *rs0, int v
 #define ROLE_EXIT() return
 #define ROLE_ATTR
 // Statistics formed inside a fused launch (WgramArgs::stat_flags).  fused_wait_flag: ONE lane of the first
-// loader wave waits until the diagonal items of its two panels have published (normally they did long ago:
-// they come first in every list); a wait that gives up -- it cannot, a diagonal item waits for nobody --
-// leaves a mark in the last word of the dynamic LDS and the epilogue then poisons its results (NaN).
-template <typename T> __device__ __forceinline__ void fused_wait_flag(const int *f0, const int *f1, char *smem_raw, int lane) {
+// loader wave waits until the diagonal items of its two panels have published.  They precede the waiter in its
+// own list (fold-major lists, geometry.hpp) and wait for nobody, so the flags are normally up long before they
+// are asked for and the wait is bounded by one item's duration whatever else shares the device.  The spin limit
+// is the safety net under that argument (HIP promises no dispatch order): a wait that gives up leaves mark 0 in
+// the last words of the dynamic LDS -- every wave of the item then writes NOTHING -- and appends the item's list
+// position to WgramArgs::retry_items; the host's second launch of this kernel over that list (retry_mode)
+// recomputes the item when every flag of the first launch is up.  Giving up THERE (it cannot) is counted in
+// fused_status[1] and mark 2 poisons the item's results with NaN; cvm_fold_update_ex reports either through
+// *status.  Marks: 1 = go, 0 = skip (recomputed later), 2 = poison.
+constexpr int FUSED_GO = 1, FUSED_SKIP = 0, FUSED_POISON = 2;
+template <typename T>
+__device__ __forceinline__ void fused_wait_flag(const int *f0, const int *f1, char *smem_raw, int lane, int seg,
+                                                int xcd_q, int slot_q, int *fused_status,
+                                                unsigned long long *retry_items, int retry_mode, int test_mode) {
   if (lane != 0) return;
   int ok = 1;
-  for (int w = 0; w < 2; ++w) {
+  const long limit = test_mode == 2 ? 4 : (1L << 22);
+  const bool feign = (test_mode == 1 || test_mode == 3) && seg % 3 == 0 && (!retry_mode || test_mode == 3);
+  for (int w = 0; w < 2 && ok; ++w) {
     const int *f = w ? f1 : f0;
     long spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    while (feign || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1L << 22)) { ok = 0; break; }
+      if (feign || ++spins > limit) { ok = 0; break; }
     }
   }
-  *reinterpret_cast<volatile int *>(smem_raw + fused_launch_lds_bytes<T>() - 16) = ok;
+  int mark = FUSED_GO;
+  if (!ok) {
+    if (!retry_mode && fused_status && retry_items) {
+      const int pos = __hip_atomic_fetch_add(fused_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      retry_items[pos] = ((unsigned long long)(unsigned)xcd_q << 32) | (unsigned)slot_q;
+      mark = FUSED_SKIP;
+    } else {
+      if (fused_status) __hip_atomic_fetch_add(fused_status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mark = FUSED_POISON;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the count is at the memory before this workgroup can leave)
+  }
+  *reinterpret_cast<volatile int *>(smem_raw + fused_launch_lds_bytes<T>() - 16) = mark;
 }
-template <typename T> __device__ __forceinline__ double fused_swt(const double *p, const int *stat_flags, const char *smem_raw) {
-  const double v = ldc(p);
-  if (!stat_flags) return v;
-  const int ok = *reinterpret_cast<const volatile int *>(smem_raw + fused_launch_lds_bytes<T>() - 16);
-  return ok ? v : __builtin_nan("");
+// the mark of this item (off-diagonal items of a launch that forms its statistics; every wave, behind the barrier
+// that follows fused_wait_flag)
+template <typename T> __device__ __forceinline__ int fused_mark(const int *stat_flags, const char *smem_raw) {
+  if (!stat_flags) return FUSED_GO;
+  return uni(*reinterpret_cast<const volatile int *>(smem_raw + fused_launch_lds_bytes<T>() - 16));
 }
 
 template <typename T, bool WEIGHTED, bool GATHER, bool HWR, bool MFMR, int ROLER, bool FUSEDR = false>
@@ -348,10 +372,12 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       // the loop, so that every wave's (device-coherent) loads of the statistics come after the match.
       if (a.stat_flags && do_g && !diag && d == 0) {
         const int *fl = a.stat_flags + (size_t)seg * g.P;
-        fused_wait_flag<T>(fl + ti, fl + tj, smem_raw, lane);
+        fused_wait_flag<T>(fl + ti, fl + tj, smem_raw, lane, seg, uni(xcd_q), uni(slot_q), a.fused_status,
+                           a.retry_items, a.retry_mode, a.test_mode);
       }
     }
-    if (FUSEDR) __builtin_amdgcn_s_barrier();       // the compute waves reuse the ring in their epilogue
+    if (FUSEDR) lds_barrier();                      // the compute waves reuse the ring in their epilogue (and the
+                                                    // mark of fused_wait_flag has landed in LDS: lgkmcnt(0) first)
     if constexpr (FUSEDR) {
       if (do_g && diag && a.stat_flags) {           // the diagonal item forms its statistics first: two more barriers
         __builtin_amdgcn_s_barrier();
@@ -391,12 +417,13 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         lds_barrier();     // B_parked (LDS only: the direct stores need not be acknowledged first)
         diag_tile_finish<T, TP>(Td, rs0, wave_all, 1, ti, K, (const T *)a.G, outp, swt, cX, sX, lane);
       }
-      if (do_g && !diag) {
+      const int mark = (do_g && !diag) ? fused_mark<T>(a.stat_flags, smem_raw) : FUSED_GO;
+      if (do_g && !diag && mark != FUSED_SKIP) {
         // off-diagonal tile of the fused route: help compute wave d with the second half of its
         // 64x64 block (see the compute role's epilogue; same two barriers)
         const int K = g.K, M = g.M;
         const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
-        const double swt = fused_swt<T>(fs + 2 * K + 2 * M, a.stat_flags, smem_raw);
+        const double swt = mark == FUSED_POISON ? __builtin_nan("") : ldc(fs + 2 * K + 2 * M);
         const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
         const size_t fo = (size_t)(a.seg0 + seg);
         const int a0 = ti * TILE + 64 * (d >> 1), b0 = tj * TILE + 64 * (d & 1);
@@ -637,7 +664,9 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
     __syncthreads();   // all loaders have drained their LDS-DMA (and, statistics formed in the launch: polled the flags)
     const int K = g.K, M = g.M;
     const double *fs = a.fstats + (size_t)seg * fstat_len(K, M);
-    const double swt = h_wave ? ldc(fs + 2 * K + 2 * M) : fused_swt<T>(fs + 2 * K + 2 * M, a.stat_flags, smem_raw);
+    const int mark = (do_g && !diag) ? fused_mark<T>(a.stat_flags, smem_raw) : FUSED_GO;
+    if (mark == FUSED_SKIP) ROLE_EXIT();      // its wait gave up: nothing is written, the retry launch recomputes the item
+    const double swt = mark == FUSED_POISON ? __builtin_nan("") : ldc(fs + 2 * K + 2 * M);
     const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
     const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
     const size_t fo = (size_t)(a.seg0 + seg);
@@ -1317,6 +1346,16 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
   // next real item of the lists, starting with the home XCD's: {xcd, position} or xcd = -1
   auto fetch = [&](int &fx, int &fq, int &probe) {
     Item tmp;
+    if (FUSED && a.retry_mode) {
+      // the retry launch: the items whose wait gave up in the first launch, in the order they were listed
+      const int q = fetch_position(a.queue, 0);
+      const int n = __hip_atomic_load(a.fused_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q < n) {
+        const unsigned long long it = __hip_atomic_load(a.retry_items + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fx = (int)(it >> 32); fq = (int)(it & 0xffffffffu);
+      } else { fx = -1; fq = 0; }
+      return;
+    }
     while (probe < 8) {
       const int x = (home + probe) & 7;
       const int q = fetch_position(a.queue, x);
@@ -1361,6 +1400,20 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
       for (int x = 0; x < 8; ++x)
         __hip_atomic_store(a.queue + x * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.queue + QUEUE_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (FUSED && a.retry_mode && a.status_out) {
+        // what the caller may read behind the call (cvm_fold_update_ex): every workgroup of this launch has
+        // made its last fetch, and an item that gave up here counted itself before its workgroup's exit add
+        const int redone = __hip_atomic_load(a.fused_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lost = __hip_atomic_load(a.fused_status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int st = lost ? 1 : (redone ? 2 : 0);
+        if (st) {
+          // (1 outranks 2: a poisoned batch stays poisoned whatever the other batches of the call report)
+          int cur = __hip_atomic_load(a.status_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (cur != 1 && cur != st) {
+            if (__hip_atomic_compare_exchange_strong(a.status_out, &cur, st, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+          }
+        }
+      }
     }
   }
 #ifdef CVM_STAMPS

@@ -175,6 +175,7 @@ class CVMatrix:
         output: str = "torch",
         serve_loops: Optional[bool] = None,
         reuse_outputs: bool = False,
+        trust_tensor_versions: Optional[bool] = None,
     ) -> None:
         # ``lazy_fit=None`` (default): ``fit`` may defer its arithmetic to the first use only
         # when the object owns private copies of its inputs (``copy=True``, like the reference's
@@ -203,6 +204,19 @@ class CVMatrix:
         # next one.  For loops that consume each step's results before the next step (a multi-GPU rank's
         # step is shorter than the allocations it would otherwise issue).
         self.reuse_outputs = bool(reuse_outputs)
+        # ``trust_tensor_versions`` (default OFF; CVM_TRUST_VERSIONS=1 turns the default on): when ``fit`` is
+        # handed the very device tensors of this object's previous ``fit`` and torch's version counters say
+        # nothing was written to them since, skip what that fit already did -- the private copies (``copy=True``),
+        # the read-back and sign check of the weights, the shape bookkeeping (a benchmark-style loop of fit +
+        # batched call on resident inputs: 0.070 -> 0.040 ms of host time per step).  The version counter sees
+        # every write made THROUGH torch; it does not see ``t.data`` writes, DLPack / ``__cuda_array_interface__``
+        # consumers (CuPy, Numba), raw-pointer kernels or another library's in-place update.  After such a write a
+        # trusting ``fit`` would return the PREVIOUS data's matrices, where the reference re-reads its inputs on
+        # every ``fit`` (cvmatrix.py:207-328) -- hence off unless asked for, per object here or per call with
+        # ``fit(..., assume_unchanged=True)``.
+        if trust_tensor_versions is None:
+            trust_tensor_versions = os.environ.get("CVM_TRUST_VERSIONS", "0") != "0"
+        self.trust_tensor_versions = bool(trust_tensor_versions)
         self._arena = {}
         self._fit_src = None
         # ``output="numpy"``: every result (matrices, statistics, the XTX/XTY/sum_* attributes)
@@ -532,7 +546,7 @@ class CVMatrix:
             return torch.cuda.current_stream(self.device).cuda_stream
 
     # ------------------------------------------------------------------ fit stage
-    def fit(self, X, Y=None, weights=None, folds=None) -> None:
+    def fit(self, X, Y=None, weights=None, folds=None, assume_unchanged: Optional[bool] = None) -> None:
         """Store ``X``, ``Y``, ``weights`` on the device and compute the full-data
         ``XᵀWX``, ``XᵀWY`` and column statistics in one pass (cvmatrix.py:207-328).  With
         ``lazy_fit`` (the default) that pass is left pending until the matrices are first needed
@@ -546,9 +560,16 @@ class CVMatrix:
         ``prepare_folds`` / kept in ``self.sweep_folds``) only runs the correction kernels:
         half the arithmetic of ``fit`` + fold update.  Results agree to rounding.
 
+        ``assume_unchanged`` (not in the reference; default: the object's ``trust_tensor_versions``, off): the
+        caller states that device tensors which ARE the previous fit's (same objects, same torch version
+        counters -- both are still checked) hold the previous fit's values, so the copies, the weight
+        validation and the bookkeeping of that fit stand.  Do not state it for tensors something writes to
+        behind torch's back (``.data``, DLPack, raw pointers): see ``trust_tensor_versions``.
+
         Raises ``ValueError("Weights must be non-negative.")`` like cvmatrix.py:1188-1189.
         """
         lib = _lib.load()
+        trust = self.trust_tensor_versions if assume_unchanged is None else bool(assume_unchanged)
         self.device = self._pick_device()
         # nothing of an earlier fit may survive a fit that raises half-way
         self._sweep = None
@@ -562,7 +583,7 @@ class CVMatrix:
             # the same device tensors as the last fit of this object, unmodified since (object identity +
             # torch's version counter, which every in-place write through any view bumps): the device
             # copies / aliases, the validated weights and the shapes of that fit are still right
-            same = self._same_fit_inputs(X, Y, weights)
+            same = trust and self._same_fit_inputs(X, Y, weights)
             if not same:
                 self._fit_src = None
                 Ku = self._cols_of(X)
@@ -578,7 +599,7 @@ class CVMatrix:
                 else:
                     self.Y, self._Mu, self._Md = None, None, None
                 if weights is not None:
-                    self._check_weights_host(weights)
+                    self._check_weights_host(weights, trust)
                     self.weights = self._init_mat(weights)
                     if self.weights.shape != (self.N, 1):
                         raise ValueError("weights must have shape (N,) or (N, 1)")
@@ -586,7 +607,7 @@ class CVMatrix:
                     if self.weights is not None or self._w_host is not None:
                         self._w_gen = _NO_WEIGHTS
                     self.weights, self._w_host, self._w_checked, self._w_checked_src = None, None, None, None
-                self._remember_fit_inputs(X, Y, weights)
+                self._remember_fit_inputs(X, Y, weights)      # (what a LATER fit may be told is unchanged)
             M = self._Md or 0
             self._alloc_globals(lib.cvm_gstats_len(self._Kd, M))
             self._neg = None
@@ -696,14 +717,15 @@ class CVMatrix:
             return (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), w.dtype)
         return None
 
-    def _check_weights_host(self, weights) -> None:
+    def _check_weights_host(self, weights, trust: bool = False) -> None:
         """Sign check (cvmatrix.py:1188-1189) + host copy of the weights (per-fold validity
-        checks), before anything is launched.  A device tensor costs one read-back; the SAME
-        tensor object, unmodified since the last fit (identity + version counter -- the object is
-        kept referenced so its address cannot be recycled by another tensor), is not read again."""
+        checks), before anything is launched.  A device tensor costs one read-back; with ``trust``
+        (``trust_tensor_versions`` / ``fit(assume_unchanged=True)``) the SAME tensor object, unmodified
+        since the last fit by torch's version counter (the object is kept referenced, so its address
+        cannot be recycled by another tensor), is not read again."""
         if isinstance(weights, torch.Tensor) and weights.device.type != "cpu":
             key = self._weights_key(weights)
-            if (self.serve_loops and weights is self._w_checked_src and key == self._w_checked
+            if (trust and self.serve_loops and weights is self._w_checked_src and key == self._w_checked
                     and self._w_host is not None):
                 return
             h = weights.detach().reshape(-1).cpu().numpy()
@@ -1217,7 +1239,10 @@ class CVMatrix:
                 p_idx, p_off = batch._host_idx.ctypes.data, batch.host_offsets.ctypes.data
             else:
                 p_idx, p_off = batch.idx.data_ptr(), batch.offsets.data_ptr()
-            rc = lib.cvm_fold_update(
+            status = self.__dict__.get("_fold_status_t")
+            if status is None or status.device != dev:
+                status = self._fold_status_t = torch.zeros(1, dtype=torch.int32, device=dev)
+            rc = lib.cvm_fold_update_ex(
                 self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights),
                 p_idx, p_off,
                 batch.host_offsets.ctypes.data, P, self.N, K, M, self._cdt, flags,
@@ -1225,9 +1250,34 @@ class CVMatrix:
                 _lib.ptr(self._H), self._gs.data_ptr(), _lib.ptr(out_XTX),
                 _lib.ptr(out_XTY), muX.data_ptr(), sdX.data_ptr(), _lib.ptr(muY),
                 _lib.ptr(sdY), _lib.ptr(out_fold), ws.data_ptr(), ws.numel(), self._stream(),
+                status.data_ptr(),
             )
-            _lib.check(rc, "cvm_fold_update")
+            _lib.check(rc, "cvm_fold_update_ex")
         return out_XTX, out_XTY, (muX, sdX, muY, sdY), out_fold
+
+    def fold_status(self, reset: bool = True) -> int:
+        """Status word of the fold-stage calls made so far (``cvm_fold_update_ex``; one device read, it
+        waits for the stream): 0 = no work item ever gave up waiting for another, 2 = some did and were
+        recomputed inside their call (every result valid), 1 = results of some call hold NaN (a fault:
+        the reference's contract is "raise or return correct numbers", cvmatrix.py:754-896, and the
+        caller who wants to raise can).  ``reset`` zeroes the word."""
+        t = self.__dict__.get("_fold_status_t")
+        if t is None:
+            return 0
+        v = int(t.item())
+        if reset and v:
+            t.zero_()
+        return v
+
+    def _own_results(self, xtx, xty, stats):
+        """Results of ``_run`` that the object is about to KEEP (the slices a per-fold loop is served from):
+        with ``reuse_outputs`` they are the arena's buffers, which the next call of the same shape -- a
+        batched call the user makes between two calls of the loop -- overwrites; the kept copy must then be
+        the object's own."""
+        if not self.reuse_outputs:
+            return xtx, xty, stats
+        cl = lambda t: None if t is None else t.clone()      # noqa: E731
+        return cl(xtx), cl(xty), tuple(cl(t) for t in stats)
 
     def _training_matrices_batched(self, rXTX: bool, rXTY: bool, folds):
         """Batched counterpart of cvmatrix.py:754-896.  Leading axis = fold."""
@@ -1327,6 +1377,7 @@ class CVMatrix:
                     # once (a second request for a fold recomputes it: the caller may have changed
                     # its matrices in place).  The data-dependent raises stay per call.
                     xtx, xty, st, _ = self._run(batch, rXTX, rXTY, sweep_all=True)
+                    xtx, xty, st = self._own_results(xtx, xty, st)
                     c = self._cut_t                 # (padded device copies: cut once, for all folds)
                     st = (c(st[0], "X"), c(st[1], "X"), c(st[2], "Y"), c(st[3], "Y"))
                     self._sweep_cache = {"key": (rXTX, rXTY), "xtx": c(xtx, "XX"), "xty": c(xty, "XY"), "stats": st,
@@ -1431,6 +1482,7 @@ class CVMatrix:
         sub._sizes = full.sizes[a:b]
         rXTX, rXTY = ra.key
         xtx, xty, (muX, sdX, muY, sdY), _ = self._run(sub, rXTX, rXTY)
+        xtx, xty, (muX, sdX, muY, sdY) = self._own_results(xtx, xty, (muX, sdX, muY, sdY))
         cX, cY, sX, sY = self.center_X, self.center_Y, self.scale_X, self.scale_Y
         r_muX, r_muY, r_sdX, r_sdY = cX or (rXTY and cY), rXTY and (cX or cY), sX, rXTY and sY
         c = self._cut_t                             # (padded device copies: cut the chunk once)

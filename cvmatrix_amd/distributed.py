@@ -156,11 +156,11 @@ class ShardedCVMatrix(CVMatrix):
     def my_folds(self, sizes: Sequence[int]) -> List[int]:
         return assign_folds(sizes, self.world)[self.rank]
 
-    def fit(self, X, Y=None, weights=None, folds=None) -> None:
+    def fit(self, X, Y=None, weights=None, folds=None, assume_unchanged=None) -> None:
         if self.world > 1 and self.mode == "replicated" and folds is not None:
             raise ValueError("fit(folds=...) needs mode='row_sharded' (or a single process)")
         self._tail_pending = False
-        super().fit(X, Y, weights, folds=folds)     # row_sharded: this rank's rows (and folds)
+        super().fit(X, Y, weights, folds=folds, assume_unchanged=assume_unchanged)     # row_sharded: this rank's rows (and folds)
 
     def _launch_fit(self, lib) -> None:
         if self.world > 1 and self.mode == "replicated" and self.rank != self.src:

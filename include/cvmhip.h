@@ -29,8 +29,11 @@
  *     per stream / device is the intended use).  The library's only process-wide state is the
  *     optional launch-timing recorder below (mutex-guarded), once-per-device kernel
  *     attributes (atomic flags) and one 1 MiB device allocation per device, made on first use
- *     and kept (work-queue blocks of the persistent Gram kernel, one per stream, handed out
- *     under a mutex); planning depends on the arguments alone.
+ *     and kept (1024 work-queue blocks of the persistent Gram kernel, one per stream that uses
+ *     it, handed out under a mutex and RECYCLED: when all are taken, the block of the stream
+ *     that has gone longest without a Gram launch and has nothing in flight changes hands, so
+ *     a service may create and destroy streams without bound); planning depends on the
+ *     arguments alone.
  */
 #ifndef CVMHIP_H
 #define CVMHIP_H
@@ -120,6 +123,23 @@ int cvm_fold_update(const void *X, const void *Y, const void *w, const int64_t *
                     const double *gstats, void *out_XTX, void *out_XTY, void *out_muX,
                     void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
                     void *ws, size_t ws_bytes, void *stream);
+
+/* cvm_fold_update with a status word (the reference's contract is "raise or return correct numbers",
+ * cvmatrix.py:625-629, 1074-1078: this is how a caller proves the second half).
+ *   status   DEVICE int32[1], zeroed by the caller before the call, or NULL.
+ * One route of the fold stage -- mid-size folds that form their statistics inside the Gram launch -- lets
+ * work items wait for flags that other items of the same launch raise.  The wait is bounded; an item whose
+ * wait gives up writes nothing and is recomputed by a second launch of the same call once every flag is up.
+ * Behind the call (on `stream`):  *status == 0  nothing gave up;  2  some items were recomputed, every output
+ * is valid;  1  an item gave up in the second launch too (not possible by the kernel's own logic: a fault) and
+ * its outputs hold NaN.  Every other route leaves *status untouched. */
+int cvm_fold_update_ex(const void *X, const void *Y, const void *w, const int64_t *idx,
+                       const int64_t *offsets, const int64_t *host_offsets,
+                       int64_t n_folds, int64_t N, int K, int M, int dtype, unsigned flags,
+                       double ddof, double resolution, const void *G, const void *H,
+                       const double *gstats, void *out_XTX, void *out_XTY, void *out_muX,
+                       void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
+                       void *ws, size_t ws_bytes, void *stream, int32_t *status);
 
 /* One-sweep cross-validation (no counterpart in the reference).  When the
  * folds PARTITION the rows -- every row of X in exactly one fold, as the reference's own

@@ -114,16 +114,57 @@ def test_weights_are_validated_again_when_a_new_tensor_reuses_the_address(amd, h
         with pytest.raises(ValueError, match="Weights must be non-negative."):
             m.fit(X, None, w2)
         del w2
-    # the same unmodified tensor object IS recognised (no second read-back) ...
+    # by default every fit reads its inputs again, like the reference (cvmatrix.py:207-328) ...
     w = torch.rand(N, dtype=torch.float64, device=hip_device)
     m.fit(X, None, w)
     host = m._w_host
     m.fit(X, None, w)
+    assert m._w_host is not host
+    # ... a caller who says the tensors are unchanged is believed as far as torch's version counters agree
+    # (no second read-back of the same unmodified tensor object) ...
+    host = m._w_host
+    m.fit(X, None, w, assume_unchanged=True)
     assert m._w_host is host
-    # ... until it is modified in place
+    # ... until the tensor is modified in place
     w[3] = -2.0
     with pytest.raises(ValueError, match="Weights must be non-negative."):
+        m.fit(X, None, w, assume_unchanged=True)
+
+
+def test_writes_behind_torchs_back_are_seen_unless_the_caller_vouches_for_the_tensors(amd, hip_device):
+    """The blind spot of the fit() fast path, and who carries it.  torch's version counter does not see a
+    write through ``t.data`` (nor DLPack consumers, raw-pointer kernels, other libraries).  DEFAULT: fit()
+    re-reads its inputs on every call like the reference (cvmatrix.py:207-328) -- new X, new weights and a
+    negative weight smuggled in that way are all seen.  ``trust_tensor_versions=True`` /
+    ``fit(assume_unchanged=True)``: the caller vouches for the tensors, and a trusting fit of private copies
+    (``copy=True``) returns the PREVIOUS data's matrices -- the documented price of the 30 us it saves."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    N, K = 4000, 24
+    X = torch.from_numpy(rng.random((N, K))).to(hip_device)
+    w = torch.from_numpy(rng.random(N) + 0.1).to(hip_device)
+    for lazy in (False, True):
+        m = amd.CVMatrix(copy=True, lazy_fit=lazy)                     # the default policy
         m.fit(X, None, w)
+        g0 = m.XTX.clone()
+        X.data.mul_(2.0)                                               # no version bump
+        m.fit(X, None, w)
+        assert_normwise(m.XTX, 4.0 * to_np(g0), 1e-12, "refit after a .data write")
+        X.data.mul_(0.5)
+        w.data[5] = -1.0
+        with pytest.raises(ValueError, match="Weights must be non-negative."):
+            m.fit(X, None, w)
+        w.data[5] = 0.5
+        t = amd.CVMatrix(copy=True, lazy_fit=lazy, trust_tensor_versions=True)
+        t.fit(X, None, w)
+        g1 = t.XTX.clone()
+        X.data.mul_(2.0)
+        t.fit(X, None, w)                                              # believed: still the old private copy
+        assert torch.equal(t.XTX, g1)
+        t.fit(X, None, w, assume_unchanged=False)                      # the caller knows better this time
+        assert_normwise(t.XTX, 4.0 * to_np(g1), 1e-12, "assume_unchanged=False")
+        X.data.mul_(0.5)
 
 
 def test_fold_batch_is_checked_against_the_fit_it_is_used_with(amd):
@@ -399,6 +440,36 @@ def test_indices_changed_in_place_are_never_served_stale(amd, route, change):
 
 
 @pytest.mark.serving
+def test_reused_output_buffers_never_leak_into_the_served_loop(amd):
+    """``reuse_outputs=True`` writes a call's results into buffers keyed by shape; the per-fold loop is served
+    from slices the object keeps.  A batched call of the same shape made BETWEEN two calls of the loop must not
+    change what the loop's later calls return (the kept slices are the object's own copies)."""
+    rng = np.random.default_rng(77)
+    N, K, M, P = 6000, 40, 3, 6
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N) + 0.05
+    p = amd.Partitioner(np.arange(N) % P)
+    other = amd.Partitioner((np.arange(N) // 7) % P)       # another partition into P folds: same output shapes
+    o = OracleCVMatrix()
+    o.fit(X, Y, w)
+    for lazy in (True, False):
+        m = amd.CVMatrix(reuse_outputs=True, lazy_fit=lazy)
+        m.fit(X, Y, w)
+        keys = list(p.folds_dict)
+        (ax, ay), ast = m.training_XTX_XTY(p.get_validation_indices(keys[0]))
+        ax, ay = ax.clone(), ay.clone()
+        m.training_XTX_XTY_batched(other)                   # same (P, K, M): the arena's buffers are rewritten
+        for k in keys[1:]:
+            v = p.get_validation_indices(k)
+            (bx, by), bst = m.training_XTX_XTY(v)
+            (rx, ry), rst = o.training_XTX_XTY(v)
+            assert_normwise(bx, rx, 1e-10, f"fold {k} XTX")
+            assert_normwise(by, ry, 1e-10, f"fold {k} XTY")
+            assert_stats(bst, rst, what=f"fold {k}")
+        (rx, ry), _ = o.training_XTX_XTY(p.get_validation_indices(keys[0]))
+        assert_normwise(ax, rx, 1e-10, "fold 0 XTX")
+
+
+@pytest.mark.serving
 def test_serve_loops_off_recomputes_every_call(amd, monkeypatch):
     """``CVMatrix(serve_loops=False)`` / CVM_SERVE_LOOPS=0: no sweep for the loop, no read-ahead, no
     kept batches, no weights identity cache -- every call launches its own kernels on what it is
@@ -517,6 +588,48 @@ def test_two_threads_two_models_two_streams(amd, hip_device):
         assert len(got[i]) == len(want[i])
         for (a, b), (c, d) in zip(got[i], want[i]):
             assert torch.equal(a, c) and torch.equal(b, d)
+
+
+def test_more_streams_than_queue_blocks(amd, hip_device):
+    """The library owns one piece of device state: 1024 work-queue blocks per device for the persistent Gram
+    kernel, one per stream that launches it.  A service that keeps creating streams must not run out of them:
+    blocks of streams with nothing in flight change hands (csrc/host.hpp: acquire_queue).  1300 streams here --
+    400 of them destroyed at once, 900 kept alive -- each runs a fit; then the first kept streams run again on
+    whatever block they are handed now.  Every result equals the first, bit for bit."""
+    import torch
+
+    rng = np.random.default_rng(33)
+    N, K, M = 1500, 128, 2
+    X = torch.as_tensor(rng.random((N, K)), device=hip_device)
+    Y = torch.as_tensor(rng.random((N, M)), device=hip_device)
+    w = torch.as_tensor(rng.random(N) + 0.01, device=hip_device)
+    m = amd.CVMatrix(copy=False, lazy_fit=False)
+    m.fit(X, Y, w)
+    want = m.XTX.clone()
+    torch.cuda.synchronize()
+    kept = []
+    for i in range(1300):
+        st = torch.cuda.Stream(device=hip_device)
+        with torch.cuda.stream(st):
+            mi = amd.CVMatrix(copy=False, lazy_fit=False)
+            mi.fit(X, Y, w)
+            got = mi.XTX
+        if i % 100 == 0 or i >= 1290:
+            st.synchronize()
+            assert torch.equal(got, want), i
+        if i >= 400:
+            kept.append(st)
+        else:
+            st.synchronize()
+            del st
+    torch.cuda.synchronize()
+    for st in kept[:40]:
+        with torch.cuda.stream(st):
+            mi = amd.CVMatrix(copy=False, lazy_fit=False)
+            mi.fit(X, Y, w)
+            got = mi.XTX
+        st.synchronize()
+        assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("dtype", [np.float16, np.longdouble])

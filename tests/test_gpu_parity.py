@@ -96,8 +96,8 @@ def test_g3_leave_one_out_sweep(amd, chunk):
 # unweighted, uncentred XTY of a 6000-row fold at K=640, M=70 -- the MFMA accumulates a row split in
 # float32 where OpenBLAS blocks its sums), so the allowance is eight.  The 2e-5 / 2e-6 floors of
 # rounds 1-2 were never needed.
-FP32_EPS = float(np.finfo(np.float32).eps)
-# Round 4: the float32 Gram kernels fold their accumulators into a second set every 256 rows (two-level
+from fp32_gate import FP32_EPS, fp32_floor  # noqa: E402  (the gate's one definition: tests/fp32_gate.py)
+# Round 4: the float32 Gram kernels fold their accumulators into a second set every 1024 rows (FOLD_STAGES * 16; two-level
 # sums, like the blocked sgemm of the reference's BLAS), whatever the row-split plan: the allowance on top
 # of twice the yardstick is back to two roundings (result and yardstick are both float32 arrays: where the
 # yardstick is itself one rounding, "twice" is below the resolution of the comparison).
@@ -105,7 +105,7 @@ FP32_EPS = float(np.finfo(np.float32).eps)
 # float64 and rounds once, so means agree to a rounding; a standard deviation is the root of a
 # difference of sums and may lose a few more
 F32_STAT_RTOL = 2e-6
-FP32_FLOOR = 2 * FP32_EPS
+FP32_FLOOR = fp32_floor()      # two roundings; one more per extra partial under a forced split plan (fp32_gate.py)
 
 
 def assert_fp32_like_reference(got, ref64, ref32, what, floor=FP32_FLOOR):
@@ -1523,7 +1523,7 @@ def test_forced_split_plans(plan):
 @pytest.mark.parametrize("switch", ["CVM_NO_FUSED=1", "CVM_FORCE_FALLBACK=1", "CVM_NO_SWEEP_MERGE=1", "CVM_NO_DIRECT=1",
                                     "CVM_NO_COMPACT=1", "CVM_NO_INLINE_STATS=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0",
                                     "CVM_SMALL_MAXN=128", "CVM_MID_TILE=0", "CVM_MID_MINN=1", "CVM_MID_MAXN=1000",
-                                    "CVM_MID_OWNSTATS=1"])
+                                    "CVM_MID_OWNSTATS=1", "CVM_FUSED_PREPASS=1", "CVM_FUSED_ORDER=1"])
 def test_route_forcing_switches(switch):
     """One pass of tools/route_matrix.sh inside the suite: every route-forcing switch of the library
     (read once per process, hence a subprocess each) over tests/forced_plan_check.py -- two-stage
@@ -1537,6 +1537,99 @@ def test_route_forcing_switches(switch):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "forced_plan_check.py")],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_FUSED_TIMEOUT_CODE = """
+import numpy as np, torch, sys
+sys.path.insert(0, %(root)r)
+from cvmatrix_amd import CVMatrix
+from oracle.cvmatrix_oracle import OracleCVMatrix
+mode = %(mode)d
+worst = 0.0
+# (a hundred folds each: with few work items the planner cuts the folds' rows into splits and the call takes the
+#  route with partials, which waits for nothing)
+for dtype, N, K, M, nv, seed in ((np.float64, 30000, 516, 16, 300, 1), (np.float64, 40000, 260, 2, 400, 2),
+                                 (np.float32, 33000, 260, 4, 330, 3)):
+    rng = np.random.default_rng(seed)
+    X, Y, w = rng.random((N, K)) + 0.1, rng.random((N, M)), rng.random(N) + 0.01
+    perm = rng.permutation(N)
+    folds = [np.sort(perm[i:i + nv]) for i in range(0, N, nv)]
+    o = OracleCVMatrix(); o.fit(X, Y, w)
+    m = CVMatrix(dtype=dtype, lazy_fit=False); m.fit(X, Y, w)
+    (bx, by), st = m.training_XTX_XTY_batched(folds)
+    status = m.fold_status()
+    tol = 1e-10 if dtype is np.float64 else 2e-4
+    for f in list(range(0, 12)) + list(range(12, len(folds), 7)):
+        (rx, ry), rst = o.training_XTX_XTY(folds[f])
+        gx, gy = bx[f].double().cpu().numpy(), by[f].double().cpu().numpy()
+        if mode == 3 and f %% 3 == 0:
+            # the retry launch was made to give up too: every off-diagonal tile of these folds is poisoned,
+            # nothing of them passes for a number
+            assert np.isnan(gx).any(), f
+            continue
+        assert np.isfinite(gx).all() and np.isfinite(gy).all(), f
+        worst = max(worst, np.abs(gx - rx).max() / np.abs(rx).max(), np.abs(gy - ry).max() / np.abs(ry).max())
+        assert (gx == gx.T).all()
+        for g_, r_ in zip(st, rst):
+            worst = max(worst, np.abs(g_[f].double().cpu().numpy() - r_).max() / np.abs(r_).max())
+    assert worst <= tol, (dtype, worst)
+    print("status", status)
+    if mode == 1: assert status == 2, status
+    if mode == 2: assert status in (0, 2), status
+    if mode == 3: assert status == 1, status
+print("timeouts handled ok")
+"""
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_a_flag_wait_that_gives_up_is_recomputed_and_reported(mode):
+    """Mid-size folds form their statistics inside the Gram launch: off-diagonal work items wait for flags that
+    diagonal items of the same launch raise (wgram4.hpp).  The wait is bounded, and what happens when it gives
+    up is tested here by making it give up (``CVM_FUSED_TEST_TIMEOUT``): 1 = the off-diagonal items of every
+    third fold give up at once, 2 = a spin limit of four polls (they give up whenever a flag is not up yet),
+    3 = like 1 and the retry launch is made to give up as well.  Modes 1 and 2: every result is the oracle's
+    (the items were recomputed by the second launch of the same call), ``fold_status()`` says 2 where items
+    were recomputed.  Mode 3: status 1 and NaN in the affected folds -- never a finite wrong number.  The
+    reference's contract: cvmatrix.py:754-896 raises or returns correct numbers."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _FUSED_TIMEOUT_CODE % {"root": root, "mode": mode}
+    env = dict(os.environ, CVM_FUSED_TEST_TIMEOUT=str(mode))
+    env.pop("CVM_FORCE_SPLITS", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "timeouts handled ok" in r.stdout
+
+
+def test_fused_route_next_to_a_kernel_that_holds_the_compute_units(amd):
+    """The same route while another stream keeps the compute units busy (a chain of large matrix products):
+    workgroups of the Gram launch then start late and out of step, which is when an inter-workgroup wait shows
+    what it is made of.  Results must be bit for bit those of the quiet device, and the status word must not
+    report poisoned outputs."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    N, K, M, nv = 30000, 516, 16, 300
+    X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N) + 0.01
+    folds = [np.arange(f, N, N // nv)[:nv] for f in range(N // nv)]
+    m = amd.CVMatrix(lazy_fit=False)
+    m.fit(X, Y, w)
+    b = m.prepare_folds(folds)
+    (qx, qy), _ = m.training_XTX_XTY_batched(b)
+    qx, qy = qx.clone(), qy.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    A = torch.rand((6144, 6144), device="cuda", dtype=torch.float32)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            C_ = A
+            for _ in range(12):
+                C_ = (C_ @ A) * 1e-4
+        (bx, by), _ = m.training_XTX_XTY_batched(b)
+        torch.cuda.synchronize()
+        assert torch.equal(bx, qx) and torch.equal(by, qy), rep
+    assert m.fold_status() in (0, 2)
 
 
 def test_wide_matrices_k8192_k16384():
@@ -1644,7 +1737,7 @@ def test_mid_tile_route_shapes(amd, dtype, K, M, sizes):
 def test_randomised_routes_against_the_oracle(tool, args, env):
     """tools/fuzz_all.py / fuzz_small.py: random shapes, fold structures, element types, flags,
     weights, ddof, lazy or eager fit and call styles through every route of the fold stage,
-    against the oracle (float64 1e-10; float32 twice the oracle's own float32 error + 2e-5)."""
+    against the oracle (float64 1e-10; float32 twice the oracle's own float32 error + two roundings, tests/fp32_gate.py)."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -276,7 +276,11 @@ def test_local_counts_decide_the_checks_without_the_global_ones():
 
 
 def test_emulated_rank_is_importable_without_a_gpu():
-    from cvmatrix_amd.emulate import EmulatedRank
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from emulate import EmulatedRank      # (tools/emulate.py: a bench helper, not part of the package)
 
     r = EmulatedRank(emu_world=8, emu_rank=3, lazy_fit=True)
     assert r.world == 8 and r.rank == 3 and r._exchanges_globals() and r.lazy_fit

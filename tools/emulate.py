@@ -12,8 +12,8 @@ from __future__ import annotations
 
 import torch
 
-from .cvmatrix import CVMatrix
-from .distributed import ShardedCVMatrix
+from cvmatrix_amd.cvmatrix import CVMatrix
+from cvmatrix_amd.distributed import ShardedCVMatrix
 
 
 class EmulatedRank(ShardedCVMatrix):

@@ -9,6 +9,8 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fp32_gate import fp32_bound      # the float32 gate's one definition
 from cvmatrix_amd import CVMatrix, Partitioner
 from oracle.cvmatrix_oracle import OracleCVMatrix
 
@@ -110,11 +112,11 @@ for c in range(cases):
                 sx, _ = o32.training_XTX(v)
                 sy = None
         ex = nerr(bx[f], rx)
-        tolx = 1e-10 if dt is np.float64 else 2 * nerr(sx, rx) + 2.4e-7
+        tolx = 1e-10 if dt is np.float64 else fp32_bound(nerr(sx, rx))
         assert ex <= tolx, (what, "XTX", ex, tolx)
         if by is not None:
             ey = nerr(by[f], ry)
-            toly = 1e-10 if dt is np.float64 else 2 * nerr(sy, ry) + 2.4e-7
+            toly = 1e-10 if dt is np.float64 else fp32_bound(nerr(sy, ry))
             assert ey <= toly, (what, "XTY", ey, toly)
             if dt is np.float64 and ey > worst:
                 worst, worst_what = ey, (what, "XTY", int(f))

@@ -1,4 +1,4 @@
-"""Host time of one per-rank step of a G-GPU strong-scaling job (emulated, cvmatrix_amd/emulate.py):
+"""Host time of one per-rank step of a G-GPU strong-scaling job (emulated, tools/emulate.py):
 cProfile of fit() + batched training_XTX_XTY over the rank's folds at the C3 shape.
     python tools/profile_rank_host.py [G]"""
 import cProfile, pstats, os, sys, time
@@ -6,7 +6,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cvmatrix_amd import Partitioner
 from cvmatrix_amd.distributed import shard_folds
-from cvmatrix_amd.emulate import EmulatedRank, others_share
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from emulate import EmulatedRank, others_share
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N, K, M, P = 100000, 512, 16, 10

@@ -9,18 +9,17 @@
 cd "$(dirname "$0")/.."
 for e in "CVM_FORCE_SPLITS=3,5" "CVM_FORCE_SPLITS=7,2" "CVM_NO_FUSED=1" "CVM_FORCE_FALLBACK=1" \
          "CVM_NO_SWEEP_MERGE=1" "CVM_NO_DIRECT=1" "CVM_PAD=0" "CVM_NO_COMPACT=1" "CVM_NO_INLINE_STATS=1" \
-         "CVM_SERVE_LOOPS=0" "CVM_SMALL_MAXN=128" "CVM_SMALL_MAXN=64" "CVM_SMALL_TILE=1" "CVM_SMALL_TILE=2" "CVM_MID_TILE=0" "CVM_MID_MINN=1" "CVM_MID_MAXN=1000" "CVM_MID_OWNSTATS=1"; do
+         "CVM_SERVE_LOOPS=0" "CVM_SMALL_MAXN=128" "CVM_SMALL_MAXN=64" "CVM_SMALL_TILE=1" "CVM_SMALL_TILE=2" "CVM_MID_TILE=0" "CVM_MID_MINN=1" "CVM_MID_MAXN=1000" "CVM_MID_OWNSTATS=1" \
+         "CVM_FUSED_PREPASS=1" "CVM_FUSED_ORDER=1"; do
   echo "== $e"
   mark="gpu"
   extra=""
   # (with loop serving off, the tests that look INSIDE the serving have nothing to see: they carry the
-  #  `serving` marker.  Since round 4 the float32 Gram kernels sum in chains of at most 1024 rows whatever the
-  #  plan, so the float32 cases run under the forced split plans too -- but for ONE comparison: plan 3/5, which
-  #  the planner never makes for that shape, puts fold 2's XTY of the K = 516 three-fold case at 2.14e-6 against a
-  #  gate of 2.02e-6 (twice NumPy-float32's own error plus two roundings); profiles/r4/route_matrix.txt.)
+  #  `serving` marker.  The float32 cases run under the forced split plans too, no case deselected: the gate's
+  #  allowance is derived from the plan in effect -- one float32 rounding per partial a forced plan adds to a
+  #  tile's ordered sum, tests/fp32_gate.py.)
   case "$e" in
     CVM_SERVE_LOOPS=0) mark="gpu and not serving" ;;
-    CVM_FORCE_SPLITS=3,5) extra=" and not (float32_shape_sweep and 516)" ;;
   esac
   env $e timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -m "$mark" -q \
       -k "not bench_command and not plan and not full_size_properties and not forced_split and not randomised$extra" 2>&1 | grep -E "^FAILED|passed|failed" | tail -8
