@@ -165,8 +165,10 @@ SplitChoice choose_splits2(int64_t n_seg, int64_t max_rows, const Geom &g, int e
   if (cap > mem_cap) cap = mem_cap;
   if (cap > 128) cap = 128;
   if (cap < 1) cap = 1;
-  // CVM_FORCE_SPLITS="s_off,s_diag": experiments (tools/) pin the plan; clamped to the caps
-  static const char *force = getenv("CVM_FORCE_SPLITS");
+  // CVM_FORCE_SPLITS="s_off,s_diag": experiments (tools/) and tests pin the plan; clamped to the caps.  Read at
+  // every call (the one switch that is: tests/test_gpu_planner.py times the planner's plan against forced
+  // neighbours inside one process)
+  const char *force = getenv("CVM_FORCE_SPLITS");
   if (force && !g.diag_only && g.nTiles > g.P) {
     int so = 0, sd = 0;
     if (sscanf(force, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1)
@@ -725,6 +727,12 @@ template <typename T> int launch_mid(MidArgs m, bool weighted, int64_t nb, int64
   m.ipf = m.n_xtx + m.nt * m.yextra;
   m.n_items = (long long)nb * m.ipf;
   m.per_xcd = (m.n_items + 7) / 8;
+  m.nb = (int)nb;
+  if (m.stat_flags) {                      // statistics formed in the launch: whole folds per XCD (mid_tile.hpp)
+    if (m.yextra) return fail(CVM_EINVAL, "launch_mid: statistics in the launch need M <= 16%s");
+    m.fpx = (int)((nb + 7) / 8);
+    m.per_xcd = (long long)m.fpx * m.ipf;
+  }
   m.maxn = (int)((max_rows + 15) / 16 * 16);
   if (m.maxn < 16) m.maxn = 16;
   const size_t lds = mid_lds_bytes<T>(m.maxn);
@@ -734,6 +742,13 @@ template <typename T> int launch_mid(MidArgs m, bool weighted, int64_t nb, int64
   TimedLaunch *tl = timed_begin(KIND_FOLD, st);
   if (weighted) hipLaunchKernelGGL((mid_tile_kernel<T, true>), grid, dim3(MID_THREADS), lds, st, m);
   else hipLaunchKernelGGL((mid_tile_kernel<T, false>), grid, dim3(MID_THREADS), lds, st, m);
+  if (m.stat_flags) {
+    // the items whose wait for a flag gave up (none, unless the device is shared in a way that breaks the
+    // dispatch-order argument of mid_tile.hpp): once more, behind the launch that has raised every flag
+    m.retry_mode = 1;
+    if (weighted) hipLaunchKernelGGL((mid_retry_kernel<T, true>), dim3(64), dim3(MID_THREADS), lds, st, m);
+    else hipLaunchKernelGGL((mid_retry_kernel<T, false>), dim3(64), dim3(MID_THREADS), lds, st, m);
+  }
   timed_end(tl, st);
   HIP_OK(hipGetLastError());
   return CVM_OK;
@@ -791,6 +806,7 @@ struct FoldSwitches {
   int mid_minn, mid_maxn;      // CVM_MID_MINN / CVM_MID_MAXN: row limits of mid_tile_kernel (0: the measured table)
   bool mid_off;                // CVM_MID_TILE=0: never mid_tile_kernel
   bool mid_own;                // CVM_MID_OWNSTATS=1: its items sum their own columns (no pre-pass; measured slower)
+  bool mid_ink;                // CVM_MID_INK=1: mid_tile_kernel forms its statistics in the launch (measured slower: below)
   bool force_fallback;         // CVM_FORCE_FALLBACK=1: the general Gram kernel
   bool no_fused;               // CVM_NO_FUSED=1: partials + apply_kernel for one-unit folds too
   bool prepass;                // CVM_FUSED_PREPASS=1: statistics by colstats_kernel + fold_stats_kernel, not in the launch
@@ -804,6 +820,7 @@ const FoldSwitches &fold_switches() {
     f.mid_minn = num("CVM_MID_MINN", 0); f.mid_maxn = num("CVM_MID_MAXN", 0);
     f.mid_off = num("CVM_MID_TILE", 1) == 0;
     f.mid_own = num("CVM_MID_OWNSTATS", 0) != 0;
+    f.mid_ink = num("CVM_MID_INK", 0) != 0;
     f.force_fallback = num("CVM_FORCE_FALLBACK", 0) != 0;
     f.no_fused = num("CVM_NO_FUSED", 0) != 0;
     f.prepass = num("CVM_FUSED_PREPASS", 0) != 0;
@@ -971,8 +988,33 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       const int per0 = p.g.nTiles - p.g.P;
       const bool ink = !mid && !sw.prepass && p.g.Yc == 1 &&
                        fst + (size_t)p.g.P * 4 + (size_t)per0 * 8 + 512 <= per_fold;
+      // mid_tile_kernel can form its statistics in the launch the same way (round 5, CVM_MID_INK=1: its diagonal
+      // tiles sum their panel's columns and publish, the others poll behind their stage loop; M <= 16 when XTY is
+      // wanted).  Built, green, measured and NOT the default: the diagonal tiles' column sums are vector
+      // arithmetic next to three other workgroups' float64 MFMAs, and every off-diagonal tile pays one more
+      // dependent memory round trip behind its loop -- the C3 rows in 1000 folds 1.16 -> 1.24 ms, in 3000 folds
+      // 2.16 -> 2.30 ms (1.29 / 2.35 before the diagonal tiles were dispatched a fold ahead), where the pre-pass it
+      // removes costs 0.09 ms (profiles/r5/mid_tile/inlaunch_statistics.txt)
+      const int nt64 = (K + 63) / 64, noff64 = nt64 * (nt64 - 1) / 2;
+      const bool mid_ink = mid && sw.mid_ink && !sw.prepass && !(want_xty && M > 16) &&
+                           fst + (size_t)nt64 * 4 + (size_t)noff64 * 8 + 512 <= per_fold;
       for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
+        if (mid_ink) {
+          // workspace of the batch: [fstats nb x fst | flags nb x nt | status 4 ints | retry list nb x off-diagonal tiles]
+          double *fstats = (double *)ws;
+          int *sflags = (int *)((char *)ws + align_up((size_t)nb * fst, 256));
+          const size_t flag_bytes = align_up((size_t)nb * nt64 * sizeof(int), 16);
+          int *fstatus = (int *)((char *)sflags + flag_bytes);
+          HIP_OK(hipMemsetAsync(sflags, 0, flag_bytes + 16, st));
+          MidArgs m = mid_args(c, f0, fstats);
+          m.stat_flags = sflags; m.fused_status = fstatus;
+          m.retry_items = (unsigned long long *)((char *)fstatus + 16);
+          m.status_out = status; m.test_mode = sw.fused_test;
+          rc = launch_mid<T>(m, w != nullptr, nb, max_rows, st);
+          if (rc != CVM_OK) return rc;
+          continue;
+        }
         if (ink) {
           double *fstats = (double *)ws;
           int *sflags = (int *)((char *)ws + align_up((size_t)nb * fst, 256));

@@ -56,8 +56,43 @@ struct MidArgs {
   int yextra;                    // XTY-only items per panel (64 response columns each, past the first 16)
   int ipf;                       // items per fold
   int maxn;                      // rows the LDS lists hold (a multiple of 16, >= the longest fold)
+  int chmax;                     // (tools/experiments/mid_chain.hpp: tiles per chain at most)
   unsigned flags;
+  // Statistics formed INSIDE the launch (round 5; stat_flags != nullptr, fstats writable, yextra == 0): the diagonal
+  // tile of (fold, panel) sums its panel's columns (and the Y tile's, and the weights) in row order like an item of
+  // the own-statistics mode, derives the training means / reciprocal stds, writes them to fstats with
+  // device-coherent stores and raises stat_flags[fold * nt + panel]; an off-diagonal tile polls the flags of its
+  // two panels behind its stage loop.  Items: a fold's nt diagonal tiles first, whole folds per XCD (fpx), so a
+  // waiting workgroup was dispatched after the ones it waits for.  The wait is bounded: an item that gives up
+  // writes nothing and lists itself in retry_items (count in fused_status[0]); the host's second launch
+  // (retry_mode) recomputes the listed items behind the first; giving up there counts in fused_status[1] and
+  // poisons the item's outputs with NaN; its last workgroup (exit counter fused_status[2]) folds both into
+  // *status_out like wgram4_kernel's retry launch (cvm_fold_update_ex).
+  int *stat_flags;
+  int *fused_status;
+  unsigned long long *retry_items;
+  int32_t *status_out;
+  int retry_mode, test_mode;
+  int fpx, nb;                   // folds per XCD, folds of the batch
+  // measurements only (tools/mid_probe.hip builds with -DCVM_MID_ABLATE; the library never sets them):
+  // dbg bits: 1 no output stores, 2 no G loads, 4 no LDS-DMA after the first stages, 8 no MFMA, 16 return after the loop
+  int dbg;
+  unsigned long long *stamps;    // [512][8] cycle stamps of sampled workgroups
 };
+#ifdef CVM_MID_ABLATE
+#define MID_DBG(a) ((a).dbg)
+#define MID_STAMP(i)                                                                                  \
+  do {                                                                                                \
+    if (a.stamps && tid == 0 && (bid & 63) == 5 && (bid >> 6) < 512) {                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+      a.stamps[(size_t)(bid >> 6) * 8 + (i)] = __builtin_amdgcn_s_memtime();                          \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+    }                                                                                                 \
+  } while (0)
+#else
+#define MID_DBG(a) 0
+#define MID_STAMP(i)
+#endif
 constexpr int MID_THREADS = 256;
 #ifndef CVM_MID_SR
 #define CVM_MID_SR 16            // rows per stage
@@ -78,8 +113,9 @@ template <typename T> inline size_t mid_lds_bytes(int maxn) {
   return mid_region_bytes<T>() + 2 * 256 * 8 + (size_t)maxn * sizeof(T) + (size_t)maxn * 4;
 }
 
+// one work item: fold f of the batch, item q of the fold
 template <typename T, bool WEIGHTED>
-__global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(const MidArgs a) {
+__device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, const int q, const int bid, char *smem_raw) {
   typedef typename MF<T>::acc_t acc_t;
   constexpr int ES = (int)sizeof(T), EPL = 16 / ES;
   constexpr int SR = MID_SR, NBUF = MID_NBUF, KPS = SR / 4;   // k-steps per stage
@@ -94,17 +130,22 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
   constexpr int VW = 16 / ES, LPRO = 64 / VW, JB = 16 / VW;
   static_assert(RPW >= RPI, "a wave's rows of a stage fill whole DMA instructions");
   typedef T vt __attribute__((ext_vector_type(VW)));
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int bid = blockIdx.x;
-  const long long item = (long long)(bid & 7) * a.per_xcd + (bid >> 3);
-  if (item >= a.n_items) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const int dbg = MID_DBG(a);
+  MID_STAMP(0);
   const int K = a.K, M = a.M;
-  const int f = (int)(item / a.ipf);
-  const int q = (int)(item - (long long)f * a.ipf);
+  const bool ink = a.stat_flags != nullptr;
   // kind 0: XTX tile (ti, tj); kind 2: XTY-only item (panel ti, response columns 16 + 64 yc ..)
   int ti = 0, tj = 0, yc = 0, kind = 0;
-  if (q < a.n_xtx) {
+  if (ink) {
+    // (statistics formed in the launch: the fold's diagonal tiles first, then the others row by row)
+    if (q < a.nt) ti = tj = q;
+    else {
+      int rem = q - a.nt;
+      while (rem >= a.nt - 1 - ti) { rem -= a.nt - 1 - ti; ++ti; }
+      tj = ti + 1 + rem;
+    }
+  } else if (q < a.n_xtx) {
     int rem = q;
     while (rem >= a.nt - ti) { rem -= a.nt - ti; ++ti; }
     tj = ti + rem;
@@ -138,8 +179,12 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
   T *wl = reinterpret_cast<T *>(sq + 256);
   int *rowl = reinterpret_cast<int *>(wl + a.maxn);
   T (*Ts)[65] = reinterpret_cast<T (*)[65]>(smem_raw);
-  const bool own = a.fstats == nullptr;
-  const double *fs = own ? nullptr : a.fstats + (size_t)f * fstat_len(K, M);
+  // where the statistics come from: `own` -- this item sums its staged columns itself (every item when there is no
+  // statistics vector at all; the diagonal tiles when the statistics are formed in the launch); `late` -- from the
+  // diagonal tiles of its two panels, behind the stage loop; else from the pre-pass, at once
+  const bool own = a.fstats == nullptr || (ink && diag);
+  const bool late = ink && !diag;
+  const double *fs = a.fstats == nullptr ? nullptr : a.fstats + (size_t)f * fstat_len(K, M);
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
   const bool rXTY = a.flags & CVM_RET_XTY;
@@ -155,12 +200,15 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
   // ---- the fold's row numbers, the tile's statistics (the weights: behind the first stages' DMAs) ----
   const int npad = nst * SR;
   for (int r = tid; r < npad; r += MID_THREADS) rowl[r] = r < n ? (int)a.idx[rbeg + r] : 0;
+  MID_STAMP(1);
   double swt = 0.0;
   // (own statistics) the full-data sums of this thread's column of the blocks: X column and response column
   double gsx = 0, gqx = 0, gsy = 0, gqy = 0, gsw = 0, gnz = 0;
   const int xcol = ((which < 2) ? a0 : b0) + wc64;        // (diagonal tile: b0 == a0)
   const int ycol = ybase + wc64;
-  if (!own) {
+  if (late) {
+    // (nothing yet)
+  } else if (!own) {
     double v = (which & 1) ? 1.0 : 0.0;
     if (xcol < K && (kind == 0 || which < 2)) {
       if (!(which & 1) && cX) v = fs[xcol];
@@ -186,6 +234,7 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
   const bool loadB = kind == 0 && !diag;
   auto issue = [&](int s) -> int {
     int cnt = 0;
+    if ((dbg & 4) && s >= NBUF - 1) return 0;
     const unsigned bufb = lds0 + (unsigned)((s % NBUF) * MID_STAGE_ELEMS * ES);
 #pragma unroll
     for (int qi = 0; qi < IPW; ++qi) {
@@ -234,6 +283,11 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
   // the G pieces of this wave's sixteen rows of the tile: requested before the accumulators go to LDS
   auto g_preload = [&]() {
     if (!finish_xtx) return;
+    if (dbg & 2) {
+#pragma unroll
+      for (int j = 0; j < JB; ++j) gv[j] = (vt)(T)0;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
       const int gr = a0 + 16 * wave + VW * j + sub;
@@ -347,6 +401,62 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
     if (which == 2) sq[64 + wc64] = v_y;
     if (which == 3) sq[128 + wc64] = v_y;
   };
+  // ---- statistics formed in the launch: the hand-off ---------------------------------------------------------
+  // (diagonal tile, behind stats_phase and its barrier) wave 0 copies the panel's means / reciprocal stds -- as the
+  // blocks hold them: 0 / 1 where the flags ask for no centring / scaling -- and sw_T to the fold's statistics
+  // vector with device-coherent stores, waits for ITS stores and raises the panel's flag
+  auto publish = [&]() {
+    if (!(ink && diag) || wave != 0) return;
+    double *fsw = const_cast<double *>(fs);
+    if (a0 + lane < K) { stc(fsw + a0 + lane, rs[lane]); stc(fsw + K + a0 + lane, rs[64 + lane]); }
+    if (lane == 0) stc(fsw + 2 * K + 2 * M, swt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(a.stat_flags + (size_t)f * a.nt + ti, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // (off-diagonal tile, behind the stage loop) one lane waits for the flags of the two panels -- bounded: see
+  // MidArgs -- then every thread fetches its entry of the blocks with device-coherent loads.  false: the item
+  // gave up, is listed for the retry launch and writes nothing.
+  auto await_statistics = [&]() -> bool {
+    int *markp = reinterpret_cast<int *>(sq + 250);
+    if (tid == 0) {
+      int ok = 1;
+      const long limit = a.test_mode == 2 ? 4 : (1L << 18);
+      const bool feign = (a.test_mode == 1 || a.test_mode == 3) && f % 3 == 0 && (!a.retry_mode || a.test_mode == 3);
+      for (int w2 = 0; w2 < 2 && ok; ++w2) {
+        const int *fl = a.stat_flags + (size_t)f * a.nt + (w2 ? tj : ti);
+        long spins = 0;
+        while (feign || __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (feign || ++spins > limit) { ok = 0; break; }
+        }
+      }
+      int mark = 1;
+      if (!ok) {
+        if (!a.retry_mode) {
+          const int pos = __hip_atomic_fetch_add(a.fused_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          a.retry_items[pos] = (unsigned long long)f * (unsigned long long)a.ipf + (unsigned long long)q;
+          mark = 0;
+        } else {
+          __hip_atomic_fetch_add(a.fused_status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          mark = 2;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *reinterpret_cast<volatile int *>(markp) = mark;
+    }
+    lds_barrier();
+    const int mark = uni(*reinterpret_cast<volatile int *>(markp));
+    if (mark == 0) return false;
+    double v = (which & 1) ? 1.0 : 0.0;
+    if (xcol < K) {
+      if (!(which & 1) && cX) v = ldc(fs + xcol);
+      if ((which & 1) && sX) v = ldc(fs + K + xcol);
+    }
+    swt = ldc(fs + 2 * K + 2 * M);
+    if (mark == 2) { v = __builtin_nan(""); swt = v; }      // (never a finite wrong number)
+    rs[tid] = v;
+    return true;
+  };
   if (role == 2) {
     acc_t acc[4];
 #pragma unroll
@@ -375,23 +485,37 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
 #pragma unroll 1
     for (int s = 0; s < nst; ++s) {
       stage_head(s);
-      ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
+      if (s == 0) MID_STAMP(2);
+      if (!(dbg & 8)) ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
       stage_stats(s);
     }
+    MID_STAMP(3);
+    if (dbg & 16) return;
     g_preload();
     stats_phase();
     lds_barrier();                                       // the blocks are in LDS; the ring is free
+    publish();                                           // (a no-op in this wave: wave 0 publishes)
     // XTY piece straight from the accumulators (cvmatrix.py:1001-1010 for XTY)
     T *out = reinterpret_cast<T *>(a.out_XTY) + fo * (size_t)K * M;
     const T *Ht = reinterpret_cast<const T *>(a.H);
     const int col = ycol0 + lc, yl = col - ybase;
+    // (all sixteen pieces of H requested before the first is used: one memory round trip, not sixteen -- the other
+    //  waves of a diagonal tile wait for this one at the next barrier)
+    T hv[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = a0 + 16 * m + MF<T>::drow(lane, r);
+        hv[m][r] = Ht[(size_t)(row < K ? row : 0) * M + (col < M ? col : 0)];
+      }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int lr = 16 * m + MF<T>::drow(lane, r), row = a0 + lr;
-        if (row < K && col < M) {
-          double vv = (double)Ht[(size_t)row * M + col] - (double)acc[m][r];
+        if (row < K && col < M && !(dbg & 1)) {
+          double vv = (double)hv[m][r] - (double)acc[m][r];
           if (cX || cY) vv -= swt * (sq[lr] * sq[64 + yl]);
           if (sX && sY) vv = vv * (rs[64 + lr] * sq[128 + yl]);
           else if (sX) vv = vv * rs[64 + lr];
@@ -429,12 +553,17 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
 #pragma unroll 1
     for (int s = 0; s < nst; ++s) {
       stage_head(s);
-      if (role == 1) ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
+      if (s == 0) MID_STAMP(2);
+      if (role == 1 && !(dbg & 8)) ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
       stage_stats(s);
     }
+    MID_STAMP(3);
+    if (dbg & 16) return;
     g_preload();
+    if (late && !await_statistics()) return;             // (its wait gave up: nothing is written, the retry launch recomputes it)
     stats_phase();
     lds_barrier();                                       // the blocks are in LDS; the ring is free: the tile goes over it
+    publish();
     if (finish_xtx) {
       if (role == 1) {
 #pragma unroll
@@ -449,6 +578,7 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
   }
   if (!finish_xtx) return;
   lds_barrier();                                         // the tile is in LDS
+  MID_STAMP(4);
   // (fused_finish_direct's arithmetic, finalize.hpp, on the preloaded pieces)
   {
     double muc[VW], sdc[VW];
@@ -468,14 +598,75 @@ __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(cons
         if (sX) x = x * (sdr * sdc[e]);
         vv[e] = (T)x;
       }
-      out_store(reinterpret_cast<vt *>(outp + (size_t)gr * K + gc), vv);
+      if (!(dbg & 1)) out_store(reinterpret_cast<vt *>(outp + (size_t)gr * K + gc), vv);
       if (!diag) {
 #pragma unroll
         for (int e = 0; e < VW; ++e) Ts[lr][lcc + e] = vv[e];
       }
     }
   }
+  MID_STAMP(5);
   if (diag) return;
   lds_barrier();                                         // the finished values are parked in Ts (LDS only: the stores stay in flight)
-  fused_finish_mirror<T, 65>(Ts, a0, b0, K, outp, lane, 16 * wave, 16 * wave + 16);
+  if (!(dbg & 1)) fused_finish_mirror<T, 65>(Ts, a0, b0, K, outp, lane, 16 * wave, 16 * wave + 16);
+  MID_STAMP(6);
+}
+
+template <typename T, bool WEIGHTED>
+__global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(const MidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int bid = blockIdx.x;
+  int f, q;
+  if (a.stat_flags) {
+    // whole folds per XCD: workgroup b -> XCD b % 8, position b / 8 of that XCD's sequence.  The sequence runs the
+    // diagonal tiles one fold AHEAD of the others -- diag(0) | diag(1), off(0) | diag(2), off(1) | ... | off(last)
+    // -- so that (the hardware starts an XCD's workgroups in order) a fold's statistics are a fold's worth of
+    // work old when its off-diagonal tiles ask for them
+    const int pos = bid >> 3, noff = a.ipf - a.nt;
+    int fl;
+    if (pos < a.nt) { fl = 0; q = pos; }
+    else {
+      const int p2 = pos - a.nt, k = p2 / a.ipf, r = p2 - k * a.ipf;
+      if (k < a.fpx - 1) { if (r < a.nt) { fl = k + 1; q = r; } else { fl = k; q = r; } }
+      else { fl = a.fpx - 1; q = a.nt + (p2 - (a.fpx - 1) * a.ipf); if (q >= a.ipf) return; }
+    }
+    (void)noff;
+    f = (bid & 7) * a.fpx + fl;
+    if (fl >= a.fpx || f >= a.nb) return;
+  } else {
+    const long long item = (long long)(bid & 7) * a.per_xcd + (bid >> 3);
+    if (item >= a.n_items) return;
+    f = (int)(item / a.ipf);
+    q = (int)(item - (long long)f * a.ipf);
+  }
+  mid_tile_item<T, WEIGHTED>(a, f, q, bid, smem_raw);
+}
+
+// The retry launch of a call that forms its statistics in the launch (MidArgs::retry_mode): the items whose wait
+// gave up in the first launch, a few workgroups walking the list; the last one to leave reports.
+template <typename T, bool WEIGHTED>
+__global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_retry_kernel(const MidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int bid = blockIdx.x;
+  const int n = __hip_atomic_load(a.fused_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+  for (int i = bid; i < n; i += (int)gridDim.x) {
+    const unsigned long long it = a.retry_items[i];
+    mid_tile_item<T, WEIGHTED>(a, (int)(it / (unsigned long long)a.ipf), (int)(it % (unsigned long long)a.ipf), bid, smem_raw);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int left = __hip_atomic_fetch_add(a.fused_status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == (int)gridDim.x - 1 && a.status_out) {
+      const int lost = __hip_atomic_load(a.fused_status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int st = lost ? 1 : (n ? 2 : 0);
+      if (st) {
+        int cur = __hip_atomic_load(a.status_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (cur != 1 && cur != st) {
+          if (__hip_atomic_compare_exchange_strong(a.status_out, &cur, st, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+      }
+    }
+  }
 }

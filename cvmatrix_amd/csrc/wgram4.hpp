@@ -706,10 +706,12 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       if (active) {
         // the statistics first, then the G pieces of this wave's 32 rows: both in flight while the
         // accumulators go to LDS (the statistics are waited for alone: they were issued first)
-        const double r0v = (cX && a0 + lane < K) ? ldc(fs + a0 + lane) : 0.0;
-        const double r1v = (sX && a0 + lane < K) ? ldc(fs + K + a0 + lane) : 1.0;
-        const double r2v = (cX && b0 + lane < K) ? ldc(fs + b0 + lane) : 0.0;
-        const double r3v = (sX && b0 + lane < K) ? ldc(fs + K + b0 + lane) : 1.0;
+        double r0v = (cX && a0 + lane < K) ? ldc(fs + a0 + lane) : 0.0;
+        double r1v = (sX && a0 + lane < K) ? ldc(fs + K + a0 + lane) : 1.0;
+        double r2v = (cX && b0 + lane < K) ? ldc(fs + b0 + lane) : 0.0;
+        double r3v = (sX && b0 + lane < K) ? ldc(fs + K + b0 + lane) : 1.0;
+        // (a poisoned item: the reciprocal stds too, so that scaling without centring cannot pass a number either)
+        if (mark == FUSED_POISON) r0v = r1v = r2v = r3v = __builtin_nan("");
         fused_g_preload32<T>(gp, a0, b0, K, (const T *)a.G, lane, 0);
         rs[lane] = r0v; rs[64 + lane] = r1v; rs[128 + lane] = r2v; rs[192 + lane] = r3v;
 #pragma unroll

@@ -1523,7 +1523,7 @@ def test_forced_split_plans(plan):
 @pytest.mark.parametrize("switch", ["CVM_NO_FUSED=1", "CVM_FORCE_FALLBACK=1", "CVM_NO_SWEEP_MERGE=1", "CVM_NO_DIRECT=1",
                                     "CVM_NO_COMPACT=1", "CVM_NO_INLINE_STATS=1", "CVM_SERVE_LOOPS=0", "CVM_PAD=0",
                                     "CVM_SMALL_MAXN=128", "CVM_MID_TILE=0", "CVM_MID_MINN=1", "CVM_MID_MAXN=1000",
-                                    "CVM_MID_OWNSTATS=1", "CVM_FUSED_PREPASS=1", "CVM_FUSED_ORDER=1"])
+                                    "CVM_MID_OWNSTATS=1", "CVM_FUSED_PREPASS=1", "CVM_FUSED_ORDER=1", "CVM_MID_INK=1"])
 def test_route_forcing_switches(switch):
     """One pass of tools/route_matrix.sh inside the suite: every route-forcing switch of the library
     (read once per process, hence a subprocess each) over tests/forced_plan_check.py -- two-stage
@@ -1548,8 +1548,11 @@ mode = %(mode)d
 worst = 0.0
 # (a hundred folds each: with few work items the planner cuts the folds' rows into splits and the call takes the
 #  route with partials, which waits for nothing)
-for dtype, N, K, M, nv, seed in ((np.float64, 30000, 516, 16, 300, 1), (np.float64, 40000, 260, 2, 400, 2),
-                                 (np.float32, 33000, 260, 4, 330, 3)):
+# (folds of 300 rows and more: the fused Gram route; of 100 rows: mid_tile_kernel under CVM_MID_INK=1 -- both form
+#  their statistics in the launch)
+for dtype, N, K, M, nv, seed in ((np.float64, 30000, 516, 16, 300, 1), (np.float64, 12000, 516, 16, 100, 4),
+                                 (np.float64, 40000, 260, 2, 400, 2), (np.float32, 33000, 260, 4, 330, 3),
+                                 (np.float32, 12000, 132, 4, 60, 5)):
     rng = np.random.default_rng(seed)
     X, Y, w = rng.random((N, K)) + 0.1, rng.random((N, M)), rng.random(N) + 0.01
     perm = rng.permutation(N)
@@ -1558,11 +1561,13 @@ for dtype, N, K, M, nv, seed in ((np.float64, 30000, 516, 16, 300, 1), (np.float
     m = CVMatrix(dtype=dtype, lazy_fit=False); m.fit(X, Y, w)
     (bx, by), st = m.training_XTX_XTY_batched(folds)
     status = m.fold_status()
+    # (the route that waits is taken when the planner gives every fold one unit; the first problem is sized so
+    #  that it does, the others may or may not -- status 0 then, and every fold must be right)
     tol = 1e-10 if dtype is np.float64 else 2e-4
     for f in list(range(0, 12)) + list(range(12, len(folds), 7)):
         (rx, ry), rst = o.training_XTX_XTY(folds[f])
         gx, gy = bx[f].double().cpu().numpy(), by[f].double().cpu().numpy()
-        if mode == 3 and f %% 3 == 0:
+        if mode == 3 and status == 1 and f %% 3 == 0:
             # the retry launch was made to give up too: every off-diagonal tile of these folds is poisoned,
             # nothing of them passes for a number
             assert np.isnan(gx).any(), f
@@ -1574,9 +1579,10 @@ for dtype, N, K, M, nv, seed in ((np.float64, 30000, 516, 16, 300, 1), (np.float
             worst = max(worst, np.abs(g_[f].double().cpu().numpy() - r_).max() / np.abs(r_).max())
     assert worst <= tol, (dtype, worst)
     print("status", status)
-    if mode == 1: assert status == 2, status
+    first = seed in (1, 4)
+    if mode == 1: assert status == 2 if first else status in (0, 2), status
     if mode == 2: assert status in (0, 2), status
-    if mode == 3: assert status == 1, status
+    if mode == 3: assert status == 1 if first else status in (0, 1), status
 print("timeouts handled ok")
 """
 
@@ -1595,7 +1601,7 @@ def test_a_flag_wait_that_gives_up_is_recomputed_and_reported(mode):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _FUSED_TIMEOUT_CODE % {"root": root, "mode": mode}
-    env = dict(os.environ, CVM_FUSED_TEST_TIMEOUT=str(mode))
+    env = dict(os.environ, CVM_FUSED_TEST_TIMEOUT=str(mode), CVM_MID_INK="1")     # (mid_tile_kernel's hand-off too)
     env.pop("CVM_FORCE_SPLITS", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
