@@ -19,6 +19,10 @@ SHAPES = [
     ("C3", 100000, 512, 16, 10, np.float64),
     ("C4 scaled (N / 4, 16 folds)", 250000, 1024, 32, 16, np.float64),
     ("C5 scaled (N / 4, 5 folds)", 50000, 4096, 1, 5, np.float32),
+    # the slowest rank's share of C3 at 8 / 4 / 2 GPUs (2 / 3 / 5 of the ten folds): the multi-GPU step's Gram launch
+    ("C3r8 (2 folds: a rank of 8)", 20000, 512, 16, 2, np.float64),
+    ("C3r4 (3 folds: a rank of 4)", 30000, 512, 16, 3, np.float64),
+    ("C3r2 (5 folds: a rank of 2)", 50000, 512, 16, 5, np.float64),
 ]
 
 
@@ -69,7 +73,7 @@ def test_the_planners_plan_is_within_five_percent_of_its_neighbours(name, N, K, 
     assert lib.cvm_plan_fold(P, (N + P - 1) // P, K, M, cdt, 0x3F, 1 << 40, info) == 0
     so, sd = int(info[0]), int(info[6])
     cand = [(so, sd)]
-    for dso, dsd in ((-1, 0), (1, 0), (0, -1), (0, 1), (1, 1), (-1, -1), (2, 2)):
+    for dso, dsd in ((-1, 0), (1, 0), (0, -1), (0, 1), (1, 1), (-1, -1), (2, 2), (-2, -2), (3, 3), (2, 0), (0, 2)):
         c = (so + dso, sd + dsd)
         if c[0] >= 1 and c[1] >= 1 and c not in cand:
             cand.append(c)
