@@ -116,6 +116,7 @@ def test_weights_are_validated_again_when_a_new_tensor_reuses_the_address(amd, h
         del w2
     # by default every fit reads its inputs again, like the reference (cvmatrix.py:207-328) ...
     w = torch.rand(N, dtype=torch.float64, device=hip_device)
+    m = amd.CVMatrix(copy=True, serve_loops=True)
     m.fit(X, None, w)
     host = m._w_host
     m.fit(X, None, w)
@@ -156,7 +157,7 @@ def test_writes_behind_torchs_back_are_seen_unless_the_caller_vouches_for_the_te
         with pytest.raises(ValueError, match="Weights must be non-negative."):
             m.fit(X, None, w)
         w.data[5] = 0.5
-        t = amd.CVMatrix(copy=True, lazy_fit=lazy, trust_tensor_versions=True)
+        t = amd.CVMatrix(copy=True, lazy_fit=lazy, trust_tensor_versions=True, serve_loops=True)
         t.fit(X, None, w)
         g1 = t.XTX.clone()
         X.data.mul_(2.0)

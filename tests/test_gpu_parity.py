@@ -1602,7 +1602,10 @@ def test_a_flag_wait_that_gives_up_is_recomputed_and_reported(mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _FUSED_TIMEOUT_CODE % {"root": root, "mode": mode}
     env = dict(os.environ, CVM_FUSED_TEST_TIMEOUT=str(mode), CVM_MID_INK="1")     # (mid_tile_kernel's hand-off too)
-    env.pop("CVM_FORCE_SPLITS", None)
+    # (the test is about the routes that wait: a switch of tools/route_matrix.sh that takes the call elsewhere is lifted)
+    for k in ("CVM_FORCE_SPLITS", "CVM_NO_FUSED", "CVM_FORCE_FALLBACK", "CVM_FUSED_PREPASS", "CVM_MID_OWNSTATS", "CVM_MID_TILE",
+              "CVM_MID_MINN", "CVM_MID_MAXN"):
+        env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     assert "timeouts handled ok" in r.stdout

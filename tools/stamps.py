@@ -5,11 +5,13 @@ import cvmatrix_amd._lib as L
 L.LIB_PATH = sys.argv[1]
 from cvmatrix_amd import CVMatrix, Partitioner
 rng = np.random.default_rng(42)
-N, K, M, P = 100000, 512, 16, int(os.environ.get("STAMP_P", "10"))
-X, Y, w = rng.random((N, K)), rng.random((N, M)), rng.random(N)
-import os
+# (STAMP_N / _K / _M / _P / _DTYPE: other shapes -- e.g. the scaled C5: STAMP_N=50000 STAMP_K=4096 STAMP_M=1 STAMP_P=5 STAMP_DTYPE=f32)
+N, K, M, P = (int(os.environ.get("STAMP_N", "100000")), int(os.environ.get("STAMP_K", "512")), int(os.environ.get("STAMP_M", "16")),
+              int(os.environ.get("STAMP_P", "10")))
+dt = np.float32 if os.environ.get("STAMP_DTYPE", "f64") == "f32" else np.float64
+X, Y, w = rng.random((N, K), dtype=dt), rng.random((N, M), dtype=dt), rng.random(N, dtype=dt)
 if os.environ.get("UNWEIGHTED"): w = None
-m = CVMatrix(lazy_fit=False); m.fit(X, Y, w)
+m = CVMatrix(dtype=dt, lazy_fit=False); m.fit(X, Y, w)
 b = m.prepare_folds(Partitioner(np.arange(N) % P))
 for _ in range(3): m.training_XTX_XTY_batched(b)
 L.load().cvm_timing_enable(1)
