@@ -46,7 +46,9 @@ python3 tools/bench_foldsizes.py > $D/fold_size_sweep.txt 2>/dev/null
 # mid-size folds (P = 1000) under the counters: mid_tile_kernel behind the statistics pre-pass
 FOLD_PS=1000 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/mid_fetch -- python3 $ROOT/tools/bench_foldsizes.py > /dev/null 2>&1
 FOLD_PS=1000 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/mid_write -- python3 $ROOT/tools/bench_foldsizes.py > /dev/null 2>&1
-mkdir -p $O/midpmc; mv $O/mid_fetch $O/midpmc/pmc_fetch; mv $O/mid_write $O/midpmc/pmc_write
+# (round 5: LDS bank conflicts against all LDS cycles, matrix-core busy cycles, for P = 1000 -- mid_tile_kernel -- and P = 300 -- the fused route)
+FOLD_PS=1000,300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mid_sq -- python3 $ROOT/tools/bench_foldsizes.py > /dev/null 2>&1
+mkdir -p $O/midpmc; mv $O/mid_fetch $O/midpmc/pmc_fetch; mv $O/mid_write $O/midpmc/pmc_write; mv $O/mid_sq $O/midpmc/pmc_sq
 mkdir -p $D/mid_tmp; python3 $ROOT/tools/summarize_rocprof.py $O/midpmc $D/mid_tmp > /dev/null; mv $D/mid_tmp/pmc_summary.json $D/midsize_P1000_pmc_summary.json; rm -rf $D/mid_tmp
 python3 tools/emulate_scaling.py --workloads C3 --out $D/emulated_scaling_C3 > $O/emu_C3.log 2>&1; python3 tools/emulate_scaling.py --workloads C4 --comm-us 0,60 --out $D/emulated_scaling_C4 > $O/emu_C4.log 2>&1
 rm -f $D/benchmark_protocol_hip.csv; python3 tools/benchmark_protocol.py --csv $D/benchmark_protocol_hip.csv > $D/benchmark_protocol.log 2>&1
