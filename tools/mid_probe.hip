@@ -35,6 +35,7 @@ namespace {
 #include "../cvmatrix_amd/csrc/small_tile.hpp"
 #include "../cvmatrix_amd/csrc/mid_tile.hpp"
 #include "experiments/mid_chain.hpp"
+#include "experiments/mid128.hpp"
 }  // namespace
 
 #define CK(x)                                                                          \
@@ -43,6 +44,10 @@ namespace {
     if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); }  \
   } while (0)
 
+__global__ void symmetrize(double *G, int K) {       // (the library's G is exactly symmetric: the kernels rely on it)
+  const int i = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+  if (j < K && j > i) G[(size_t)j * K + i] = G[(size_t)i * K + j];
+}
 __global__ void fill_rand(double *p, size_t n, unsigned seed, double lo, double hi) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -75,6 +80,7 @@ int main(int argc, char **argv) {
   fill_rand<<<256, 256>>>(Y, (size_t)N * M, 2, 0.0, 1.0);
   fill_rand<<<64, 256>>>(w, (size_t)N, 3, 0.1, 1.0);
   fill_rand<<<256, 256>>>(G, (size_t)K * K, 4, 0.0, 1.0);
+  symmetrize<<<dim3(K, (K + 255) / 256), 256>>>(G, K);
   fill_rand<<<64, 256>>>(H, (size_t)K * M, 5, 0.0, 1.0);
   fill_rand<<<256, 256>>>(fst, (size_t)P * fl, 6, 0.5, 1.5);
   std::vector<int64_t> hidx((size_t)P * n), hoffs(P + 1);
@@ -179,7 +185,60 @@ int main(int argc, char **argv) {
   CK(hipMemcpy(rX, oX, (size_t)P * K * K * 8, hipMemcpyDeviceToDevice));
   CK(hipMemcpy(rY, oY, (size_t)P * K * M * 8, hipMemcpyDeviceToDevice));
   std::vector<double> h0((size_t)4 * K * K), h1((size_t)4 * K * K);
-  for (int chmax : {1, 2, 3, 4, 8}) {
+  // ---- mid128_kernel: 128 x 128 items, eight computing waves, two workgroups per CU -----------------------------------
+  {
+    MidArgs c = m;
+    c.nt = (K + 127) / 128;
+    c.ipf = c.nt * (c.nt + 1) / 2;
+    c.n_items = (long long)P * c.ipf; c.per_xcd = (c.n_items + 7) / 8;
+    const dim3 cg((unsigned)(c.per_xcd * 8));
+    CK(hipFuncSetAttribute((const void *)mid128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M128_LDS_BYTES));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)mid128_kernel<true>, M128_THREADS, M128_LDS_BYTES));
+    printf("mid128: %zu bytes of LDS, %d workgroups per CU by the occupancy API, %d items per fold\n", (size_t)M128_LDS_BYTES, occ, c.ipf);
+    auto run128 = [&](int dbg, const char *label) {
+      c.dbg = dbg;
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((mid128_kernel<true>), cg, dim3(M128_THREADS), M128_LDS_BYTES, 0, c);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((mid128_kernel<true>), cg, dim3(M128_THREADS), M128_LDS_BYTES, 0, c);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("mid128 dbg=%2d %-44s %8.4f ms\n", dbg, label, ms / reps);
+    };
+    CK(hipMemset(oX, 0xff, (size_t)P * K * K * 8)); CK(hipMemset(oY, 0xff, (size_t)P * K * M * 8));
+    run128(0, "as built");
+    {
+      size_t bad = 0, tot = 0;
+      const int fl[4] = {0, P / 2, P - 2, P - 1};
+      for (int k = 0; k < 4; ++k) {
+        CK(hipMemcpy(h0.data() + (size_t)k * K * K, rX + (size_t)fl[k] * K * K, (size_t)K * K * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h1.data() + (size_t)k * K * K, oX + (size_t)fl[k] * K * K, (size_t)K * K * 8, hipMemcpyDeviceToHost));
+      }
+      size_t first = (size_t)-1;
+      for (size_t i = 0; i < h0.size(); ++i) { ++tot; if (memcmp(&h0[i], &h1[i], 8)) { if (first == (size_t)-1) first = i; ++bad; } }
+      std::vector<double> y0((size_t)P * K * M), y1((size_t)P * K * M);
+      CK(hipMemcpy(y0.data(), rY, y0.size() * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(y1.data(), oY, y1.size() * 8, hipMemcpyDeviceToHost));
+      size_t bady = 0;
+      for (size_t i = 0; i < y0.size(); ++i) if (memcmp(&y0[i], &y1[i], 8)) ++bady;
+      printf("   against mid_tile_kernel: %zu of %zu XTX elements of 4 folds differ, %zu of %zu XTY elements\n", bad, tot, bady, y0.size());
+      if (bad) {
+        const size_t e = first % ((size_t)K * K);
+        printf("   first difference: fold slot %zu row %zu col %zu: %.17g vs %.17g\n", first / ((size_t)K * K), e / K, e % K, h0[first], h1[first]);
+      }
+    }
+#ifdef CVM_MID_ABLATE
+    run128(1, "no output stores");
+    run128(3, "no stores, no G loads");
+    run128(4, "no LDS-DMA after the first stage");
+    run128(8, "no MFMA");
+    run128(16, "loops only");
+#endif
+  }
+  for (int chmax : {1, 3}) {
     MidArgs c = m;
     c.chmax = chmax;
     c.ipf = chain_items_per_fold(c.nt, chmax);
