@@ -101,6 +101,7 @@ int main(int argc, char **argv) {
   m.nt = (K + 63) / 64; m.n_xtx = m.nt * (m.nt + 1) / 2; m.yextra = 0; m.ipf = m.n_xtx;
   m.n_items = (long long)P * m.ipf; m.per_xcd = (m.n_items + 7) / 8;
   m.maxn = (n + 15) / 16 * 16;
+  m.nb = P;
   const size_t lds = mid_lds_bytes<double>(m.maxn);
   const dim3 grid((unsigned)(m.per_xcd * 8));
   hipEvent_t e0, e1;
@@ -151,6 +152,14 @@ int main(int argc, char **argv) {
   for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((mid_tile_kernel<double, true>), grid, dim3(MID_THREADS), lds, 0, m);
   CK(hipDeviceSynchronize());
   run(0, "as shipped", true);
+#ifdef CVM_MID_PROLOGUE_ABL
+  run(32, "row numbers computed, not loaded", true);
+  run(96, "+ no statistics loads", true);
+  run(224, "+ no weight gather", true);
+  run(226, "+ no G loads", true);
+  run(0, "as shipped (again)", true);
+  return 0;
+#endif
   run(1, "no output stores", false);
   run(2, "no G loads", false);
   run(3, "no stores, no G loads", false);
