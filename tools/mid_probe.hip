@@ -152,7 +152,7 @@ int main(int argc, char **argv) {
   for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((mid_tile_kernel<double, true>), grid, dim3(MID_THREADS), lds, 0, m);
   CK(hipDeviceSynchronize());
   run(0, "as shipped", true);
-#ifdef CVM_MID_PROLOGUE_ABL
+#ifdef CVM_MID_PROLOGUE_ABL   // (with tools/experiments/mid_prologue_ablation.patch applied to mid_tile.hpp: bits 32 / 64 / 128)
   run(32, "row numbers computed, not loaded", true);
   run(96, "+ no statistics loads", true);
   run(224, "+ no weight gather", true);
