@@ -1,7 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5z
-o=gpurun_out/r5z/prologue.txt
-for P in 1000 3000 300; do
-  timeout 300 tools/mid_probe_p2 $P 512 100000 10 >> $o 2>&1
-done
+o=gpurun_out/r5z/routes.txt
+export FOLD_PS=100,125,150,200,250,300,400,500,700,1000
+echo "##### default" >> $o; timeout 600 python tools/bench_foldsizes.py 2>&1 | grep "P=" >> $o
+echo "##### CVM_MID_MAXN=1100" >> $o; CVM_MID_MAXN=1100 timeout 600 python tools/bench_foldsizes.py 2>&1 | grep "P=" >> $o
+echo "##### CVM_MID_MAXN=1100 CVM_MID_INK=1" >> $o; CVM_MID_MAXN=1100 CVM_MID_INK=1 timeout 600 python tools/bench_foldsizes.py 2>&1 | grep "P=" >> $o
 cat $o
