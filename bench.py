@@ -42,8 +42,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from fp32_gate import fp32_bound  # noqa: E402  (the float32 parity gate's one definition: tests/fp32_gate.py)
+from cvmatrix_amd.fp32_gate import fp32_bound  # noqa: E402  (the float32 accuracy contract's one definition)
 
 WORKLOADS = {
     # name: (N, K, M, P, weighted, flags, dtype)
@@ -247,6 +246,25 @@ def measure_hbm_traffic(workload, path):
         shutil.rmtree(base, ignore_errors=True)
 
 
+def self_launch(n_ranks):
+    """Start `torch.distributed.run` with one rank per GPU as a child process, on a free port of the
+    loopback interface; the ranks re-enter this script with WORLD_SIZE set.  Returns the child's exit
+    code.  (The parent must not have initialised the GPU: it has not imported torch.)"""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +315,13 @@ def main():
                          "~1 min); the figure of profiles/hbm_traffic.json is reported instead")
     args = ap.parse_args()
 
+    # `python3 bench.py --gpus N` (N > 1) without a launcher: start the ranks ourselves, the way the reference's
+    # harness is one command (benchmarks/benchmark.py:293-308).  This process never touches the GPU -- torch is
+    # not even imported yet -- it starts torch.distributed.run as a CHILD, lets rank 0's JSON line through and
+    # leaves with the child's exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_world:
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -307,9 +332,8 @@ def main():
     if emu and world > 1:
         sys.exit("--emulate-world runs in ONE process (no torch.distributed.run)")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                     "(one rank per GPU)")
+        sys.exit(f"bench.py --gpus {args.gpus} was started as one of {world} ranks: the launcher's "
+                 "--nproc-per-node and --gpus must agree")
     # one rank per GPU.  (CVM_DIST_BACKEND=gloo lets several ranks share one GPU: used only
     # to exercise the N>1 code path on a 1-GPU box.)
     backend = os.environ.get("CVM_DIST_BACKEND", "nccl")
@@ -753,7 +777,7 @@ def main():
                 elif len(errs) > 4:
                     # float32: at most 2x the error the reference's algorithm
                     # makes in plain float32 on the same problem (measured here, fp32_algorithm_error)
-                    bound, bound_y = fp32_bound(errs[4]), fp32_bound(errs[5])      # (+ two float32 roundings: tests/fp32_gate.py)
+                    bound, bound_y = fp32_bound(errs[4]), fp32_bound(errs[5])      # (+ two float32 roundings: cvmatrix_amd/fp32_gate.py)
                 else:
                     bound = bound_y = 1e-3              # (several ranks: SURVEY 8d's fixed allowance)
                 good = errs[0] <= bound and errs[1] <= bound_y and all(e <= max(bound, 1e-10) for e in errs[2:4])

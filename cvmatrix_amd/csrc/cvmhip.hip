@@ -375,6 +375,15 @@ int cvm_timing_read_kinds(double *ms4, int64_t *n4) {
   return timing_collect(ms4, n4);
 }
 
+int cvm_clock_probe(void *device_buf, size_t bytes) {
+  if (device_buf && ((uintptr_t)device_buf % 8 || bytes < 32)) return fail(CVM_EINVAL, "cvm_clock_probe: an 8-byte aligned buffer of at least 32 bytes%s");
+  const size_t wgs = device_buf ? bytes / 32 : 0;
+  g_clock_buf.store(nullptr, std::memory_order_release);
+  g_clock_wgs.store((int)(wgs > 65536 ? 65536 : wgs), std::memory_order_relaxed);
+  g_clock_buf.store((unsigned long long *)device_buf, std::memory_order_release);
+  return CVM_OK;
+}
+
 int cvm_fill_probe(void *buf, size_t bytes, void *stream) {
   if (!buf || bytes % 16 || (uintptr_t)buf % 16) return fail(CVM_EINVAL, "cvm_fill_probe: 16-byte pieces%s");
   const size_t pieces = bytes / 16;

@@ -141,6 +141,13 @@ template <typename T> struct WgramArgs {
   double *out_fold;
   int dbg;              // diagnostic ablations (env CVM_DEBUG): 1 no global loads after the
                         // first stage, 2 no MFMA, 4 no VALU column sums; results are wrong
+  // clock probe of the PRODUCT kernel (cvm_clock_probe; nullptr = off, the default): workgroup b < clock_wgs stores
+  // {s_memtime, s_memrealtime} once when it starts and once when it has run out of work items -- two scalar clock
+  // reads per workgroup LIFETIME, nothing inside the item loop -- so that the shader clock the chip holds under
+  // this very kernel is (d memtime / d memrealtime) x 100 MHz.  The buffer is the caller's and nothing else in the
+  // library reads it.
+  unsigned long long *clock_stamps;
+  int clock_wgs;
 };
 
 template <typename T> __device__ __forceinline__ T *unit_tiles(char *ws, const Geom &g, long u) {

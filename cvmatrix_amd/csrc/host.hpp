@@ -46,6 +46,12 @@ inline TimedLaunch *timed_begin(int kind, hipStream_t st) {
 inline void timed_end(TimedLaunch *tl, hipStream_t st) { if (tl) (void)hipEventRecord(tl->b, st); }
 enum { KIND_FIT = 0, KIND_FOLD = 1 };
 
+// ---- optional clock probe of the product Gram kernel (cvm_clock_probe) -------------------
+// A caller-owned device buffer; while one is set every LDS-DMA Gram launch of the process hands it to the
+// kernel (WgramArgs::clock_stamps).  Two words, read together by the launcher.
+std::atomic<unsigned long long *> g_clock_buf{nullptr};
+std::atomic<int> g_clock_wgs{0};
+
 // once-per-device flags of hipFuncSetAttribute: a bit mask updated atomically (setting the
 // attribute twice from two racing threads is harmless, a torn read-modify-write is not)
 inline bool attr_needed(std::atomic<unsigned long long> &done, int dev) {
@@ -427,6 +433,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     return fail(CVM_EINVAL, "launch_wgram: fused epilogue needs the LDS-DMA kernel%s");
   if (fast) {
     (void)queue;
+    args.clock_stamps = g_clock_buf.load(std::memory_order_acquire);
+    args.clock_wgs = args.clock_stamps ? g_clock_wgs.load(std::memory_order_relaxed) : 0;
     args.queue = acquire_queue(dev, st);
     if (!args.queue) return fail(CVM_ELAUNCH, "launch_wgram: no work-queue block (allocation failed, or 1024 streams with Gram launches in flight at once)%s");
     // persistent workgroups: as many as the device keeps resident at once -- one per CU by the kernel's LDS,

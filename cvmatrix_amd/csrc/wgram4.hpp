@@ -1367,6 +1367,12 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     }
     fx = -1; fq = 0;
   };
+  // clock probe (off unless cvm_clock_probe handed a buffer): the workgroup's first clock pair
+  const bool clk = a.clock_stamps && threadIdx.x == 0 && (int)blockIdx.x < a.clock_wgs;
+  if (clk) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), q0 = __builtin_amdgcn_s_memrealtime();
+    a.clock_stamps[4 * blockIdx.x + 0] = c0; a.clock_stamps[4 * blockIdx.x + 1] = q0;
+  }
   int probe = 0;                                 // lists already found empty (kept by the fetching thread)
   if (threadIdx.x == 4 * 64) {
     int fx, fq;
@@ -1392,6 +1398,10 @@ __global__ __launch_bounds__(NT4, 2) void wgram4_kernel(const WgramArgs<T> a) {
     // stores need not be acknowledged before the next item's loaders start (a __syncthreads() here
     // made every wave wait for them -- several microseconds per item with stores streaming to HBM)
     lds_barrier();
+  }
+  if (clk) {                                     // ... and its second, behind its last item (its stores may still be in flight)
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
+    a.clock_stamps[4 * blockIdx.x + 2] = c1; a.clock_stamps[4 * blockIdx.x + 3] = q1;
   }
   // the queue block is the library's (host.hpp: queue pool) and must be all zero again for its
   // next launch: the last workgroup to leave -- every other one has made its last fetch -- clears it

@@ -1,4 +1,4 @@
-"""The float32 parity gate in one place (tests/test_gpu_parity.py, tools/fuzz_all.py, bench.py).
+"""The float32 accuracy contract of the library in one place (imported by tests/test_gpu_parity.py, tools/fuzz_all.py, bench.py).
 
 BASELINE.md section 4: a float32 result may be off from the float64 reference by at most TWICE the error the
 reference's own algorithm makes in NumPy float32 on the same inputs (the "yardstick").  Result and yardstick

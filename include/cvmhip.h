@@ -272,6 +272,20 @@ int cvm_timing_read_kinds(double *ms4, int64_t *n4);
  * (`frac_of_fill` next to `frac`).  No reference counterpart: the reference has no device. */
 int cvm_fill_probe(void *buf, size_t bytes, void *stream);
 
+/* Benchmark support: the shader clock the chip holds UNDER the product's LDS-DMA Gram kernel (the kernel of
+ * cvm_gram_fit / cvm_sweep_* / cvm_fold_update), read inside the shipped kernel itself.  While a caller-owned
+ * device buffer is set (8-byte aligned; NULL switches the probe off, the default), every such launch of the
+ * process makes workgroup b < bytes / 32 store four 64-bit words at buf + 32 b:
+ *   [0] s_memtime, [1] s_memrealtime when the workgroup starts;  [2], [3] the same pair when it has run out of
+ *   work items
+ * -- two scalar clock reads per workgroup lifetime, nothing inside the item loop; results are unchanged.
+ * ([2] - [0]) / ([3] - [1]) x 100 MHz is the average shader clock over that workgroup's life (s_memrealtime
+ * ticks at 100 MHz whatever the chip does; MI355X_MICROARCH.md "DVFS give-back" item 6), ([3] - [1]) its
+ * duration in 10 ns units.  bench.py reports the median over the workgroups of the last timed launch as
+ * roofline.effective_clock_mhz.  The caller synchronises before it reads the buffer, and clears the probe
+ * before it frees it.  No reference counterpart: the reference has no device. */
+int cvm_clock_probe(void *device_buf, size_t bytes);
+
 /* Introspection for benchmarks/profiles: geometry chosen for a problem (info: int64[8]).
  * info[0]=row splits per fold of the off-diagonal 128x128 tiles, [6]=row splits of the diagonal
  * tiles (which also produce XTY and the column sums and cost less per row: the two kinds are cut

@@ -96,7 +96,7 @@ def test_g3_leave_one_out_sweep(amd, chunk):
 # unweighted, uncentred XTY of a 6000-row fold at K=640, M=70 -- the MFMA accumulates a row split in
 # float32 where OpenBLAS blocks its sums), so the allowance is eight.  The 2e-5 / 2e-6 floors of
 # rounds 1-2 were never needed.
-from fp32_gate import FP32_EPS, fp32_floor  # noqa: E402  (the gate's one definition: tests/fp32_gate.py)
+from cvmatrix_amd.fp32_gate import FP32_EPS, fp32_floor  # noqa: E402  (the gate's one definition: cvmatrix_amd/fp32_gate.py)
 # Round 4: the float32 Gram kernels fold their accumulators into a second set every 1024 rows (FOLD_STAGES * 16; two-level
 # sums, like the blocked sgemm of the reference's BLAS), whatever the row-split plan: the allowance on top
 # of twice the yardstick is back to two roundings (result and yardstick are both float32 arrays: where the
@@ -1331,6 +1331,34 @@ def test_bench_command_two_ranks_strong_scaling(amd, mode, path):
     assert line2["scaling_ceiling_vs_1gpu"] == 2.0 and line1["scaling_ceiling_vs_1gpu"] == 1.0
 
 
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with NO launcher in front -- the form the driver uses for `--gpus 1` -- starts
+    `torch.distributed.run` itself as a child process (the parent never touches the GPU), relays rank 0's one JSON
+    line and leaves with the child's exit code (the reference's harness is one command too,
+    benchmarks/benchmark.py:293-308).  Two ranks on cuda:0 over gloo here; RCCL on a multi-GPU node."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(CVM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "4000", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["parity"].startswith("ok"), line
+    # a launcher whose rank count disagrees with --gpus is refused, not silently run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rows", "4000", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                         cwd=root, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "must agree" in bad.stderr
+
+
 def test_multi_gpu_smoke_two_ranks_on_one_gpu():
     """``__graft_entry__.rccl_smoke`` -- what ``smoke()`` starts on a box with two GPUs, over RCCL -- run here by
     two ranks that share cuda:0 over gloo: every fold of every rank against the oracle, row-sharded (one
@@ -1746,7 +1774,7 @@ def test_mid_tile_route_shapes(amd, dtype, K, M, sizes):
 def test_randomised_routes_against_the_oracle(tool, args, env):
     """tools/fuzz_all.py / fuzz_small.py: random shapes, fold structures, element types, flags,
     weights, ddof, lazy or eager fit and call styles through every route of the fold stage,
-    against the oracle (float64 1e-10; float32 twice the oracle's own float32 error + two roundings, tests/fp32_gate.py)."""
+    against the oracle (float64 1e-10; float32 twice the oracle's own float32 error + two roundings, cvmatrix_amd/fp32_gate.py)."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

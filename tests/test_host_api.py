@@ -319,3 +319,35 @@ def test_periodic_labels_take_the_formula_and_build_the_same_dict():
         with pytest.raises(ValueError, match="Fold nope not found."):
             p.get_validation_indices("nope")
     assert took >= 8          # the periodic ones did take the formula
+
+
+def test_plain_bench_command_with_several_gpus_launches_its_own_ranks(monkeypatch):
+    """`python3 bench.py --gpus N` (no launcher, the form the driver uses at N = 1): the parent builds a
+    `torch.distributed.run` command with one rank per GPU on a free loopback port and returns the child's exit code,
+    before torch is imported in the parent (nothing there may touch the GPU)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-5] == os.path.join(root, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

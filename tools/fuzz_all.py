@@ -10,7 +10,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from fp32_gate import fp32_bound      # the float32 gate's one definition
+from cvmatrix_amd.fp32_gate import fp32_bound      # the float32 gate's one definition
 from cvmatrix_amd import CVMatrix, Partitioner
 from oracle.cvmatrix_oracle import OracleCVMatrix
 

@@ -17,7 +17,7 @@ for e in "CVM_FORCE_SPLITS=3,5" "CVM_FORCE_SPLITS=7,2" "CVM_NO_FUSED=1" "CVM_FOR
   # (with loop serving off, the tests that look INSIDE the serving have nothing to see: they carry the
   #  `serving` marker.  The float32 cases run under the forced split plans too, no case deselected: the gate's
   #  allowance is derived from the plan in effect -- one float32 rounding per partial a forced plan adds to a
-  #  tile's ordered sum, tests/fp32_gate.py.)
+  #  tile's ordered sum, cvmatrix_amd/fp32_gate.py.)
   case "$e" in
     CVM_SERVE_LOOPS=0) mark="gpu and not serving" ;;
   esac
