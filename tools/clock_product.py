@@ -134,6 +134,9 @@ def run(name, seconds):
     k = 0 if kind == "fit" else 1
     gram_ms = ms4[k] / max(n4[k], 1)
     pr = read_probe(probe)
+    if RAW_DIR:
+        os.makedirs(RAW_DIR, exist_ok=True)
+        np.save(os.path.join(RAW_DIR, f"stamps_{name}.npy"), probe.cpu().numpy().reshape(-1, 4))
     rows = float(N)
     flops = rows * (K * (K + 1) + 2.0 * K * M)
     tf = flops / (gram_ms * 1e-3) / 1e12
@@ -154,8 +157,13 @@ def run(name, seconds):
     return out
 
 
+RAW_DIR = None
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--raw" in sys.argv:
+        RAW_DIR = sys.argv[sys.argv.index("--raw") + 1]
+        args = [a for a in args if a != RAW_DIR]
     secs = 3.0
     if "--seconds" in sys.argv:
         secs = float(sys.argv[sys.argv.index("--seconds") + 1])
