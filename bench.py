@@ -246,6 +246,24 @@ def measure_hbm_traffic(workload, path):
         shutil.rmtree(base, ignore_errors=True)
 
 
+def clock_probe_summary(stamps):
+    """cvm_clock_probe's buffer -> shader clock and workgroup lifetimes of the last probed launch.  Per workgroup
+    [s_memtime, s_memrealtime] at its start and when it ran out of work; s_memrealtime ticks at 100 MHz."""
+    s = np.asarray(stamps).astype(np.uint64).reshape(-1, 4)
+    s = s[(s[:, 1] > 0) & (s[:, 3] > s[:, 1])]
+    if not len(s):
+        return None
+    dc = (s[:, 2] - s[:, 0]).astype(np.float64)
+    dq = (s[:, 3] - s[:, 1]).astype(np.float64)
+    mhz = dc / dq * 100.0
+    span = float(s[:, 3].max() - s[:, 1].min())
+    return {"effective_clock_mhz": round(float(np.median(mhz)), 1),
+            "clock_mhz_min_max_over_workgroups": [round(float(mhz.min()), 1), round(float(mhz.max()), 1)],
+            "workgroups": int(len(s)), "workgroup_life_us_mean": round(float(dq.mean()) / 100.0, 1),
+            "workgroup_life_us_max": round(float(dq.max()) / 100.0, 1), "launch_span_us": round(span / 100.0, 1),
+            "cu_time_used": round(float(dq.sum() / (len(s) * span)), 4)}
+
+
 def self_launch(n_ranks):
     """Start `torch.distributed.run` with one rank per GPU as a child process, on a free port of the
     loopback interface; the ranks re-enter this script with WORLD_SIZE set.  Returns the child's exit
@@ -466,11 +484,18 @@ def main():
         out = step()
     fence()
     lib.cvm_timing_enable(1)
+    # the clock the chip holds under the Gram kernel, read by the kernel itself (cvm_clock_probe: two scalar clock
+    # pairs per workgroup lifetime, nothing inside the item loop; every launch overwrites the buffer, what is read
+    # after the timed region are the stamps of its LAST Gram launch)
+    clock_buf = torch.zeros(1024 * 4, dtype=torch.int64, device=dev)
+    lib.cvm_clock_probe(C.c_void_p(clock_buf.data_ptr()), C.c_size_t(clock_buf.numel() * 8))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     t1 = time.perf_counter()
+    lib.cvm_clock_probe(None, C.c_size_t(0))
+    clock = clock_probe_summary(clock_buf.cpu().numpy())
     ms_fit, ms_fold = C.c_double(), C.c_double()
     n_fit, n_fold = C.c_int64(), C.c_int64()
     lib.cvm_timing_read(C.byref(ms_fit), C.byref(n_fit), C.byref(ms_fold), C.byref(n_fold))
@@ -723,6 +748,29 @@ def main():
                "ms_per_step": round(alt_ms, 4), "folds_per_s": round(total_folds_per_step / (alt_ms * 1e-3), 1),
                "host_ms": breakdown(am, ab, reps=10)["host_ms"]}
         del am, ab, ast_
+    # the same step through the API AS THE REFERENCE SPELLS IT (cvmatrix/cvmatrix.py:157-167: every optional
+    # argument at its default; only the workload's own flags / dtype are passed), on the same resident tensors:
+    # copy=True (private device copies of X, Y, weights at every fit), lazy fit, fresh result tensors every call,
+    # the weights validated on every fit (on the device: no read-back, no host wait) -- and the same with
+    # copy=False (inputs aliased; fit() is then eager like the reference's, two Gram launches per step) and with
+    # copy=False + lazy_fit=True (one sweep).  None of them uses trust_tensor_versions / reuse_outputs.
+    api = None
+    if not ho and world == 1 and not emu and n_mine:
+        api = {"what": "fit + one batched training_XTX_XTY per step on the resident tensors, timed like other_output_policy; "
+                       "no trust_tensor_versions, no reuse_outputs: every fit re-validates its inputs"}
+        for label, kw in (("CVMatrix()", {}), ("CVMatrix(copy=False)", {"copy": False}),
+                          ("CVMatrix(copy=False, lazy_fit=True)", {"copy": False, "lazy_fit": True})):
+            dm = CVMatrix(*flags, ddof=1, dtype=dtype, **kw)
+            dm.fit(Xd, Yd, wd)
+            db_ = dm.prepare_folds(fold_lists)
+            dst = step_of(dm, db_)
+            for _ in range(40 if args.workload in ("C2", "C3") else 2):
+                dst()
+            d_ms = timed(dst, reps=100 if args.workload in ("C2", "C3") else 5)
+            api[label] = {"ms_per_step": round(d_ms, 4), "folds_per_s": round(total_folds_per_step / (d_ms * 1e-3), 1),
+                          "host_ms": breakdown(dm, db_, reps=10)["host_ms"]}
+            del dm, db_, dst
+        torch.cuda.empty_cache()
     # per-rank breakdown of the timed step and the pipelined figure (every rank: both contain the exchange)
     bd = pipe = None
     if not ho or args.with_breakdown:
@@ -858,6 +906,15 @@ def main():
             "algorithmic_hbm_bytes_per_launch": b_alg,
             "hbm_frac_if_bytes_bound": round(b_alg / (gram_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if gram_ms > 0 else None,
         }
+        if clock:
+            # (the peak is quoted at the nominal 2400 MHz; what the silicon gave this launch is peak x clock / 2400)
+            roofline.update(clock)
+            roofline["frac_of_clock_adjusted_peak"] = round(achieved / (peak * clock["effective_clock_mhz"] / 2400.0), 4)
+            roofline["clock_source"] = ("cvm_clock_probe: s_memtime / s_memrealtime x 100 MHz around each workgroup's life in the "
+                                        "LAST timed launch of the product kernel, median over its workgroups (calibration: "
+                                        "tools/mfma_peak.hip reads 64.00 / 32.00 cycles per float64 / float32 MFMA with the same "
+                                        "stamps; profiles/r6/mfma_peak_clock_calibration.txt); cu_time_used = sum of workgroup "
+                                        "lifetimes / (workgroups x launch span)")
         roofline = {k: (None if isinstance(v, float) and v != v else v) for k, v in roofline.items()}
 
         # the reference's whole benchmark protocol (benchmarks/benchmark.py:101-158, 293-308):
@@ -1076,7 +1133,10 @@ def main():
                                    "ms_per_step": j_["ms_per_step"], "folds_per_s": j_["value"],
                                    "gram_avg_launch_ms": rf_["avg_launch_ms"], "gram_launches_timed": rf_["launches_timed"],
                                    "gram_flops_per_launch": rf_["flops_per_launch"], "achieved_TFLOPs": rf_["achieved"],
-                                   "peak_TFLOPs": rf_["peak"], "frac": rf_["frac"], "parity": j_["parity"],
+                                   "peak_TFLOPs": rf_["peak"], "frac": rf_["frac"],
+                                   "effective_clock_mhz": rf_.get("effective_clock_mhz"),
+                                   "frac_of_clock_adjusted_peak": rf_.get("frac_of_clock_adjusted_peak"),
+                                   "cu_time_used": rf_.get("cu_time_used"), "parity": j_["parity"],
                                    "wall_s": round(time.perf_counter() - a_, 1)}
                 elif wl_ not in others:
                     others[wl_] = {"error": f"rc={r_.returncode}: {(r_.stderr or '')[-300:]}"}
@@ -1170,7 +1230,7 @@ def main():
             "per_fold_call_identical_to_batched": per_fold_same,
             "per_fold_call_two_stage_folds_per_s": round(total_folds_per_step / (loop2_ms * 1e-3), 1),
             "reference_protocol": proto,
-            "step_breakdown": bd, "other_output_policy": alt, "pipelined": pipe,
+            "step_breakdown": bd, "other_output_policy": alt, "api_defaults": api, "pipelined": pipe,
             "parity": parity, "roofline": roofline, "cpu_baseline": cpu,
             "supplementary_hbm_regime": supp,
             "other_workloads": others,

@@ -24,10 +24,10 @@ IDX_HOST = 0x40
 
 EXPORTS = (
     "cvm_version", "cvm_source_hash", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
-    "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_fold_update_ex", "cvm_plan_fold",
+    "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_fold_update_ex", "cvm_plan_fold", "cvm_debug_force_splits",
     "cvm_timing_enable", "cvm_timing_read", "cvm_timing_read_kinds", "cvm_fill_probe", "cvm_clock_probe",
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds", "cvm_sweep_fold_range", "cvm_sweep_all",
-    "cvm_partition_workspace_bytes", "cvm_partition_labels", "cvm_partition_periodic",
+    "cvm_partition_workspace_bytes", "cvm_partition_labels", "cvm_partition_periodic", "cvm_weights_check",
     "cvm_pls_workspace_bytes", "cvm_pls_fit", "cvm_pls_plan",
     "cvm_pls_sse_workspace_bytes", "cvm_pls_validation_sse",
 )
@@ -102,6 +102,8 @@ def load():
     lib.cvm_partition_labels.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]
     lib.cvm_partition_periodic.restype = C.c_int
     lib.cvm_partition_periodic.argtypes = [vp, i64, i64, vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.cvm_weights_check.restype = C.c_int
+    lib.cvm_weights_check.argtypes = [vp, i64, C.c_int, vp, vp]
     lib.cvm_pls_workspace_bytes.restype = sz
     lib.cvm_pls_workspace_bytes.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cvm_pls_fit.restype = C.c_int
@@ -124,6 +126,8 @@ def load():
     lib.cvm_fill_probe.argtypes = [vp, sz, vp]
     lib.cvm_clock_probe.restype = C.c_int
     lib.cvm_clock_probe.argtypes = [vp, sz]
+    lib.cvm_debug_force_splits.restype = C.c_int
+    lib.cvm_debug_force_splits.argtypes = [C.c_int, C.c_int]
     lib.cvm_plan_fold.restype = C.c_int
     lib.cvm_plan_fold.argtypes = [i64, i64, C.c_int, C.c_int, C.c_int, u32, sz, vp]
     _lib = lib

@@ -39,7 +39,6 @@ namespace {
 #include "finalize.hpp"
 #include "colstats.hpp"
 #include "small_folds.hpp"
-#include "small_tile.hpp"
 #include "mid_tile.hpp"
 #include "host.hpp"
 #include "partition.hpp"
@@ -283,6 +282,12 @@ int cvm_partition_periodic(const int64_t *labels, int64_t N, int64_t n_labels, c
                                  (hipStream_t)stream);
 }
 
+int cvm_weights_check(const void *w, int64_t N, int dtype, int64_t *out2, void *stream) {
+  if (!out2 || N < 0 || (N > 0 && !w)) return fail(CVM_EINVAL, "cvm_weights_check: bad argument%s");
+  if (dtype != CVM_F64 && dtype != CVM_F32) return fail(CVM_EINVAL, "cvm_weights_check: dtype must be CVM_F32 or CVM_F64%s");
+  return weights_check_impl(w, N, dtype, out2, (hipStream_t)stream);
+}
+
 size_t cvm_pls_workspace_bytes(int64_t n_folds, int K, int M, int A, int dtype) {
   if (n_folds < 0 || K <= 0 || M <= 0 || M > PLS_MAXM || A <= 0 || A > PLS_MAXA) return 0;
   return pls_workspace_bytes(n_folds, K, M, A, dtype == CVM_F64 ? 8 : 4, pls_cu_count());
@@ -390,6 +395,13 @@ int cvm_fill_probe(void *buf, size_t bytes, void *stream) {
   if (!pieces) return CVM_OK;
   hipLaunchKernelGGL(fill_probe_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float *)buf, pieces);
   HIP_OK(hipGetLastError());
+  return CVM_OK;
+}
+
+int cvm_debug_force_splits(int s_off, int s_diag) {
+  if (s_off == 0 && s_diag == 0) { g_force_splits.store(0, std::memory_order_relaxed); return CVM_OK; }
+  if (s_off < 1 || s_diag < 1 || s_off > 65535 || s_diag > 65535) return fail(CVM_EINVAL, "cvm_debug_force_splits: 1 <= splits <= 65535, or 0, 0%s");
+  g_force_splits.store(((unsigned)s_off << 16) | (unsigned)s_diag, std::memory_order_relaxed);
   return CVM_OK;
 }
 

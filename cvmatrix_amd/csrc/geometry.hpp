@@ -323,3 +323,22 @@ __device__ __forceinline__ void split_range(int64_t n, int splits, int sp, int64
   r0 = (int64_t)sp * per; if (r0 > n) r0 = n;
   r1 = r0 + per; if (r1 > n) r1 = n;
 }
+
+// all but the n youngest vector-memory operations of this wave are done (n wave-uniform, 0..16)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define CVM_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    CVM_W(0) CVM_W(1) CVM_W(2) CVM_W(3) CVM_W(4) CVM_W(5) CVM_W(6) CVM_W(7) CVM_W(8)
+    CVM_W(9) CVM_W(10) CVM_W(11) CVM_W(12) CVM_W(13) CVM_W(14) CVM_W(15)
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+  }
+#undef CVM_W
+}
+
+// one LDS-DMA instruction: lane l copies 16 bytes from its own `src` to LDS byte address lds_addr + 16 l
+__device__ __forceinline__ void dma16_lanes(const void *src, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+}

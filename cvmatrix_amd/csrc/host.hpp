@@ -157,6 +157,23 @@ double simulate_launch(int64_t n_seg, int64_t max_rows, const Geom &g, int s_off
   return t_end;
 }
 
+// A forced row-split plan (experiments, tests): one atomic word (s_off << 16 | s_diag, 0 = the planner decides),
+// set by cvm_debug_force_splits; the environment variable CVM_FORCE_SPLITS="s_off,s_diag" is read ONCE, as its
+// initial value (getenv beside another thread's setenv is a data race in glibc: nothing here calls it per launch).
+std::atomic<unsigned> g_force_splits{0xffffffffu};       // 0xffffffff: environment not consulted yet
+inline unsigned forced_splits() {
+  unsigned v = g_force_splits.load(std::memory_order_relaxed);
+  if (v != 0xffffffffu) return v;
+  unsigned init = 0;
+  if (const char *force = getenv("CVM_FORCE_SPLITS")) {
+    int so = 0, sd = 0;
+    if (sscanf(force, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1 && so < 65536 && sd < 65536) init = ((unsigned)so << 16) | (unsigned)sd;
+  }
+  unsigned expect = 0xffffffffu;
+  g_force_splits.compare_exchange_strong(expect, init, std::memory_order_relaxed);
+  return g_force_splits.load(std::memory_order_relaxed);
+}
+
 SplitChoice choose_splits2(int64_t n_seg, int64_t max_rows, const Geom &g, int esize, int target) {
   if (n_seg < 1) n_seg = 1;
   // plan for a rounded-up row count (1/16 steps of the leading power of two): ragged folds asked
@@ -171,14 +188,11 @@ SplitChoice choose_splits2(int64_t n_seg, int64_t max_rows, const Geom &g, int e
   if (cap > mem_cap) cap = mem_cap;
   if (cap > 128) cap = 128;
   if (cap < 1) cap = 1;
-  // CVM_FORCE_SPLITS="s_off,s_diag": experiments (tools/) and tests pin the plan; clamped to the caps.  Read at
-  // every call (the one switch that is: tests/test_gpu_planner.py times the planner's plan against forced
-  // neighbours inside one process)
-  const char *force = getenv("CVM_FORCE_SPLITS");
+  // a forced plan (cvm_debug_force_splits / CVM_FORCE_SPLITS: experiments and tests), clamped to the caps
+  const unsigned force = forced_splits();
   if (force && !g.diag_only && g.nTiles > g.P) {
-    int so = 0, sd = 0;
-    if (sscanf(force, "%d,%d", &so, &sd) == 2 && so >= 1 && sd >= 1)
-      return SplitChoice{(int)(so > cap ? cap : so), (int)(sd > cap ? cap : sd)};
+    const int so = (int)(force >> 16), sd = (int)(force & 0xffffu);
+    return SplitChoice{(int)(so > cap ? cap : so), (int)(sd > cap ? cap : sd)};
   }
   static std::mutex mu;
   static std::map<SplitKey, SplitChoice> cache;
@@ -326,13 +340,21 @@ struct QueuePool {
   std::map<hipStream_t, unsigned> block_of;
   std::vector<hipStream_t> owner;           // by block
   std::vector<unsigned long long> last;     // by block: tick of its last hand-out
+  std::vector<hipEvent_t> ev;               // by block: recorded behind the block's last Gram launch (the library's own)
+  std::vector<char> state;                  // by block: 0 never launched (all zero), 1 ev says when its last launch is done,
+                                            //           2 handed out, launch not enqueued yet, 3 never recycled (captured)
   unsigned long long tick = 0;
 };
-unsigned *acquire_queue(int dev, hipStream_t st) {
-  static std::mutex mu;
-  static QueuePool pools[64];
-  QueuePool &p = pools[dev & 63];
-  std::lock_guard<std::mutex> lock(mu);
+std::mutex g_queue_mu;
+QueuePool g_queue_pools[64];
+// The block of stream `st` (handed out in state 2: the caller enqueues its launch and then calls queue_launched).
+// When all blocks have owners, the least recently used block whose LAST launch has completed -- by the library's
+// own event behind that launch, never by a query of somebody else's (possibly destroyed, possibly capturing)
+// stream handle -- changes hands; a block handed out whose launch is not enqueued yet (state 2) and a block whose
+// launch was captured into a graph (state 3: it may replay at any time) are never taken.
+unsigned *acquire_queue(int dev, hipStream_t st, unsigned *block_out) {
+  QueuePool &p = g_queue_pools[dev & 63];
+  std::lock_guard<std::mutex> lock(g_queue_mu);
   if (!p.mem) {
     void *mem = nullptr;
     if (hipMalloc(&mem, (size_t)QUEUE_POOL * QUEUE_BYTES) != hipSuccess) return nullptr;
@@ -350,16 +372,20 @@ unsigned *acquire_queue(int dev, hipStream_t st) {
       b = (unsigned)p.owner.size();
       p.owner.push_back(st);
       p.last.push_back(0);
+      p.ev.push_back(nullptr);
+      p.state.push_back(0);
     } else {
-      // least recently used first; take the first one with nothing in flight
+      // least recently used first; take the first one whose last launch is known to be over
       std::vector<unsigned> order(QUEUE_POOL);
       for (unsigned i = 0; i < QUEUE_POOL; ++i) order[i] = i;
       std::sort(order.begin(), order.end(), [&](unsigned a, unsigned c) { return p.last[a] < p.last[c]; });
       b = QUEUE_POOL;
       for (unsigned cand : order) {
-        const hipError_t q = hipStreamQuery(p.owner[cand]);
-        if (q == hipErrorNotReady) continue;          // that stream still has work queued: its block may be in use
-        if (q != hipSuccess) (void)hipGetLastError(); // (a destroyed stream's handle: clear the sticky error)
+        if (p.state[cand] >= 2) continue;
+        if (p.state[cand] == 1) {
+          const hipError_t q = hipEventQuery(p.ev[cand]);
+          if (q != hipSuccess) { if (q != hipErrorNotReady) (void)hipGetLastError(); continue; }
+        }
         b = cand;
         break;
       }
@@ -369,8 +395,23 @@ unsigned *acquire_queue(int dev, hipStream_t st) {
     }
     it = p.block_of.emplace(st, b).first;
   }
-  p.last[it->second] = p.tick;
-  return p.mem + (size_t)it->second * (QUEUE_BYTES / sizeof(unsigned));
+  const unsigned b = it->second;
+  p.last[b] = p.tick;
+  if (p.state[b] != 3) p.state[b] = 2;
+  if (block_out) *block_out = b;
+  return p.mem + (size_t)b * (QUEUE_BYTES / sizeof(unsigned));
+}
+// the launch that uses block `b` has been enqueued on `st` (or has failed: then the block is as it was)
+void queue_launched(int dev, unsigned b, hipStream_t st) {
+  QueuePool &p = g_queue_pools[dev & 63];
+  std::lock_guard<std::mutex> lock(g_queue_mu);
+  if (b >= p.state.size() || p.state[b] == 3) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  if (cs != hipStreamCaptureStatusNone) { p.state[b] = 3; return; }       // a graph may replay the launch whenever it likes
+  if (!p.ev[b] && hipEventCreateWithFlags(&p.ev[b], hipEventDisableTiming) != hipSuccess) { p.ev[b] = nullptr; p.state[b] = 3; return; }
+  if (hipEventRecord(p.ev[b], st) != hipSuccess) { (void)hipGetLastError(); p.state[b] = 3; return; }
+  p.state[b] = 1;
 }
 
 int device_cu_count(int dev) {
@@ -435,7 +476,8 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     (void)queue;
     args.clock_stamps = g_clock_buf.load(std::memory_order_acquire);
     args.clock_wgs = args.clock_stamps ? g_clock_wgs.load(std::memory_order_relaxed) : 0;
-    args.queue = acquire_queue(dev, st);
+    unsigned qblock = 0;
+    args.queue = acquire_queue(dev, st, &qblock);
     if (!args.queue) return fail(CVM_ELAUNCH, "launch_wgram: no work-queue block (allocation failed, or 1024 streams with Gram launches in flight at once)%s");
     // persistent workgroups: as many as the device keeps resident at once -- one per CU by the kernel's LDS,
     // asked of the occupancy API once per kernel and device -- and no more than the lists are long.  (Results
@@ -469,6 +511,7 @@ int launch_wgram(const WgramArgs<T> &a, bool weighted, bool gather, bool aligned
     } else if (weighted) { if (gather) CVM_LAUNCH4(true, true, false); else CVM_LAUNCH4(true, false, false); }
     else { if (gather) CVM_LAUNCH4(false, true, false); else CVM_LAUNCH4(false, false, false); }
 #undef CVM_LAUNCH4
+    queue_launched(dev, qblock, st);
   } else if (weighted) {
     if (gather) { if (aligned) CVM_LAUNCH(true, true, true); else CVM_LAUNCH(true, true, false); }
     else { if (aligned) CVM_LAUNCH(true, false, true); else CVM_LAUNCH(true, false, false); }
@@ -539,9 +582,10 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // 1.91 / 1.87, 64 rows 1.59 / 1.73; K=1024 ... 4096 64 rows 2.13 / 2.02 ... 2.38 / 2.35, 80 rows
 // 1.77 / 1.84 ... 2.04 / 2.24.  CVM_SMALL_MAXN (32 .. 128) overrides the table for measurements
 // and tests.
-// workspace of the direct small-fold route per fold: the statistics vector + small_tile_kernel's record
+// workspace of the direct small-fold route per fold: the statistics vector
 inline size_t small_ws_per_fold(int K, int M, int esize) {
-  return fstat_len(K, M) * 8 + small_rec_layout(K, esize).stride;
+  (void)esize;
+  return fstat_len(K, M) * 8;
 }
 int small_route_limit(int K, int esize) {
   static const int forced = [] {
@@ -562,8 +606,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
                     const void *G, const void *H, const double *gstats, void *out_XTX, void *out_XTY,
                     void *out_muX, void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
                     void *ws, size_t ws_bytes, hipStream_t st) {
-  // per fold: the float64 statistics vector and the record small_tile_kernel reads (small_tile.hpp)
-  const SmallRecLayout rl = small_rec_layout(K, (int)sizeof(T));
+  // per fold: the float64 statistics vector
   const size_t per_fold = small_ws_per_fold(K, M, (int)sizeof(T));
   int64_t nb_max = (int64_t)((ws_bytes > 256 ? ws_bytes - 256 : 0) / per_fold);
   if (nb_max < 1) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
@@ -574,14 +617,8 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
   memset(&a, 0, sizeof(a));
   a.X = X; a.Y = Y; a.w = w; a.idx = idx; a.offs = offsets; a.K = K; a.M = M;
   a.G = G; a.H = H; a.gstats = gstats; a.fstats = (double *)ws;
-  a.rec = (char *)ws + align_up((size_t)nb_max * fstat_len(K, M) * 8, 256);
-  a.rec_stride = rl.stride; a.rec_mu = rl.mu; a.rec_isd = rl.isd; a.rec_rows = rl.rows; a.rec_w = rl.w;
-  // small_tile_kernel (CVM_SMALL_TILE: 0 = the round-3 kernels only (default), 1 = this kernel, 2 = also in place of the
-  // whole-rows kernel): rows and G in whole 16-byte pieces, folds of at most SMALL_ROWS rows
-  static const int tile_mode = getenv("CVM_SMALL_TILE") ? atoi(getenv("CVM_SMALL_TILE")) : 0;
-  const bool tile_ok = tile_mode > 0 && max_rows <= SMALL_ROWS && ((size_t)K * sizeof(T)) % 16 == 0 &&
-                       ((uintptr_t)X % 16 == 0) && ((uintptr_t)G % 16 == 0) && ((uintptr_t)out_XTX % 16 == 0) &&
-                       (flags & CVM_RET_XTX) && out_XTX;
+  // (round 4's accumulator-direct tile kernel -- small_tile_kernel, CVM_SMALL_TILE -- was measured slower than the
+  //  kernels below and left the product in round 6: tools/experiments/pruned_r6_routes.patch)
   a.out_XTX = (flags & CVM_RET_XTX) ? out_XTX : nullptr;
   a.out_XTY = (flags & CVM_RET_XTY) ? out_XTY : nullptr;
   a.out_muX = out_muX; a.out_sdX = out_sdX; a.out_muY = out_muY; a.out_sdY = out_sdY;
@@ -621,7 +658,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
     const int vw = 16 / (int)sizeof(T);
     const int lpr = K <= 64 * vw ? 64 : (K <= 128 * vw ? 128 : 256);     // pieces per row of a workgroup
     const int tc = lpr * vw;
-    const bool direct = !no_direct && !(tile_ok && tile_mode >= 2) && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
+    const bool direct = !no_direct && max_rows <= 2 && nb >= 8 && K <= tc && 2 * K > tc &&
                         (size_t)K * K * sizeof(T) <= ((size_t)2 << 20) + (64 << 10) &&
                         ((size_t)K * sizeof(T)) % 16 == 0 && ((size_t)K * sizeof(T)) % 128 != 0 &&
                         ((uintptr_t)G % 16 == 0) && ((uintptr_t)X % 16 == 0) &&
@@ -651,46 +688,6 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         else if (lpr == 128) CVM_ROWS(128);
         else CVM_ROWS(256);
 #undef CVM_ROWS
-      } else if (tile_ok) {
-        // every 64 x 64 tile of XTX by small_tile_kernel; the XTY panels by the round-3 kernel
-        // k-steps of a fold: its rows and, when XTX is centred, the row of means; + the isd step
-        a.tsteps = (int)((max_rows + ((flags & CVM_CENTER_X) ? 1 : 0) + 3) / 4) + 1;
-        const int64_t tiles = (int64_t)a.P64 * a.P64;
-        static const int fpb_forced = getenv("CVM_SMALL_FPB") ? atoi(getenv("CVM_SMALL_FPB")) : 0;
-        int fpt = (int)(tiles * nb / (24 * 256));              // folds per workgroup: >= 24 workgroups per CU in the launch
-        if (fpt > 8) fpt = 8;
-        if (fpb_forced > 0) fpt = fpb_forced;
-        if (fpt > TL_FPB) fpt = TL_FPB;
-        if (fpt < 1) fpt = 1;
-        SmallArgs t = a;
-        static const int tile_dbg = getenv("CVM_TILE_DEBUG") ? atoi(getenv("CVM_TILE_DEBUG")) : 0;
-        t.dbg = tile_dbg;
-        t.fpb = fpt; t.x0 = 0;
-        t.gx = (int)tiles; t.gy = (int)((nb + fpt - 1) / fpt);
-        static const int nbuf_env = getenv("CVM_TILE_NBUF") ? atoi(getenv("CVM_TILE_NBUF")) : 0;
-        t.nbuf = nbuf_env >= 2 && nbuf_env <= 3 ? nbuf_env : 2;      // (three buffers: measured no faster in float32, slower in float64)
-        if (small_tile_lds<T>(t.tsteps, fpt, t.nbuf) > 150 * 1024) t.nbuf = 2;
-        const size_t lds = small_tile_lds<T>(t.tsteps, fpt, t.nbuf);
-        if (lds > 64 * 1024) {
-          int dev = 0;
-          HIP_OK(hipGetDevice(&dev));
-          static std::atomic<unsigned long long> attr_done{0};   // one bit per device
-          if (attr_needed(attr_done, dev)) {
-            HIP_OK(hipFuncSetAttribute((const void *)small_tile_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-            attr_set(attr_done, dev);
-          }
-        }
-        const dim3 gt_((unsigned)(8 * (((size_t)t.gx * t.gy + 7) / 8)));
-        hipLaunchKernelGGL((small_tile_kernel<T>), gt_, dim3(256), lds, st, t);
-        if (a.out_XTY && M > 0) {
-          // (one fold per workgroup: the panels of a group of 8 folds one after the other took 47 us at K = 4096)
-          a.fpb = 1;
-          a.x0 = a.nT64; a.gx = a.P64; a.gy = (int)nb;
-          const dim3 g1((unsigned)(8 * (((size_t)a.gx * a.gy + 7) / 8)));
-          if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), g1, dim3(256), 0, st, a);
-          else hipLaunchKernelGGL((small_apply_kernel<T, false>), g1, dim3(256), 0, st, a);
-          a.x0 = 0;
-        }
       } else {
         a.gx = (int)ga.x; a.gy = (int)ga.y;
         const dim3 g1((unsigned)(8 * (((size_t)ga.x * ga.y + 7) / 8)));
@@ -736,11 +733,6 @@ template <typename T> int launch_mid(MidArgs m, bool weighted, int64_t nb, int64
   m.n_items = (long long)nb * m.ipf;
   m.per_xcd = (m.n_items + 7) / 8;
   m.nb = (int)nb;
-  if (m.stat_flags) {                      // statistics formed in the launch: whole folds per XCD (mid_tile.hpp)
-    if (m.yextra) return fail(CVM_EINVAL, "launch_mid: statistics in the launch need M <= 16%s");
-    m.fpx = (int)((nb + 7) / 8);
-    m.per_xcd = (long long)m.fpx * m.ipf;
-  }
   m.maxn = (int)((max_rows + 15) / 16 * 16);
   if (m.maxn < 16) m.maxn = 16;
   const size_t lds = mid_lds_bytes<T>(m.maxn);
@@ -750,13 +742,6 @@ template <typename T> int launch_mid(MidArgs m, bool weighted, int64_t nb, int64
   TimedLaunch *tl = timed_begin(KIND_FOLD, st);
   if (weighted) hipLaunchKernelGGL((mid_tile_kernel<T, true>), grid, dim3(MID_THREADS), lds, st, m);
   else hipLaunchKernelGGL((mid_tile_kernel<T, false>), grid, dim3(MID_THREADS), lds, st, m);
-  if (m.stat_flags) {
-    // the items whose wait for a flag gave up (none, unless the device is shared in a way that breaks the
-    // dispatch-order argument of mid_tile.hpp): once more, behind the launch that has raised every flag
-    m.retry_mode = 1;
-    if (weighted) hipLaunchKernelGGL((mid_retry_kernel<T, true>), dim3(64), dim3(MID_THREADS), lds, st, m);
-    else hipLaunchKernelGGL((mid_retry_kernel<T, false>), dim3(64), dim3(MID_THREADS), lds, st, m);
-  }
   timed_end(tl, st);
   HIP_OK(hipGetLastError());
   return CVM_OK;
@@ -813,8 +798,6 @@ int fold_statistics_impl(const void *X, const void *Y, const void *w, const int6
 struct FoldSwitches {
   int mid_minn, mid_maxn;      // CVM_MID_MINN / CVM_MID_MAXN: row limits of mid_tile_kernel (0: the measured table)
   bool mid_off;                // CVM_MID_TILE=0: never mid_tile_kernel
-  bool mid_own;                // CVM_MID_OWNSTATS=1: its items sum their own columns (no pre-pass; measured slower)
-  bool mid_ink;                // CVM_MID_INK=1: mid_tile_kernel forms its statistics in the launch (measured slower: below)
   bool force_fallback;         // CVM_FORCE_FALLBACK=1: the general Gram kernel
   bool no_fused;               // CVM_NO_FUSED=1: partials + apply_kernel for one-unit folds too
   bool prepass;                // CVM_FUSED_PREPASS=1: statistics by colstats_kernel + fold_stats_kernel, not in the launch
@@ -827,8 +810,6 @@ const FoldSwitches &fold_switches() {
     FoldSwitches f;
     f.mid_minn = num("CVM_MID_MINN", 0); f.mid_maxn = num("CVM_MID_MAXN", 0);
     f.mid_off = num("CVM_MID_TILE", 1) == 0;
-    f.mid_own = num("CVM_MID_OWNSTATS", 0) != 0;
-    f.mid_ink = num("CVM_MID_INK", 0) != 0;
     f.force_fallback = num("CVM_FORCE_FALLBACK", 0) != 0;
     f.no_fused = num("CVM_NO_FUSED", 0) != 0;
     f.prepass = num("CVM_FUSED_PREPASS", 0) != 0;
@@ -879,13 +860,12 @@ double *launch_prepass(const FoldCall &c, const Geom &gs, int64_t csplits, int64
   return f.fstats;
 }
 
-// arguments of mid_tile_kernel over the folds [f0, ...) (fstats: from the pre-pass, or nullptr = own statistics)
+// arguments of mid_tile_kernel over the folds [f0, ...) (fstats: from the pre-pass)
 inline MidArgs mid_args(const FoldCall &c, int64_t f0, const double *fstats) {
   MidArgs m;
   memset(&m, 0, sizeof(m));
   m.X = c.X; m.Y = c.Y; m.w = c.w; m.idx = c.idx; m.offs = c.offsets; m.seg0 = f0;
-  m.fstats = fstats; m.gstats = c.gstats; m.ddof = c.ddof; m.resolution = c.resolution;
-  m.out_muX = c.out_muX; m.out_sdX = c.out_sdX; m.out_muY = c.out_muY; m.out_sdY = c.out_sdY; m.out_fold = c.out_fold;
+  m.fstats = fstats;
   m.G = c.G; m.H = c.H;
   m.out_XTX = c.out_XTX; m.out_XTY = c.want_xty ? c.out_XTY : nullptr;
   m.K = c.K; m.M = c.M; m.flags = c.flags;
@@ -975,18 +955,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       int64_t per_batch = (int64_t)(ws_bytes / per_fold);
       if (per_batch > 16384) per_batch = 16384;
       // Folds of up to a few hundred rows: mid_tile_kernel (mid_tile.hpp) -- small work items, four
-      // workgroups per CU, so that one item's stores overlap another's MFMAs -- behind the statistics pre-pass
-      // (or, CVM_MID_OWNSTATS=1, with every item summing its own columns: the C3 rows in 1000 folds 1.11 -> 1.36 ms,
-      // where the pre-pass costs 0.095 ms; profiles/r4/mid_tile/own_statistics.txt).
+      // workgroups per CU, so that one item's stores overlap another's MFMAs -- behind the statistics pre-pass.
       const bool mid = !sw.mid_off && max_rows <= mid_maxn && mid_operands_ok<T>(X, Y, w, N, K, M);
-      if (mid && sw.mid_own) {
-        for (int64_t f0 = 0; f0 < n_folds; f0 += 16384) {
-          const int64_t nb = (n_folds - f0 < 16384) ? n_folds - f0 : 16384;
-          rc = launch_mid<T>(mid_args(c, f0, nullptr), w != nullptr, nb, max_rows, st);
-          if (rc != CVM_OK) return rc;
-        }
-        return CVM_OK;
-      }
       // Statistics formed INSIDE the Gram launch (round 4): the diagonal item of (fold, panel) sums the panel's
       // columns while it streams the fold's rows anyway and publishes the panel's training means / stds, the
       // off-diagonal items wait for the two flags they need (wgram4.hpp).  No colstats_kernel + fold_stats_kernel
@@ -996,33 +966,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
       const int per0 = p.g.nTiles - p.g.P;
       const bool ink = !mid && !sw.prepass && p.g.Yc == 1 &&
                        fst + (size_t)p.g.P * 4 + (size_t)per0 * 8 + 512 <= per_fold;
-      // mid_tile_kernel can form its statistics in the launch the same way (round 5, CVM_MID_INK=1: its diagonal
-      // tiles sum their panel's columns and publish, the others poll behind their stage loop; M <= 16 when XTY is
-      // wanted).  Built, green, measured and NOT the default: the diagonal tiles' column sums are vector
-      // arithmetic next to three other workgroups' float64 MFMAs, and every off-diagonal tile pays one more
-      // dependent memory round trip behind its loop -- the C3 rows in 1000 folds 1.16 -> 1.24 ms, in 3000 folds
-      // 2.16 -> 2.30 ms (1.29 / 2.35 before the diagonal tiles were dispatched a fold ahead), where the pre-pass it
-      // removes costs 0.09 ms (profiles/r5/mid_tile/inlaunch_statistics.txt)
-      const int nt64 = (K + 63) / 64, noff64 = nt64 * (nt64 - 1) / 2;
-      const bool mid_ink = mid && sw.mid_ink && !sw.prepass && !(want_xty && M > 16) &&
-                           fst + (size_t)nt64 * 4 + (size_t)noff64 * 8 + 512 <= per_fold;
       for (int64_t f0 = 0; f0 < n_folds; f0 += per_batch) {
         const int64_t nb = (n_folds - f0 < per_batch) ? n_folds - f0 : per_batch;
-        if (mid_ink) {
-          // workspace of the batch: [fstats nb x fst | flags nb x nt | status 4 ints | retry list nb x off-diagonal tiles]
-          double *fstats = (double *)ws;
-          int *sflags = (int *)((char *)ws + align_up((size_t)nb * fst, 256));
-          const size_t flag_bytes = align_up((size_t)nb * nt64 * sizeof(int), 16);
-          int *fstatus = (int *)((char *)sflags + flag_bytes);
-          HIP_OK(hipMemsetAsync(sflags, 0, flag_bytes + 16, st));
-          MidArgs m = mid_args(c, f0, fstats);
-          m.stat_flags = sflags; m.fused_status = fstatus;
-          m.retry_items = (unsigned long long *)((char *)fstatus + 16);
-          m.status_out = status; m.test_mode = sw.fused_test;
-          rc = launch_mid<T>(m, w != nullptr, nb, max_rows, st);
-          if (rc != CVM_OK) return rc;
-          continue;
-        }
         if (ink) {
           double *fstats = (double *)ws;
           int *sflags = (int *)((char *)ws + align_up((size_t)nb * fst, 256));
@@ -1036,12 +981,16 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
           a.fused_status = fstatus;
           a.retry_items = (unsigned long long *)((char *)fstatus + 16);
           a.test_mode = sw.fused_test;
-          rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, KIND_FOLD, wq.queue, true);
+          // (both launches between ONE pair of the timing recorder's events, like launch_mid's: the route's
+          //  kernel time includes its -- normally empty, ~2 us -- retry launch)
+          TimedLaunch *tl = timed_begin(KIND_FOLD, st);
+          rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, -1, wq.queue, true);
           if (rc != CVM_OK) return rc;
           // the items whose wait for a flag gave up (none, unless the device is shared in a way that breaks the
           // kernel's progress argument): once more, behind the launch that has raised every flag
           a.retry_mode = 1; a.status_out = status;
           rc = launch_wgram<T>(a, w != nullptr, true, aligned, st, -1, wq.queue, true, 64);
+          timed_end(tl, st);
           if (rc != CVM_OK) return rc;
           continue;
         }

@@ -32,21 +32,19 @@
 //     tile with fused_finish_direct's arithmetic (finalize.hpp: total - update, rank-1 centring,
 //     reciprocal-std scaling, 16-byte nontemporal stores) and fused_finish_mirror -- the same arithmetic on
 //     the same MFMA sums as the fused route.
-//   * The per-fold statistics come from colstats_kernel + fold_stats_kernel (the pre-pass of host.hpp) -- or,
-//     MidArgs::fstats == nullptr (CVM_MID_OWNSTATS=1), every item sums its own 128 staged columns in row order
-//     on the vector units and derives them itself: the same bits, no pre-pass, and measured slower (host.hpp).
+//   * The per-fold statistics come from colstats_kernel + fold_stats_kernel (the pre-pass of host.hpp).  (Two
+//     routes without the pre-pass were built, were green and measured SLOWER, and left the product in round 6 --
+//     every item summing its own 128 staged columns on the vector units, 22 % slower at 1000 folds; the diagonal
+//     tiles forming the statistics and handing them to the others behind flags, 7 % slower: the code is
+//     tools/experiments/pruned_r6_routes.patch, the numbers profiles/r4/mid_tile/own_statistics.txt and
+//     profiles/r5/mid_tile/inlaunch_statistics.txt.)
 #pragma once
 
 struct MidArgs {
   const void *X, *Y, *w;
   const int64_t *idx, *offs;
   int64_t seg0;                  // first fold of this batch in offs / the outputs
-  const double *fstats;          // [fold of batch][fstat_len] from the pre-pass, or nullptr: every item forms the
-                                 // statistics of its own columns (below) from the rows it stages anyway
-  const double *gstats;          // (then:) the full-data sums, cvm_gstats_len entries
-  double ddof, resolution;
-  void *out_muX, *out_sdX, *out_muY, *out_sdY;
-  double *out_fold;
+  const double *fstats;          // [fold of batch][fstat_len] from the pre-pass
   const void *G, *H;
   void *out_XTX, *out_XTY;
   long long n_items, per_xcd;    // work items; workgroups per XCD
@@ -58,22 +56,7 @@ struct MidArgs {
   int maxn;                      // rows the LDS lists hold (a multiple of 16, >= the longest fold)
   int chmax;                     // (tools/experiments/mid_chain.hpp: tiles per chain at most)
   unsigned flags;
-  // Statistics formed INSIDE the launch (round 5; stat_flags != nullptr, fstats writable, yextra == 0): the diagonal
-  // tile of (fold, panel) sums its panel's columns (and the Y tile's, and the weights) in row order like an item of
-  // the own-statistics mode, derives the training means / reciprocal stds, writes them to fstats with
-  // device-coherent stores and raises stat_flags[fold * nt + panel]; an off-diagonal tile polls the flags of its
-  // two panels behind its stage loop.  Items: a fold's nt diagonal tiles first, whole folds per XCD (fpx), so a
-  // waiting workgroup was dispatched after the ones it waits for.  The wait is bounded: an item that gives up
-  // writes nothing and lists itself in retry_items (count in fused_status[0]); the host's second launch
-  // (retry_mode) recomputes the listed items behind the first; giving up there counts in fused_status[1] and
-  // poisons the item's outputs with NaN; its last workgroup (exit counter fused_status[2]) folds both into
-  // *status_out like wgram4_kernel's retry launch (cvm_fold_update_ex).
-  int *stat_flags;
-  int *fused_status;
-  unsigned long long *retry_items;
-  int32_t *status_out;
-  int retry_mode, test_mode;
-  int fpx, nb;                   // folds per XCD, folds of the batch
+  int nb;                        // folds of the batch
   // measurements only (tools/mid_probe.hip builds with -DCVM_MID_ABLATE; the library never sets them):
   // dbg bits: 1 no output stores, 2 no G loads, 4 no LDS-DMA after the first stages, 8 no MFMA, 16 return after the loop
   int dbg;
@@ -134,18 +117,9 @@ __device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, con
   const int dbg = MID_DBG(a);
   MID_STAMP(0);
   const int K = a.K, M = a.M;
-  const bool ink = a.stat_flags != nullptr;
   // kind 0: XTX tile (ti, tj); kind 2: XTY-only item (panel ti, response columns 16 + 64 yc ..)
   int ti = 0, tj = 0, yc = 0, kind = 0;
-  if (ink) {
-    // (statistics formed in the launch: the fold's diagonal tiles first, then the others row by row)
-    if (q < a.nt) ti = tj = q;
-    else {
-      int rem = q - a.nt;
-      while (rem >= a.nt - 1 - ti) { rem -= a.nt - 1 - ti; ++ti; }
-      tj = ti + 1 + rem;
-    }
-  } else if (q < a.n_xtx) {
+  if (q < a.n_xtx) {
     int rem = q;
     while (rem >= a.nt - ti) { rem -= a.nt - ti; ++ti; }
     tj = ti + rem;
@@ -179,17 +153,10 @@ __device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, con
   T *wl = reinterpret_cast<T *>(sq + 256);
   int *rowl = reinterpret_cast<int *>(wl + a.maxn);
   T (*Ts)[65] = reinterpret_cast<T (*)[65]>(smem_raw);
-  // where the statistics come from: `own` -- this item sums its staged columns itself (every item when there is no
-  // statistics vector at all; the diagonal tiles when the statistics are formed in the launch); `late` -- from the
-  // diagonal tiles of its two panels, behind the stage loop; else from the pre-pass, at once
-  const bool own = a.fstats == nullptr || (ink && diag);
-  const bool late = ink && !diag;
-  const double *fs = a.fstats == nullptr ? nullptr : a.fstats + (size_t)f * fstat_len(K, M);
+  // the fold's statistics: from the pre-pass
+  const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
-  const bool rXTY = a.flags & CVM_RET_XTY;
-  const bool want_muX = cX || sX || (rXTY && cY), want_sdX = sX;
-  const bool want_muY = rXTY && (cX || cY || sY), want_sdY = rXTY && sY;
   const size_t fo = (size_t)(a.seg0 + f);
   const bool finish_xtx = kind == 0 && a.out_XTX != nullptr;
   // the response columns this item holds in LDS: a diagonal tile the first sixteen, an XTY-only item up to 64
@@ -202,13 +169,9 @@ __device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, con
   for (int r = tid; r < npad; r += MID_THREADS) rowl[r] = r < n ? (int)a.idx[rbeg + r] : 0;
   MID_STAMP(1);
   double swt = 0.0;
-  // (own statistics) the full-data sums of this thread's column of the blocks: X column and response column
-  double gsx = 0, gqx = 0, gsy = 0, gqy = 0, gsw = 0, gnz = 0;
   const int xcol = ((which < 2) ? a0 : b0) + wc64;        // (diagonal tile: b0 == a0)
   const int ycol = ybase + wc64;
-  if (late) {
-    // (nothing yet)
-  } else if (!own) {
+  {
     double v = (which & 1) ? 1.0 : 0.0;
     if (xcol < K && (kind == 0 || which < 2)) {
       if (!(which & 1) && cX) v = fs[xcol];
@@ -219,10 +182,6 @@ __device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, con
     if (which == 2) sq[64 + wc64] = ((cX || cY) && wc64 < ny) ? fs[2 * K + ycol] : 0.0;
     if (which == 3) sq[128 + wc64] = (sY && wc64 < ny) ? fs[2 * K + M + ycol] : 1.0;
     swt = fs[2 * K + 2 * M];
-  } else {
-    if (xcol < K && (kind == 0 || which < 2)) { gsx = a.gstats[xcol]; gqx = a.gstats[K + xcol]; }
-    if (which >= 2 && wc64 < ny) { gsy = a.gstats[2 * K + ycol]; gqy = a.gstats[2 * K + M + ycol]; }
-    gsw = a.gstats[2 * K + 2 * M]; gnz = a.gstats[2 * K + 2 * M + 1];
   }
   __syncthreads();
 
@@ -314,149 +273,6 @@ __device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, con
     lds_barrier();
     cnt[(s + NBUF - 1) % NBUF] = (s + NBUF - 1 < nst) ? issue(s + NBUF - 1) : 0;
   };
-  // ---- own statistics: lane (c, half) of wave w sums column 32 w + c of the 128 staged columns over the
-  // fold's rows IN ROW ORDER -- half 0: s += w x, half 1: q += (w x) x, in float64 like colstats_kernel, so the
-  // statistics are the pre-pass's (and small_stats_kernel's) bit for bit; thread 0 sums the weights.
-  const int scol = 32 * wave + (lane & 31);
-  const bool is_q = lane >= 32;
-  const bool sB = scol >= 64;
-  const bool svalid = own && (sB ? (loadB ? true : (scol - 64 < ny)) : true);
-  const int soff = !sB ? scol : (loadB ? SR * 64 + (scol - 64) : SR * 64 + ((scol - 64) >> 4) * SR * 16 + ((scol - 64) & 15));
-  const int srs = (!sB || loadB) ? 64 : 16;
-  double sacc = 0.0, swv = 0.0, nzv = 0.0;
-  auto stage_stats = [&](int s) {
-    if (!own) return;
-    const T *buf = ring + (s % NBUF) * MID_STAGE_ELEMS;
-    const T *wst = wl + SR * s;
-    const int rows_here = n - SR * s < SR ? n - SR * s : SR;
-    if (svalid) {
-#pragma unroll 4
-      for (int r = 0; r < rows_here; ++r) {
-        const T x = buf[soff + r * srs];
-        const T pv = WEIGHTED ? (T)(x * wst[r]) : x;
-        sacc += is_q ? (double)(T)(pv * x) : (double)pv;
-      }
-    }
-    if (WEIGHTED && tid == 0) {
-      for (int r = 0; r < rows_here; ++r) { swv += (double)wst[r]; nzv += (wst[r] != (T)0) ? 1.0 : 0.0; }
-    }
-  };
-  // one column: mean, reciprocal std and std of the training set (fold_column_finish's formulas, finalize.hpp)
-  auto finish_col = [&](double sv, double qv, double gs, double gq, double swt_, double divisor, bool want_sd,
-                        double &mu, double &isd, double &sd) {
-    const double st_ = gs - sv;          // cvmatrix.py:1020
-    mu = st_ / swt_;                     // cvmatrix.py:1043
-    sd = 1.0;
-    if (want_sd) {
-      const double qt = gq - qv;
-      double var = (-2 * mu * st_ + swt_ * (mu * mu) + qt) / divisor;   // 1119-1123
-      var = (var < 0) ? 0.0 : var;       // np.maximum(var, 0): NaN stays NaN
-      sd = sqrt(var);
-      if (sd <= a.resolution) sd = 1.0;  // 1128
-    }
-    isd = 1.0 / sd;
-  };
-  // after the stage loop (every wave): the sums meet in LDS, every thread derives its entries of the blocks;
-  // a diagonal tile (and the XTY items of panel 0) also write the statistics the call returns
-  auto stats_phase = [&]() {
-    if (!own) return;
-    if (svalid) sq[scol + (is_q ? 128 : 0)] = sacc;
-    if (tid == 0) { rs[0] = WEIGHTED ? swv : (double)n; rs[1] = WEIGHTED ? nzv : (double)n; }
-    lds_barrier();
-    const double swv_ = rs[0], nzv_ = rs[1];
-    const double swt_ = gsw - swv_, nzt = gnz - nzv_;
-    const double divisor = (nzt - a.ddof) * swt_ / nzt;
-    swt = swt_;
-    double v_rs = (which & 1) ? 1.0 : 0.0, v_y = (which == 3) ? 1.0 : 0.0;
-    const int xi = (which < 2 || diag) ? wc64 : 64 + wc64;           // this thread's X column among the staged sums
-    if (xcol < K && (kind == 0 || which < 2) && want_muX) {
-      double mu, isd, sd;
-      finish_col(sq[xi], sq[128 + xi], gsx, gqx, swt_, divisor, want_sdX, mu, isd, sd);
-      if (which & 1) { if (sX) v_rs = isd; }
-      else { if (cX) v_rs = mu; if (which == 0 && (cX || cY)) v_y = mu; }
-      if (diag && which == 0) {
-        const size_t o = fo * K + xcol;
-        if (a.out_muX) reinterpret_cast<T *>(a.out_muX)[o] = (T)mu;
-        if (a.out_sdX && want_sdX) reinterpret_cast<T *>(a.out_sdX)[o] = (T)sd;
-      }
-    }
-    if (which >= 2 && wc64 < ny && want_muY) {
-      double mu, isd, sd;
-      finish_col(sq[64 + wc64], sq[192 + wc64], gsy, gqy, swt_, divisor, want_sdY, mu, isd, sd);
-      if (which == 2) { if (cX || cY) v_y = mu; }
-      else if (sY) v_y = isd;
-      if (ti == 0 && which == 2) {
-        const size_t o = fo * M + ycol;
-        if (a.out_muY) reinterpret_cast<T *>(a.out_muY)[o] = (T)mu;
-        if (a.out_sdY && want_sdY) reinterpret_cast<T *>(a.out_sdY)[o] = (T)sd;
-      }
-    }
-    if (tid == 0 && diag && ti == 0 && a.out_fold) {
-      double *o = a.out_fold + 4 * fo;
-      o[0] = swt_; o[1] = nzt; o[2] = swv_; o[3] = nzv_;
-    }
-    lds_barrier();                                       // everybody has read the sums
-    rs[tid] = v_rs;
-    if (which == 0) sq[wc64] = v_y;
-    if (which == 2) sq[64 + wc64] = v_y;
-    if (which == 3) sq[128 + wc64] = v_y;
-  };
-  // ---- statistics formed in the launch: the hand-off ---------------------------------------------------------
-  // (diagonal tile, behind stats_phase and its barrier) wave 0 copies the panel's means / reciprocal stds -- as the
-  // blocks hold them: 0 / 1 where the flags ask for no centring / scaling -- and sw_T to the fold's statistics
-  // vector with device-coherent stores, waits for ITS stores and raises the panel's flag
-  auto publish = [&]() {
-    if (!(ink && diag) || wave != 0) return;
-    double *fsw = const_cast<double *>(fs);
-    if (a0 + lane < K) { stc(fsw + a0 + lane, rs[lane]); stc(fsw + K + a0 + lane, rs[64 + lane]); }
-    if (lane == 0) stc(fsw + 2 * K + 2 * M, swt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(a.stat_flags + (size_t)f * a.nt + ti, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // (off-diagonal tile, behind the stage loop) one lane waits for the flags of the two panels -- bounded: see
-  // MidArgs -- then every thread fetches its entry of the blocks with device-coherent loads.  false: the item
-  // gave up, is listed for the retry launch and writes nothing.
-  auto await_statistics = [&]() -> bool {
-    int *markp = reinterpret_cast<int *>(sq + 250);
-    if (tid == 0) {
-      int ok = 1;
-      const long limit = a.test_mode == 2 ? 4 : (1L << 18);
-      const bool feign = (a.test_mode == 1 || a.test_mode == 3) && f % 3 == 0 && (!a.retry_mode || a.test_mode == 3);
-      for (int w2 = 0; w2 < 2 && ok; ++w2) {
-        const int *fl = a.stat_flags + (size_t)f * a.nt + (w2 ? tj : ti);
-        long spins = 0;
-        while (feign || __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-          __builtin_amdgcn_s_sleep(2);
-          if (feign || ++spins > limit) { ok = 0; break; }
-        }
-      }
-      int mark = 1;
-      if (!ok) {
-        if (!a.retry_mode) {
-          const int pos = __hip_atomic_fetch_add(a.fused_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          a.retry_items[pos] = (unsigned long long)f * (unsigned long long)a.ipf + (unsigned long long)q;
-          mark = 0;
-        } else {
-          __hip_atomic_fetch_add(a.fused_status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          mark = 2;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      *reinterpret_cast<volatile int *>(markp) = mark;
-    }
-    lds_barrier();
-    const int mark = uni(*reinterpret_cast<volatile int *>(markp));
-    if (mark == 0) return false;
-    double v = (which & 1) ? 1.0 : 0.0;
-    if (xcol < K) {
-      if (!(which & 1) && cX) v = ldc(fs + xcol);
-      if ((which & 1) && sX) v = ldc(fs + K + xcol);
-    }
-    swt = ldc(fs + 2 * K + 2 * M);
-    if (mark == 2) { v = __builtin_nan(""); swt = v; }      // (never a finite wrong number)
-    rs[tid] = v;
-    return true;
-  };
   if (role == 2) {
     acc_t acc[4];
 #pragma unroll
@@ -487,14 +303,11 @@ __device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, con
       stage_head(s);
       if (s == 0) MID_STAMP(2);
       if (!(dbg & 8)) ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
-      stage_stats(s);
     }
     MID_STAMP(3);
     if (dbg & 16) return;
     g_preload();
-    stats_phase();
-    lds_barrier();                                       // the blocks are in LDS; the ring is free
-    publish();                                           // (a no-op in this wave: wave 0 publishes)
+    lds_barrier();                                       // the ring is free
     // XTY piece straight from the accumulators (cvmatrix.py:1001-1010 for XTY)
     T *out = reinterpret_cast<T *>(a.out_XTY) + fo * (size_t)K * M;
     const T *Ht = reinterpret_cast<const T *>(a.H);
@@ -555,15 +368,11 @@ __device__ __forceinline__ void mid_tile_item(const MidArgs &a, const int f, con
       stage_head(s);
       if (s == 0) MID_STAMP(2);
       if (role == 1 && !(dbg & 8)) ksteps(ring + (s % NBUF) * MID_STAGE_ELEMS, wl + SR * s, nks - KPS * s);
-      stage_stats(s);
     }
     MID_STAMP(3);
     if (dbg & 16) return;
     g_preload();
-    if (late && !await_statistics()) return;             // (its wait gave up: nothing is written, the retry launch recomputes it)
-    stats_phase();
-    lds_barrier();                                       // the blocks are in LDS; the ring is free: the tile goes over it
-    publish();
+    lds_barrier();                                       // the ring is free: the tile goes over it
     if (finish_xtx) {
       if (role == 1) {
 #pragma unroll
@@ -616,57 +425,9 @@ template <typename T, bool WEIGHTED>
 __global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_tile_kernel(const MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int bid = blockIdx.x;
-  int f, q;
-  if (a.stat_flags) {
-    // whole folds per XCD: workgroup b -> XCD b % 8, position b / 8 of that XCD's sequence.  The sequence runs the
-    // diagonal tiles one fold AHEAD of the others -- diag(0) | diag(1), off(0) | diag(2), off(1) | ... | off(last)
-    // -- so that (the hardware starts an XCD's workgroups in order) a fold's statistics are a fold's worth of
-    // work old when its off-diagonal tiles ask for them
-    const int pos = bid >> 3, noff = a.ipf - a.nt;
-    int fl;
-    if (pos < a.nt) { fl = 0; q = pos; }
-    else {
-      const int p2 = pos - a.nt, k = p2 / a.ipf, r = p2 - k * a.ipf;
-      if (k < a.fpx - 1) { if (r < a.nt) { fl = k + 1; q = r; } else { fl = k; q = r; } }
-      else { fl = a.fpx - 1; q = a.nt + (p2 - (a.fpx - 1) * a.ipf); if (q >= a.ipf) return; }
-    }
-    (void)noff;
-    f = (bid & 7) * a.fpx + fl;
-    if (fl >= a.fpx || f >= a.nb) return;
-  } else {
-    const long long item = (long long)(bid & 7) * a.per_xcd + (bid >> 3);
-    if (item >= a.n_items) return;
-    f = (int)(item / a.ipf);
-    q = (int)(item - (long long)f * a.ipf);
-  }
+  const long long item = (long long)(bid & 7) * a.per_xcd + (bid >> 3);
+  if (item >= a.n_items) return;
+  const int f = (int)(item / a.ipf);
+  const int q = (int)(item - (long long)f * a.ipf);
   mid_tile_item<T, WEIGHTED>(a, f, q, bid, smem_raw);
-}
-
-// The retry launch of a call that forms its statistics in the launch (MidArgs::retry_mode): the items whose wait
-// gave up in the first launch, a few workgroups walking the list; the last one to leave reports.
-template <typename T, bool WEIGHTED>
-__global__ __launch_bounds__(MID_THREADS, CVM_MID_WPE) void mid_retry_kernel(const MidArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int bid = blockIdx.x;
-  const int n = __hip_atomic_load(a.fused_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll 1
-  for (int i = bid; i < n; i += (int)gridDim.x) {
-    const unsigned long long it = a.retry_items[i];
-    mid_tile_item<T, WEIGHTED>(a, (int)(it / (unsigned long long)a.ipf), (int)(it % (unsigned long long)a.ipf), bid, smem_raw);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int left = __hip_atomic_fetch_add(a.fused_status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == (int)gridDim.x - 1 && a.status_out) {
-      const int lost = __hip_atomic_load(a.fused_status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int st = lost ? 1 : (n ? 2 : 0);
-      if (st) {
-        int cur = __hip_atomic_load(a.status_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (cur != 1 && cur != st) {
-          if (__hip_atomic_compare_exchange_strong(a.status_out, &cur, st, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
-      }
-    }
-  }
 }

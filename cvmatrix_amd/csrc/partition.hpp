@@ -248,3 +248,41 @@ inline int partition_periodic_impl(const int64_t *labels, int64_t N, int64_t L, 
   return CVM_OK;
 }
 
+
+// ---- weights check on the device (cvm_weights_check) ------------------------------------------------
+// cvmatrix.py:1188-1189 (`any(weights < 0)` -> ValueError) and :1226 (`count_nonzero(weights)`) for weights
+// that live on the device: out[0] = #(w < 0), out[1] = #(w != 0), exact integer counts (order-free integer
+// atomics), one small launch on the caller's stream.  The host class copies the two words to pinned memory
+// asynchronously and reads them when a result of that fit is first handed out: no read-back of the weights,
+// no host wait inside fit().
+template <typename T>
+__global__ __launch_bounds__(256) void weights_check_kernel(const T *w, int64_t N, unsigned long long *out) {
+  unsigned neg = 0, nz = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const T v = w[i];
+    neg += (v < (T)0) ? 1u : 0u;
+    nz += (v != (T)0) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { neg += __shfl_down(neg, o); nz += __shfl_down(nz, o); }
+  if ((threadIdx.x & 63) == 0) {
+    if (neg) atomicAdd(out, (unsigned long long)neg);
+    if (nz) atomicAdd(out + 1, (unsigned long long)nz);
+  }
+}
+
+inline int weights_check_impl(const void *w, int64_t N, int dtype, int64_t *out2, hipStream_t st) {
+  HIP_OK(hipMemsetAsync(out2, 0, 2 * sizeof(int64_t), st));
+  if (N > 0) {
+    int64_t nb = (N + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    if (dtype == CVM_F64)
+      hipLaunchKernelGGL(weights_check_kernel<double>, dim3((unsigned)nb), dim3(256), 0, st, (const double *)w, N,
+                         (unsigned long long *)out2);
+    else
+      hipLaunchKernelGGL(weights_check_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float *)w, N,
+                         (unsigned long long *)out2);
+  }
+  HIP_OK(hipGetLastError());
+  return CVM_OK;
+}

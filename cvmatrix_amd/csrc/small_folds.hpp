@@ -39,14 +39,7 @@ struct SmallArgs {
   int rshift;                          // small_apply_kernel: 1 << rshift row slots per fold (32, 64, 128); fpb << rshift <= 256
   int gx, gy;                          // small_apply_kernel: tiles + panels, fold groups
   int x0;                              // small_apply_kernel: first tile / panel number of this launch
-  // small_tile_kernel (small_tile.hpp): the per-fold records small_stats_kernel leaves for it
-  char *rec;                           // nullptr: no records
-  unsigned rec_stride, rec_mu, rec_isd, rec_rows, rec_w;
-  int tsteps;                          // k-steps one operand buffer holds
-  int nbuf;                            // operand buffers (2 or 3): the DMAs of fold f + nbuf - 1 are issued at the top of fold f
   int noremap;                         // 1: workgroup b works on item b (no XCD-contiguous ranges)
-  int dbg;                             // small_tile_kernel, measurements only (CVM_TILE_DEBUG; results are wrong): 1 no MFMA
-                                       // loop, 2 no operand DMAs, 4 no transpose before the stores
 };
 
 template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void small_stats_kernel(const SmallArgs a) {
@@ -70,17 +63,6 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
   const double swt = gsw - swv, nzt = gnz - nzv;
   const double divisor = (nzt - a.ddof) * swt / nzt;
   double *fs = a.fstats + (size_t)f * fstat_len(K, M);
-  char *rec = a.rec ? a.rec + (size_t)f * a.rec_stride : nullptr;
-  if (rec && blockIdx.y == 0 && threadIdx.x < SMALL_ROWS) {
-    // the fold's row numbers and weights where small_tile_kernel finds them with one load
-    const bool in = (int)threadIdx.x < n;
-    reinterpret_cast<int64_t *>(rec + a.rec_rows)[threadIdx.x] = in ? rows[threadIdx.x] : (int64_t)-1;
-    reinterpret_cast<T *>(rec + a.rec_w)[threadIdx.x] = in ? (T)wl[threadIdx.x] : (T)0;
-    if (threadIdx.x == 0) {
-      *reinterpret_cast<int *>(rec) = n;
-      *reinterpret_cast<double *>(rec + 8) = swt;
-    }
-  }
   if (threadIdx.x == 0 && blockIdx.y == 0) {
     fs[2 * K + 2 * M] = swt;
     if (a.out_fold) {
@@ -134,10 +116,6 @@ template <typename T, bool WEIGHTED> __global__ __launch_bounds__(256) void smal
     }
     fs[isX ? cc : 2 * K + cc] = mu;
     fs[isX ? K + cc : 2 * K + M + cc] = 1.0 / sd;     // reciprocal: the finish multiplies (finalize.hpp)
-    if (rec && isX) {
-      reinterpret_cast<T *>(rec + a.rec_mu)[cc] = (T)mu;
-      reinterpret_cast<T *>(rec + a.rec_isd)[cc] = (T)(1.0 / sd);
-    }
     T *omu = (T *)(isX ? a.out_muX : a.out_muY), *osd = (T *)(isX ? a.out_sdX : a.out_sdY);
     const size_t o = (size_t)(a.seg0 + f) * (isX ? K : M) + cc;
     if (omu) omu[o] = (T)mu;

@@ -97,7 +97,8 @@ class FoldBatch:
     def __init__(self, idx, offsets, host_offsets, nz_val, labels=None, host_idx=None, n_rows=0,
                  device=None, w_gen=None):
         self._idx, self._offsets = idx, offsets
-        self.host_offsets, self.nz_val, self.labels = host_offsets, nz_val, labels
+        self.host_offsets, self._nz_val, self.labels = host_offsets, nz_val, labels
+        self._nz_fn = None      # nz_val not counted yet (weights validated on the device): how to count them
         self._host_idx, self._n_rows, self._is_partition = host_idx, n_rows, None
         self._sizes = None
         self._device = device
@@ -127,6 +128,24 @@ class FoldBatch:
         if self._offsets is None:
             self._upload()
         return self._offsets
+
+    # every fold's number of validation rows with a non-zero weight.  With weights that were validated on the
+    # device (CVMatrix(validate_weights="deferred")) they are NOT counted when the batch is made: the raises they
+    # feed (cvmatrix.py:612-630, 1074-1078) are first decided on a bound that needs no per-fold count
+    # (CVMatrix._validate), and counted exactly -- here, on first access -- only when that bound does not decide
+    @property
+    def nz_val(self):
+        if self._nz_val is None and self._nz_fn is not None:
+            self._nz_val = self._nz_fn(self)
+        return self._nz_val
+
+    @nz_val.setter
+    def nz_val(self, v) -> None:
+        self._nz_val = v
+
+    @property
+    def nz_known(self) -> bool:
+        return self._nz_val is not None
 
     @property
     def is_partition(self) -> bool:
@@ -176,6 +195,7 @@ class CVMatrix:
         serve_loops: Optional[bool] = None,
         reuse_outputs: bool = False,
         trust_tensor_versions: Optional[bool] = None,
+        validate_weights: Optional[str] = None,
     ) -> None:
         # ``lazy_fit=None`` (default): ``fit`` may defer its arithmetic to the first use only
         # when the object owns private copies of its inputs (``copy=True``, like the reference's
@@ -217,6 +237,27 @@ class CVMatrix:
         if trust_tensor_versions is None:
             trust_tensor_versions = os.environ.get("CVM_TRUST_VERSIONS", "0") != "0"
         self.trust_tensor_versions = bool(trust_tensor_versions)
+        # ``validate_weights`` -- where weights handed to ``fit`` as a DEVICE tensor are checked (weights given as
+        # host arrays are always checked inside ``fit``, before they are uploaded: cvmatrix.py:1188-1189):
+        #   "deferred" (default; CVM_VALIDATE_WEIGHTS overrides the default): on the device.  ``fit`` launches one
+        #       small kernel that counts the negative and the non-zero weights (cvm_weights_check) and copies the two
+        #       counts to pinned memory asynchronously; nothing is read back and the host does not wait.
+        #       ``ValueError("Weights must be non-negative.")`` is raised by the first call that hands out a result
+        #       or an attribute of that fit -- behind its launches, in front of its return -- the way the reference's
+        #       JAX backend defers its data-dependent raises (cvmatrix.py:621-625, 1071-1074).  Per-fold counts of
+        #       non-zero weights (the "... must be greater than zero / than `ddof`" raises) are decided on a bound
+        #       that needs only the total (a fold cannot hold more non-zero weights than rows) and counted exactly
+        #       only where that bound does not decide.
+        #   "sync": ``fit`` reads the weights back (one blocking 8 N byte copy) and raises itself, like rounds 1-5.
+        if validate_weights is None:
+            validate_weights = os.environ.get("CVM_VALIDATE_WEIGHTS", "deferred")
+        if validate_weights not in ("deferred", "sync"):
+            raise ValueError(f"Invalid validate_weights: {validate_weights!r}. Must be 'deferred' or 'sync'.")
+        self.validate_weights = validate_weights
+        self._wchk = False              # a deferred weights check is pending (its counts are on their way)
+        self._wchk_bufs = None          # (device int64[2], pinned int64[2], event)
+        self._w_verified = False        # the current weights passed a deferred check
+        self._w_bad = False             # ... or failed it: every hand-out raises until the next fit
         self._arena = {}
         self._fit_src = None
         # ``output="numpy"``: every result (matrices, statistics, the XTX/XTY/sum_* attributes)
@@ -312,6 +353,10 @@ class CVMatrix:
 
     def _np_result(self, t):
         a = t.cpu().numpy()
+        # (the conversion has just waited for the stream: the fold stage's status word costs one more small read
+        #  here -- a call whose results are poisoned raises instead of handing NaN out as numbers)
+        if self.__dict__.get("_fold_status"):
+            self._raise_if_poisoned()
         return a if self._out_cast is None else a.astype(self._res_npdt)
 
     # Results whose last dimensions are the DEVICE dims (the columns of the private device copies
@@ -384,6 +429,7 @@ class CVMatrix:
     @property
     def XTX(self):
         self._ensure_fit()
+        self._resolve_weights_check()
         return self._oXX(self._G, "XTX")
 
     @XTX.setter
@@ -393,6 +439,7 @@ class CVMatrix:
     @property
     def XTY(self):
         self._ensure_fit()
+        self._resolve_weights_check()
         return self._oXY(self._H, "XTY")
 
     @XTY.setter
@@ -598,15 +645,26 @@ class CVMatrix:
                         raise ValueError("X and Y must have the same number of rows")
                 else:
                     self.Y, self._Mu, self._Md = None, None, None
+                self._wchk = False
                 if weights is not None:
-                    self._check_weights_host(weights, trust)
-                    self.weights = self._init_mat(weights)
-                    if self.weights.shape != (self.N, 1):
-                        raise ValueError("weights must have shape (N,) or (N, 1)")
+                    on_dev = isinstance(weights, torch.Tensor) and weights.device.type != "cpu"
+                    if on_dev and self.validate_weights == "deferred":
+                        known = trust and self._weights_known(weights)
+                        self.weights = self._init_mat(weights)
+                        if self.weights.shape != (self.N, 1):
+                            raise ValueError("weights must have shape (N,) or (N, 1)")
+                        if not known:
+                            self._defer_weights_check(lib, weights)
+                    else:
+                        self._check_weights_host(weights, trust)
+                        self.weights = self._init_mat(weights)
+                        if self.weights.shape != (self.N, 1):
+                            raise ValueError("weights must have shape (N,) or (N, 1)")
                 else:
                     if self.weights is not None or self._w_host is not None:
                         self._w_gen = _NO_WEIGHTS
                     self.weights, self._w_host, self._w_checked, self._w_checked_src = None, None, None, None
+                    self._w_verified = self._w_bad = False
                 self._remember_fit_inputs(X, Y, weights)      # (what a LATER fit may be told is unchanged)
             M = self._Md or 0
             self._alloc_globals(lib.cvm_gstats_len(self._Kd, M))
@@ -737,11 +795,64 @@ class CVMatrix:
             key = src = None
         if self._out_cast == "half":
             h = np.asarray(h).astype(np.float16)      # (non-zero counts are taken after the rounding, like the reference's)
+        self._w_verified = self._w_bad = False
         if bool(np.any(h < 0)):
             raise ValueError(MSG_NEG_W)
         self._w_host = np.array(h, dtype=self._npdt, copy=True)
         self._w_checked, self._w_checked_src = key, src
         self._w_gen = _WeightsToken()
+
+    # ---- weights validated on the device (validate_weights="deferred") -------------------------------------
+    def _weights_known(self, weights) -> bool:
+        """Is ``weights`` the very tensor -- unmodified since, by torch's version counter -- whose check (on the host,
+        on the device, or still on its way) belongs to the object's current weights?"""
+        return bool(self.serve_loops and weights is self._w_checked_src and self._weights_key(weights) == self._w_checked
+                    and (self._w_host is not None or self._w_verified or self._wchk) and not self._w_bad)
+
+    def _defer_weights_check(self, lib, src) -> None:
+        """cvmatrix.py:1188-1189 and 1226 for device weights, without a read-back: [#(w < 0), #(w != 0)] of the
+        object's own device copy (rounded like the reference rounds: _init_mat) by one small launch, copied to
+        pinned memory behind it; ``_resolve_weights_check`` reads them."""
+        bufs = self._wchk_bufs
+        if bufs is None or bufs[0].device != self.device:
+            bufs = self._wchk_bufs = (torch.empty(2, dtype=torch.int64, device=self.device),
+                                      torch.empty(2, dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+        d, h, ev = bufs
+        _lib.check(lib.cvm_weights_check(self.weights.data_ptr(), self.N, self._cdt, d.data_ptr(), self._stream()),
+                   "cvm_weights_check")
+        h.copy_(d, non_blocking=True)
+        ev.record()
+        self._wchk, self._w_verified, self._w_bad = True, False, False
+        self._w_host = None
+        self._w_checked, self._w_checked_src = self._weights_key(src), src
+        self._w_gen = _WeightsToken()
+
+    def _resolve_weights_check(self) -> None:
+        """Await the counts of a deferred check (a wait for one small kernel that was enqueued BEFORE the Gram
+        launch of its step: the device keeps working) and raise like ``fit`` would have.  A fit whose weights
+        failed raises at every hand-out until the next fit."""
+        if self._wchk:
+            self._wchk = False
+            _, h, ev = self._wchk_bufs
+            ev.synchronize()
+            neg, nz = int(h[0]), int(h[1])
+            if neg:
+                self._w_bad = True
+            else:
+                self._w_verified = True
+                self._nz_total_w, self._nz_total_gen = nz, self._w_gen
+                if self._nz_total is None:
+                    self._nz_total = nz
+        if self._w_bad:
+            raise ValueError(MSG_NEG_W)
+
+    def _host_weights(self) -> Optional[np.ndarray]:
+        """The weights on the host (exact per-fold counts of non-zero weights need them): read back on first
+        need when they were validated on the device."""
+        if self._w_host is None and self.weights is not None:
+            self._resolve_weights_check()
+            self._w_host = np.array(self.weights.detach().reshape(-1).cpu().numpy(), dtype=self._npdt, copy=True)
+        return self._w_host
 
     def _publish_stats(self) -> None:
         """Host-side totals used by the per-fold validity checks.  ``_n_total`` /
@@ -751,18 +862,21 @@ class CVMatrix:
         self._n_total = self.N
         if self.weights is None:
             self._nz_total = self.N
+        elif self._wchk:
+            self._nz_total = None                          # (on its way from the device: _resolve_weights_check)
         else:
             if self._nz_total_gen is not self._w_gen:      # (once per set of weights, not per fit)
-                self._nz_total_w, self._nz_total_gen = int(np.count_nonzero(self._w_host)), self._w_gen
+                self._nz_total_w, self._nz_total_gen = int(np.count_nonzero(self._host_weights())), self._w_gen
             self._nz_total = self._nz_total_w
 
     def _resolve_totals(self) -> None:
-        """Hook: make ``_n_total`` / ``_nz_total`` current (multi-GPU subclasses fetch the
-        all-reduced counts here)."""
+        """Make ``_n_total`` / ``_nz_total`` current: the counts of a deferred weights check (multi-GPU
+        subclasses then fetch the all-reduced counts)."""
+        self._resolve_weights_check()
 
     def _totals_in_flight(self) -> bool:
-        """Hook: True while those counts are still on the device (a multi-GPU exchange)."""
-        return False
+        """True while those counts are still on the device (a deferred weights check; a multi-GPU exchange)."""
+        return bool(self._wchk)
 
     def _request_totals(self) -> None:
         """Hook: start fetching those counts (asynchronously; ``_resolve_totals`` waits)."""
@@ -773,11 +887,17 @@ class CVMatrix:
         weights than ``ddof`` (and than zero), neither of the reference's raises
         (cvmatrix.py:612-630, 1074-1078) can fire whatever the other ranks hold, and the check
         needs no read-back at all."""
+        if self._wchk or self._w_bad:
+            return False                               # (the sign of the weights is still to be seen)
         if not need_stats:
             return True
         sel = slice(None) if only is None else slice(only, only + 1)
         if self.weights is not None:
-            lb = self._nz_total - batch.nz_val[sel]
+            if self._nz_total is None:
+                return False
+            # (per-fold counts not taken -- weights validated on the device --: a fold holds at most as many
+            #  non-zero weights as rows, still a lower bound)
+            lb = self._nz_total - (batch.nz_val[sel] if batch.nz_known else batch.sizes[sel])
         else:
             lb = self._n_total - batch.sizes[sel]
         return bool(lb.size == 0 or int(lb.min()) > max(int(np.ceil(self.ddof)) if need_std else 0, 0))
@@ -785,6 +905,7 @@ class CVMatrix:
     def _gslice(self, lo: int, hi: int, cond: bool):
         if not cond or self._gstats is None:
             return None
+        self._resolve_weights_check()
         return self._out(self._gstats[lo:hi].to(self._tdt).reshape(1, -1), ("gstats", lo, hi))
 
     # The reference's global statistics attributes, present under the reference's flag
@@ -835,6 +956,7 @@ class CVMatrix:
             return self._n_total
         if self._sum_w is None:
             K, M = self._Kd, self._Md or 0
+            self._resolve_weights_check()
             self._sum_w = self.dtype(self._gstats[2 * K + 2 * M].item())
         return self._sum_w
 
@@ -869,7 +991,10 @@ class CVMatrix:
                     f"this FoldBatch was prepared for {folds._n_rows} samples, the fitted "
                     f"data has {self.N}: prepare the folds again after fit()")
             if folds._w_gen is not self._w_gen:
-                folds.nz_val = self._nz_counts(folds)
+                if self.weights is not None and self._w_host is None:
+                    folds.nz_val, folds._nz_fn = None, self._nz_counts      # (counted on first need: FoldBatch.nz_val)
+                else:
+                    folds.nz_val = self._nz_counts(folds)
                 folds._w_gen = self._w_gen
             return folds
         labels = None
@@ -911,7 +1036,8 @@ class CVMatrix:
             idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
         host_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
         np.cumsum(sizes, out=host_offsets[1:])
-        nz_val = self._nz_counts_host(idx, host_offsets, sizes)
+        lazy_nz = self.weights is not None and self._w_host is None   # (weights validated on the device)
+        nz_val = None if lazy_nz else self._nz_counts_host(idx, host_offsets, sizes)
         # one host->device copy for both arrays, [offsets | idx], through a pinned staging
         # buffer and asynchronous on the stream: a pageable copy would hold the host until the
         # device has drained the stream, and the per-fold call pattern (one small copy per
@@ -922,13 +1048,17 @@ class CVMatrix:
             # the host's; the plain copy costs the host less than staging does
             if len(parts) == 1:
                 # the reference's call pattern, one small fold per call: no device copy at all
-                return FoldBatch(None, None, host_offsets, nz_val, labels,
-                                 np.ascontiguousarray(idx, dtype=np.int64), self.N, device=self.device,
-                                 w_gen=self._w_gen)
+                fb = FoldBatch(None, None, host_offsets, nz_val, labels,
+                               np.ascontiguousarray(idx, dtype=np.int64), self.N, device=self.device,
+                               w_gen=self._w_gen)
+                fb._nz_fn = self._nz_counts if lazy_nz else None
+                return fb
             with torch.cuda.device(self.device):
                 d_all = torch.from_numpy(np.concatenate([host_offsets, idx])).to(self.device)
-            return FoldBatch(d_all[n_off:], d_all[:n_off], host_offsets, nz_val, labels, idx, self.N,
-                             w_gen=self._w_gen)
+            fb = FoldBatch(d_all[n_off:], d_all[:n_off], host_offsets, nz_val, labels, idx, self.N,
+                           w_gen=self._w_gen)
+            fb._nz_fn = self._nz_counts if lazy_nz else None
+            return fb
         with torch.cuda.device(self.device):
             stage = self._staging(n_all)
             view = stage.numpy()
@@ -939,6 +1069,7 @@ class CVMatrix:
             self._stage_events[self._stage_next - 1].record()
         d_off, d_idx = d_all[:n_off], d_all[n_off:]
         fb = FoldBatch(d_idx, d_off, host_offsets, nz_val, labels, idx, self.N, w_gen=self._w_gen)
+        fb._nz_fn = self._nz_counts if lazy_nz else None
         fb._source = source
         fb._device = self.device
         if self.serve_loops and source is not None and len(parts) <= 4096:
@@ -975,9 +1106,9 @@ class CVMatrix:
     def _nz_counts_host(self, idx: np.ndarray, host_offsets: np.ndarray, sizes: np.ndarray) -> np.ndarray:
         """Non-zero weights among each fold's validation rows (exact integer counts for the
         host-side raises, cvmatrix.py:612-630, 1074-1078)."""
-        if self._w_host is None:
+        if self.weights is None:
             return sizes.copy()
-        wh = self._w_host
+        wh = self._host_weights()
         if self._nz_mask is None or self._nz_mask[0] is not wh:
             self._nz_mask = (wh, (wh != 0).astype(np.int64))   # once per fit
         nzmask = self._nz_mask[1]
@@ -1138,12 +1269,20 @@ class CVMatrix:
         only: cvmatrix.py:612-630; then ddof: 1074-1078), decided on exact host counts.
         ``only``: check fold ``only`` of the batch alone."""
         if not need_stats:
+            self._resolve_weights_check()
             return
         if self._totals_in_flight() and self._passes_on_local_counts(batch, need_stats, need_std, only):
             return
         self._resolve_totals()
         sel = slice(None) if only is None else slice(only, only + 1)
         if self.weights is not None:
+            if not batch.nz_known and self._nz_total is not None:
+                # weights validated on the device, per-fold counts not taken: a fold cannot hold more non-zero
+                # weights than rows -- if even that leaves every training set more than ``ddof`` (and than zero),
+                # neither raise can fire and the exact counts are never needed
+                sz = batch.sizes[sel]
+                if sz.size == 0 or self._nz_total - int(sz.max()) > max(int(np.ceil(self.ddof)) if need_std else 0, 0):
+                    return
             nz_train = self._nz_total - batch.nz_val[sel]
             if np.any(nz_train == 0):
                 raise ValueError(MSG_NZ_ZERO)
@@ -1239,9 +1378,13 @@ class CVMatrix:
                 p_idx, p_off = batch._host_idx.ctypes.data, batch.host_offsets.ctypes.data
             else:
                 p_idx, p_off = batch.idx.data_ptr(), batch.offsets.data_ptr()
-            status = self.__dict__.get("_fold_status_t")
-            if status is None or status.device != dev:
-                status = self._fold_status_t = torch.zeros(1, dtype=torch.int32, device=dev)
+            # (one status word per device and stream this object has launched on: words of launches in flight on
+            #  other streams are never reset under them)
+            words = self.__dict__.setdefault("_fold_status", {})
+            skey = (dev.index, self._stream())
+            status = words.get(skey)
+            if status is None:
+                status = words[skey] = torch.zeros(1, dtype=torch.int32, device=dev)
             rc = lib.cvm_fold_update_ex(
                 self.X.data_ptr(), _lib.ptr(self.Y), _lib.ptr(self.weights),
                 p_idx, p_off,
@@ -1256,18 +1399,27 @@ class CVMatrix:
         return out_XTX, out_XTY, (muX, sdX, muY, sdY), out_fold
 
     def fold_status(self, reset: bool = True) -> int:
-        """Status word of the fold-stage calls made so far (``cvm_fold_update_ex``; one device read, it
-        waits for the stream): 0 = no work item ever gave up waiting for another, 2 = some did and were
-        recomputed inside their call (every result valid), 1 = results of some call hold NaN (a fault:
-        the reference's contract is "raise or return correct numbers", cvmatrix.py:754-896, and the
-        caller who wants to raise can).  ``reset`` zeroes the word."""
-        t = self.__dict__.get("_fold_status_t")
-        if t is None:
-            return 0
-        v = int(t.item())
-        if reset and v:
-            t.zero_()
-        return v
+        """Status of the fold-stage calls made so far (``cvm_fold_update_ex``; one small device read per stream the
+        object has launched on, each waits for its stream): 0 = no work item ever gave up waiting for another, 2 =
+        some did and were recomputed inside their call (every result valid), 1 = results of some call hold NaN (a
+        fault: the reference's contract is "raise or return correct numbers", cvmatrix.py:754-896).  ``reset``
+        zeroes the words.  Results handed out as NumPy arrays (``output="numpy"``) are checked for status 1 by the
+        conversion itself (it has to wait for the device anyway) and raise ``RuntimeError``; results left on the
+        device are the caller's to check -- with this method -- before they are trusted: an asynchronous API cannot
+        raise for a launch that has not run yet."""
+        worst = 0
+        for t in self.__dict__.get("_fold_status", {}).values():
+            v = int(t.item())
+            if reset and v:
+                t.zero_()
+            worst = 1 if (v == 1 or worst == 1) else max(worst, v)
+        return worst
+
+    def _raise_if_poisoned(self) -> None:
+        if self.fold_status(reset=False) == 1:
+            self.fold_status(reset=True)
+            raise RuntimeError("cvmatrix_amd: a work item of the fold stage gave up waiting for another in both of its "
+                               "launches; the affected results hold NaN (CVMatrix.fold_status() == 1)")
 
     def _own_results(self, xtx, xty, stats):
         """Results of ``_run`` that the object is about to KEEP (the slices a per-fold loop is served from):
@@ -1494,6 +1646,7 @@ class CVMatrix:
         ra.need_stats, ra.need_std = bool(r_muX or r_muY or r_sdX or r_sdY), bool(r_sdX or r_sdY)
         # the reference's raises (cvmatrix.py:612-630, 1074-1078), decided for the whole chunk
         ra.bad_zero = ra.bad_ddof = None
+        self._resolve_weights_check()
         if ra.need_stats:
             self._resolve_totals()
             if self.weights is not None:
@@ -1560,10 +1713,11 @@ class CVMatrix:
         r_muY = rXTY and (cX or cY)
         r_sdX = sX
         r_sdY = rXTY and sY
+        self._resolve_weights_check()
         if r_muX or r_muY or r_sdX or r_sdY:        # the reference's raises, in its order (_validate)
             self._resolve_totals()
             if self.weights is not None:
-                wh = self._w_host
+                wh = self._host_weights()
                 nz_val = int(np.count_nonzero(wh[v])) if n > 1 else int(wh[v[0]] != 0)
                 nz_train = self._nz_total - nz_val
                 if nz_train == 0:

@@ -217,9 +217,10 @@ class ShardedCVMatrix(CVMatrix):
         return self.world > 1
 
     def _totals_in_flight(self) -> bool:
-        return bool(self._tail_pending)
+        return bool(self._tail_pending) or super()._totals_in_flight()
 
     def _resolve_totals(self) -> None:
+        super()._resolve_totals()               # (this rank's own weights: a deferred check raises here)
         if not self._tail_pending:
             return
         self._request_totals()

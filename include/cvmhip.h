@@ -199,6 +199,15 @@ int cvm_partition_labels(const int64_t *labels, int64_t N, int64_t n_labels, int
                          int64_t *offsets_out, int64_t *first_out, int32_t *err_flag, void *ws,
                          size_t ws_bytes, void *stream);
 
+/* The fit stage's weight validation for weights that live on the device -- cvmatrix/cvmatrix.py:1188-1189
+ * (`any(weights < 0)` -> ValueError("Weights must be non-negative.")) and :1226 (`count_nonzero(weights)`):
+ * out2 (device, int64[2]) receives [#(w < 0), #(w != 0)] as exact integer counts, by one small launch on
+ * `stream`.  The host class copies the two words to pinned memory asynchronously and reads them when a
+ * result of that fit is first handed out, so fit() neither reads the weights back nor waits for the device
+ * (the reference's own JAX backend defers its data-dependent raises the same way, cvmatrix.py:621-625,
+ * 1071-1074). */
+int cvm_weights_check(const void *w, int64_t N, int dtype, int64_t *out2, void *stream);
+
 /* Labels that are arange(N) % n_labels (the reference benchmark's folds, benchmarks/benchmark.py:232;
  * n_labels == N: leave-one-out) need no sort.  One launch: checks the labels (not_periodic[0] = 1 if
  * they are anything else -- the outputs are then garbage and the caller runs cvm_partition_labels),
@@ -285,6 +294,13 @@ int cvm_fill_probe(void *buf, size_t bytes, void *stream);
  * roofline.effective_clock_mhz.  The caller synchronises before it reads the buffer, and clears the probe
  * before it frees it.  No reference counterpart: the reference has no device. */
 int cvm_clock_probe(void *device_buf, size_t bytes);
+
+/* Experiments and tests: pin the row-split plan of every later call of this process to (s_off, s_diag) row
+ * splits of the off-diagonal / diagonal tile items (clamped to what the problem allows); (0, 0) hands the
+ * decision back to the planner.  Stored in one atomic word; the environment variable CVM_FORCE_SPLITS="a,b" is
+ * read once, as its initial value.  Results stay within the parity bar under any plan (float32: one more
+ * rounding per extra partial, cvmatrix_amd/fp32_gate.py).  No reference counterpart. */
+int cvm_debug_force_splits(int s_off, int s_diag);
 
 /* Introspection for benchmarks/profiles: geometry chosen for a problem (info: int64[8]).
  * info[0]=row splits per fold of the off-diagonal 128x128 tiles, [6]=row splits of the diagonal

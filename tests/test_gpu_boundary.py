@@ -92,14 +92,24 @@ def test_default_fit_is_eager_for_aliased_inputs_and_lazy_for_private_copies(amd
 
 
 @pytest.mark.serving
-def test_weights_are_validated_again_when_a_new_tensor_reuses_the_address(amd, hip_device):
-    """the device-weights validation cache must not be fooled by a recycled address."""
+@pytest.mark.parametrize("mode", ["sync", "deferred"])
+def test_weights_are_validated_again_when_a_new_tensor_reuses_the_address(amd, hip_device, mode):
+    """the device-weights validation cache must not be fooled by a recycled address.  Both validation
+    modes: ``sync`` raises inside fit() (a read-back), ``deferred`` (the default) at the first hand-out of that
+    fit (counts taken on the device, nothing read back)."""
     import torch
+
+    def refused(m, *a, **kw):
+        """fit + first use: the reference's raise, from fit (sync) or from the first result (deferred)"""
+        with pytest.raises(ValueError, match="Weights must be non-negative."):
+            m.fit(*a, **kw)
+            assert mode == "deferred"                      # (sync never gets here)
+            m.training_XTX(np.arange(10))
 
     rng = np.random.default_rng(4)
     N = 5000
     X = torch.from_numpy(rng.random((N, 16))).to(hip_device)
-    m = amd.CVMatrix(copy=True)
+    m = amd.CVMatrix(copy=True, validate_weights=mode)
     hit = False
     for _ in range(20):
         w = torch.rand(N, dtype=torch.float64, device=hip_device)
@@ -111,25 +121,43 @@ def test_weights_are_validated_again_when_a_new_tensor_reuses_the_address(amd, h
         w2[7] = -1.0
         w2 = w2.clone() if w2.data_ptr() != addr else w2      # whatever address it got
         hit = hit or (w2.data_ptr() == addr)
-        with pytest.raises(ValueError, match="Weights must be non-negative."):
-            m.fit(X, None, w2)
+        refused(m, X, None, w2)
         del w2
-    # by default every fit reads its inputs again, like the reference (cvmatrix.py:207-328) ...
+    # by default every fit checks its inputs again, like the reference (cvmatrix.py:207-328) ...
     w = torch.rand(N, dtype=torch.float64, device=hip_device)
-    m = amd.CVMatrix(copy=True, serve_loops=True)
+    m = amd.CVMatrix(copy=True, serve_loops=True, validate_weights=mode)
     m.fit(X, None, w)
-    host = m._w_host
-    m.fit(X, None, w)
-    assert m._w_host is not host
-    # ... a caller who says the tensors are unchanged is believed as far as torch's version counters agree
-    # (no second read-back of the same unmodified tensor object) ...
-    host = m._w_host
-    m.fit(X, None, w, assume_unchanged=True)
-    assert m._w_host is host
+    m.training_XTX(np.arange(10))
+    if mode == "sync":
+        host = m._w_host
+        m.fit(X, None, w)
+        assert m._w_host is not host
+        # ... a caller who says the tensors are unchanged is believed as far as torch's version counters agree
+        # (no second read-back of the same unmodified tensor object) ...
+        host = m._w_host
+        m.fit(X, None, w, assume_unchanged=True)
+        assert m._w_host is host
+    else:
+        assert m._w_host is None and m._w_verified          # counted on the device, never read back
+        gen = m._w_gen
+        m.fit(X, None, w)
+        assert m._wchk and m._w_gen is not gen             # checked again (a new check is on its way)
+        m.training_XTX(np.arange(10))
+        gen = m._w_gen
+        m.fit(X, None, w, assume_unchanged=True)
+        assert not m._wchk and m._w_gen is gen             # believed: no new check
     # ... until the tensor is modified in place
     w[3] = -2.0
-    with pytest.raises(ValueError, match="Weights must be non-negative."):
-        m.fit(X, None, w, assume_unchanged=True)
+    refused(m, X, None, w, assume_unchanged=True)
+    if mode == "deferred":
+        # a fit whose weights failed keeps raising at every hand-out, attributes included, until the next fit
+        with pytest.raises(ValueError, match="Weights must be non-negative."):
+            m.XTX
+        with pytest.raises(ValueError, match="Weights must be non-negative."):
+            m.training_statistics(np.arange(10))
+        w[3] = 0.5
+        m.fit(X, None, w)
+        m.training_XTX(np.arange(10))
 
 
 def test_writes_behind_torchs_back_are_seen_unless_the_caller_vouches_for_the_tensors(amd, hip_device):
@@ -155,7 +183,8 @@ def test_writes_behind_torchs_back_are_seen_unless_the_caller_vouches_for_the_te
         X.data.mul_(0.5)
         w.data[5] = -1.0
         with pytest.raises(ValueError, match="Weights must be non-negative."):
-            m.fit(X, None, w)
+            m.fit(X, None, w)                                          # (deferred validation: raised by the first use)
+            m.XTX
         w.data[5] = 0.5
         t = amd.CVMatrix(copy=True, lazy_fit=lazy, trust_tensor_versions=True, serve_loops=True)
         t.fit(X, None, w)

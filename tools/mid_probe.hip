@@ -32,7 +32,6 @@ namespace {
 #include "../cvmatrix_amd/csrc/finalize.hpp"
 #include "../cvmatrix_amd/csrc/colstats.hpp"
 #include "../cvmatrix_amd/csrc/small_folds.hpp"
-#include "../cvmatrix_amd/csrc/small_tile.hpp"
 #include "../cvmatrix_amd/csrc/mid_tile.hpp"
 #include "experiments/mid_chain.hpp"
 #include "experiments/mid128.hpp"
