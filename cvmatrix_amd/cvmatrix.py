@@ -1849,6 +1849,7 @@ class CVMatrix:
         r_muX, r_sdX = (cX or sX), sX
         r_muY, r_sdY = ((cY or sY) and hasY), (sY and hasY)
         if not (r_muX or r_sdX or r_muY or r_sdY):
+            self._resolve_weights_check()          # (nothing to compute; the reference's fit() would still have raised)
             return None, None, None, None
         self._ensure_fit()
         self._validate(batch, True, r_sdX or r_sdY)

@@ -1836,15 +1836,18 @@ def test_negative_device_weights_raise_in_fit_or_at_the_first_hand_out(amd):
                 lambda m: m.num_nonzero_w, lambda m: m.sum_w,
                 lambda m: [m.training_XTX_XTY(v) for v in amd.Partitioner(np.arange(200)).folds_dict.values()]]
         for flags in ((True,) * 4, (False,) * 4):
-            for use in uses:
+            for iu, use in enumerate(uses):
                 m = amd.CVMatrix(*flags, lazy_fit=lazy)
                 m.fit(X, Y, w)                                         # returns: nothing has been read back
-                if flags[0] is False and use in uses[6:9]:
+                if flags[0] is False and 6 <= iu <= 8:
                     continue                                           # (those attributes are None without flags)
-                with pytest.raises(ValueError, match=msg):
-                    use(m)
-                with pytest.raises(ValueError, match=msg):             # ... and keeps raising
-                    use(m)
+                for again in (0, 1):                                   # ... and keeps raising
+                    try:
+                        use(m)
+                    except ValueError as e:
+                        assert msg in str(e)
+                    else:
+                        raise AssertionError(f"use {iu} (flags {flags[0]}, lazy {lazy}, attempt {again}) did not raise")
     # host arrays are always checked inside fit(), before anything is uploaded
     with pytest.raises(ValueError, match=msg):
         amd.CVMatrix().fit(X.cpu().numpy(), None, w.cpu().numpy())
