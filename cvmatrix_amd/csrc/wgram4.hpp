@@ -33,6 +33,19 @@ constexpr int NT4 = 512;
 #ifndef CVM_INTERLEAVE
 #define CVM_INTERLEAVE 1
 #endif
+// Shape of a compute wave's block of a plain off-diagonal tile (round 6).  64 x 64 (4 x 4 MFMA tiles: 4 A-side and
+// 4 B-side fragments per k-step) was the shape of rounds 1-5; 32 x 128 (2 x 8: wave w owns rows 32 w .. 32 w + 31 of
+// the tile and all of its columns) reads 10 fragments instead of 8 but WEIGHTS only 2 instead of 4 -- the A side is
+// the weighted one, and every element of the A panel is then multiplied by exactly one wave, the minimum.
+// tools/f32_loop_probe.hip: a vector instruction inside the MFMA stream costs the matrix pipe ~12 cycles in float32
+// (the float32 MFMA runs on the vector unit's own multipliers: the two are one resource), the 16 weighting
+// multiplies of a stage 8 % of the loop; with 8 of them 0.862 -> 0.890 of the peak in the probe.  Per element type:
+#ifndef CVM_WIDE_F32
+#define CVM_WIDE_F32 1
+#endif
+#ifndef CVM_WIDE_F64
+#define CVM_WIDE_F64 1
+#endif
 constexpr int NBUF4 = 4;        // LDS stage buffers
 constexpr size_t LDS4_BYTES = (size_t)NBUF4 * BUF_ELEMS * 8;   // float64; float32 uses half of it
 template <typename T> constexpr size_t lds4_bytes() { return (size_t)NBUF4 * BUF_ELEMS * sizeof(T); }
@@ -473,8 +486,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
   double st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};
 
   const int lk = lane >> 4, lc = lane & 15;
-  const int a_col = h_wave ? 0 : 64 * wr;
-  const int b_col = h_wave ? 0 : 64 * wc;
+  // (the plain off-diagonal wave of the two-stage / sweep routes: a 32 x 128 block, see CVM_WIDE_*)
+  constexpr bool WIDE = !HWR && MFMR && ROLER == 0 && !FUSEDR && (sizeof(T) == 4 ? CVM_WIDE_F32 : CVM_WIDE_F64);
+  const int a_col = h_wave ? 0 : (WIDE ? 32 * wave : 64 * wr);
+  const int b_col = h_wave ? 0 : (WIDE ? 0 : 64 * wc);
   const int a_off = a_col + lc;
   const int b_off = h_wave ? PANEL_ELEMS + lc : (diag ? 0 : PANEL_ELEMS) + b_col + lc;
 
@@ -498,7 +513,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
   // clock rises, about 1 % measured.  Dropping the padded second column tile of the H wave the
   // same way made the gathered variant 1.7 % slower -- code placement -- and was not kept.)
   constexpr bool TRI = (ROLE == 1) && !HW;
-  constexpr int NA = HW ? 8 : 4, NB = HW ? 2 : 4;
+  constexpr int NA = HW ? 8 : (WIDE ? 2 : 4), NB = HW ? 2 : (WIDE ? 8 : 4);
   // Fragments of the NEXT k-step are read while the current one computes, across the
   // stage barrier too (the loaders guarantee stage s+1 is in LDS before stage s starts);
   // the next k-step's weighting (and column sums) sit in the middle of the current
@@ -589,8 +604,14 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
         const int r = 4 * (ks < 3 ? ks + 1 : 0) + lk;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          acc[i] = MF<T>::mfma(af[c][i >> 2], bf[c][i & 3], acc[i]);
-          if (i < 4) af[c ^ 1][i] = rb[a_off + r * PITCH + 16 * i];
+          acc[i] = MF<T>::mfma(af[c][i / NB], bf[c][i % NB], acc[i]);
+          if (WIDE) {
+            // the weight first, then the two A-side fragments it multiplies, then the eight of the B side
+            if (i == 0) wv[c ^ 1] = rb[2 * PANEL_ELEMS + r];
+            else if (i < 3) af[c ^ 1][i - 1] = rb[a_off + r * PITCH + 16 * (i - 1)];
+            else if (i < 11) bf[c ^ 1][i - 3] = rb[b_off + r * PITCH + 16 * (i - 3)];
+            else if (WEIGHTED && i >= 13 && i < 15) af[c ^ 1][i - 13] *= wv[c ^ 1];
+          } else if (i < 4) af[c ^ 1][i] = rb[a_off + r * PITCH + 16 * i];
           else if (i < 8) bf[c ^ 1][i - 4] = rb[b_off + r * PITCH + 16 * (i - 4)];
           else if (i == 8) wv[c ^ 1] = rb[2 * PANEL_ELEMS + r];
           else if (WEIGHTED && i >= 11 && i < 15) af[c ^ 1][i - 11] *= wv[c ^ 1];
@@ -796,13 +817,14 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
     }
   } else if (do_g) {
     T *tp = unit_tiles<T>(a.ws, g, u) + (size_t)it * TILE * TILE;
+    constexpr int SA = (HW || !MFM) ? 4 : NA, SB = (HW || !MFM) ? 4 : NB;      // (the block's MFMA tiles: 4 x 4, or 2 x 8)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < SA; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < SB; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc] = acc[m * 4 + n][r];
+          tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc] = acc[m * SB + n][r];
   }
 #ifdef CVM_STAMPS
   {
