@@ -30,6 +30,18 @@
 // One s_barrier per 16-row stage joins all eight waves.
 // ----------------------------------------------------------------------------------
 constexpr int NT4 = 512;
+// Partial tiles go to the workspace once and are read once, by another kernel: nontemporal stores (experiment
+// CVM_PARTIAL_NT; 0 = plain stores, whose dirty lines wait in the L2s for the end-of-kernel write-back)
+#ifndef CVM_PARTIAL_NT
+#define CVM_PARTIAL_NT 0
+#endif
+template <typename T> __device__ __forceinline__ void partial_store(T *p, T v) {
+#if CVM_PARTIAL_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 #ifndef CVM_INTERLEAVE
 #define CVM_INTERLEAVE 1
 #endif
@@ -824,7 +836,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
       for (int n = 0; n < SB; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc] = acc[m * SB + n][r];
+          partial_store(&tp[(a_col + 16 * m + MF<T>::drow(lane, r)) * TILE + b_col + 16 * n + lc], acc[m * SB + n][r]);
   }
 #ifdef CVM_STAMPS
   {
@@ -1281,7 +1293,7 @@ __device__ __noinline__ ROLE_ATTR void wgram4_diag_body(kargs_ptr<T> kargs, int 
   for (int j = 0; j < NG; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      tp[(16 * P.ft[P.at[P.ga[j]]] + MF<T>::drow(lane, r)) * TILE + 16 * P.ft[P.gb[j]] + lc] = acc[j][r];
+      partial_store(&tp[(16 * P.ft[P.at[P.ga[j]]] + MF<T>::drow(lane, r)) * TILE + 16 * P.ft[P.gb[j]] + lc], acc[j][r]);
   ROLE_EXIT();
 }
 

@@ -53,6 +53,11 @@ mkdir -p $D/mid_tmp; python3 $ROOT/tools/summarize_rocprof.py $O/midpmc $D/mid_t
 python3 tools/emulate_scaling.py --workloads C3 --out $D/emulated_scaling_C3 > $O/emu_C3.log 2>&1; python3 tools/emulate_scaling.py --workloads C4 --comm-us 0,60 --out $D/emulated_scaling_C4 > $O/emu_C4.log 2>&1
 rm -f $D/benchmark_protocol_hip.csv; python3 tools/benchmark_protocol.py --csv $D/benchmark_protocol_hip.csv > $D/benchmark_protocol.log 2>&1
 python3 tools/power_probe.py C3 C3fit C3fold C3two C4 C4fit C5 2>/dev/null > $D/power_probe.txt
+# round 6: the clock under the PRODUCT kernel (cvm_clock_probe) with rocm-smi's sclk beside it, the calibration of the
+# stamps on a bare MFMA loop, and the float32 loop probe (MFMA shapes, wave-block shapes, what a vector instruction costs)
+python3 tools/clock_product.py C3 C3fit C3fold C2 C4 C5 --seconds 3 2>/dev/null > $D/clock_product.txt
+./tools/mfma_peak 2000000 > $D/mfma_peak_clock_calibration.txt 2>&1
+./tools/f32_loop_probe 3000 > $D/f32_loop_probe.txt 2>&1
 for p in "500:250" "240:280,280:120" "240:280,240:135" "480:145,560:65"; do ./tools/dispatch_probe "$p" > /tmp/dp.txt; python3 tools/dispatch_analyze.py /tmp/dp.txt | sed -n 1,7p | cut -c1-400; echo; done > $D/dispatch_probe.txt 2>&1
 tail -3 $O/stats.log
 ls -la $D

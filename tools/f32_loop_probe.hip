@@ -121,7 +121,13 @@ __global__ __launch_bounds__(512, 2) void kern(const float *X, const float *w, i
           if (i == 0) wv[c ^ 1] = rb[2 * PANEL + r];
           else if (i < 3) af[c ^ 1][i - 1] = rb[a_off + r * PITCH + 16 * (i - 1)];
           else if (i < 11) bf[c ^ 1][i - 3] = rb[b_off + r * PITCH + 16 * (i - 3)];
-          else if (!(ABL & 1) && !(ABL & 8) && i >= 13 && i < 15) af[c ^ 1][i - 13] *= wv[c ^ 1];
+          if ((ABL & 128) && i == 12) __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8): the weight and the A side are back
+          if ((ABL & 128) && i == 15) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): ONE wait per k-step for the B side
+          if ((ABL & 16) && i >= 13 && i < 15) asm volatile("" : "+v"(af[c ^ 1][i - 13]) : "v"(wv[c ^ 1]));   // (the wait for the fragments, no instruction)
+          else if ((ABL & 32) && i >= 13 && i < 15) af[c ^ 1][i - 13] = __int_as_float(__float_as_int(af[c ^ 1][i - 13]) ^ (__float_as_int(wv[c ^ 1]) & 1));   // (two integer instructions instead of a float multiply)
+          else if ((ABL & 64) && i >= 13 && i < 15) asm volatile("v_mov_b32 %0, %0" : "+v"(af[c ^ 1][i - 13]));      // (a move)
+          else if (!(ABL & 1) && !(ABL & 8) && !(ABL & 240) && i >= 13 && i < 15) af[c ^ 1][i - 13] *= wv[c ^ 1];
+          if ((ABL & 128) && !(ABL & 1) && i >= 13 && i < 15) af[c ^ 1][i - 13] *= wv[c ^ 1];
           else if ((ABL & 8) && i == 13) { af[c ^ 1][0] *= wv[c ^ 1]; af[c ^ 1][1] *= wv[c ^ 1]; }      // (both behind ONE MFMA)
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -284,6 +290,11 @@ int main(int argc, char **argv) {
   run<0, true>(X, w, K, nstages, out, clk, "16x16x4, 64 x 64 wave blocks, with the loader waves (again)");
   run<4, true, 1>(X, w, K, nstages, out, clk, "16x16x4, 32 x 128 wave blocks, loaders, no multiplies");
   run<4, true, 8>(X, w, K, nstages, out, clk, "16x16x4, 32 x 128 wave blocks, loaders, both multiplies behind one MFMA");
+  run<4, true, 128>(X, w, K, nstages, out, clk, "32 x 128, loaders: explicit waits, one lgkmcnt(8) + one lgkmcnt(0) per k-step");
+  run<4, true, 129>(X, w, K, nstages, out, clk, "32 x 128, loaders: explicit waits, no multiplies");
+  run<4, true, 16>(X, w, K, nstages, out, clk, "32 x 128, loaders: the multiplies' WAIT for their operands only");
+  run<4, true, 32>(X, w, K, nstages, out, clk, "32 x 128, loaders: v_and + v_xor in place of each multiply");
+  run<4, true, 64>(X, w, K, nstages, out, clk, "32 x 128, loaders: v_mov in place of each multiply");
   run<4, true>(X, w, K, nstages, out, clk, "16x16x4, 32 x 128 wave blocks, with the loader waves (again)");
   // where the ~300 cycles per stage beyond the 2048 of the MFMAs go (16x16x4, no loaders: nothing else on the CU)
   run<0, false, 1>(X, w, K, nstages, out, clk, "16x16x4, no loaders, no weighting multiplies");
