@@ -1116,7 +1116,10 @@ def main():
             for wl_ in ("C2", "C4", "C5"):
                 if wl_ == args.workload:
                     continue
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl_, "--steps", "3", "--warmup", "2",
+                # (timed steps enough for the chip's steady state: the round-5 line's 2 + 3 steps read C2 at a clock still
+                #  rising and C4 1-3 % under its steady rate)
+                st_, wu_ = {"C2": ("100", "30"), "C3": ("100", "30"), "C4": ("8", "3"), "C5": ("6", "2")}[wl_]
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl_, "--steps", st_, "--warmup", wu_,
                        "--brief", "--no-live-traffic"] + (["--device-data"] if wl_ == "C5" else [])
                 a_ = time.perf_counter()
                 try:

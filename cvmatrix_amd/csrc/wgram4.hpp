@@ -521,9 +521,10 @@ __device__ __noinline__ ROLE_ATTR void wgram4_body(kargs_ptr<T> kargs, int xcd_q
   // the X-summing waves are exactly the diagonal 64x64 blocks of a diagonal tile: nothing reads
   // the strictly-lower 16x16 tiles of such a block (the finalize kernels mirror the upper ones),
   // so they are not computed -- 10 MFMAs per k-step instead of 16.  (Not wall time: the block's
-  // wave waits for the others at the stage barrier; but the kernel is power-limited and the
-  // clock rises, about 1 % measured.  Dropping the padded second column tile of the H wave the
-  // same way made the gathered variant 1.7 % slower -- code placement -- and was not kept.)
+  // wave waits for the others at the stage barrier; about 1 % measured in round 1.  The kernel is
+  // NOT clock- or power-limited: cvm_clock_probe reads 2.37-2.39 GHz under it, profiles/r6/clock_product.txt.
+  // Dropping the padded second column tile of the H wave the same way made the gathered variant
+  // 1.7 % slower -- code placement -- and was not kept.)
   constexpr bool TRI = (ROLE == 1) && !HW;
   constexpr int NA = HW ? 8 : (WIDE ? 2 : 4), NB = HW ? 2 : (WIDE ? 8 : 4);
   // Fragments of the NEXT k-step are read while the current one computes, across the
