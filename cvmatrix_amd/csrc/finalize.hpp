@@ -1277,3 +1277,197 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
     lds_barrier();
   }
 }
+
+// ----------------------------------------------------------------------------------
+// sweep_finish4_kernel (round 6): the same blocks, sums and arithmetic as sweep_finish_kernel, with the folds' partial
+// loads dealt over FOUR groups of 256 threads.  The 256-thread kernel walks its <= 16 folds one after the other --
+// request up to 8 partials of a fold, wait, add, next fold: ten dependent memory round trips per thread at C3, with
+// barely more than one workgroup per CU (272 blocks): 25 us for 84 MB, 3.4 TB/s, latency-bound (profiles/r6/
+// pmc_derived.json).  Here thread (piece, group g) loads the folds f = g, g + 4, ... only (2-3 round trips), leaves
+// each fold's update U_f in LDS as float64 -- exactly the value the other kernel keeps in a register --, and after one
+// barrier every thread forms G = sum_f U_f in fold order from LDS (the same chain: the same bits) and group g finishes
+// and stores the outputs o = g, g + 4, ... (o = 0: the full-data matrix; o >= 1: fold o - 1), four matrices per
+// barrier round through four transposition buffers.  Dynamic LDS: P x 256 pieces x 16 or 32 bytes + the statistics
+// + the buffers (65 KB at C3); the host falls back to sweep_finish_kernel when that does not fit.
+// ----------------------------------------------------------------------------------
+constexpr int SWF4_FG = 4;
+constexpr int SWF4_T = 256 * SWF4_FG;
+constexpr int SWF4_EPW = SWF4_T / SWF_MAX;       // XTY elements per workgroup
+template <typename T> constexpr size_t swf4_lds_bytes(int P) {
+  constexpr int VW = 16 / (int)sizeof(T), C = 16 * VW, SL = 32 + 2 * C + 1;
+  return (size_t)P * 256 * VW * 8 + (size_t)P * SL * 8 + (size_t)SWF4_FG * 16 * (C + 1) * sizeof(T) + 16;
+}
+template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_kernel(const FinArgs a, T *Gout, T *Hout) {
+  static_assert(SWF_R == 16, "blocks of 16 rows x 256 bytes");
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const Geom &g = a.g;
+  const int K = g.K, M = g.M, P = a.n_seg;
+  const int tid = threadIdx.x;
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int C = 16 * VW;                 // block columns
+  typedef T vld_t __attribute__((ext_vector_type(VW)));
+  const int nrb = (K + SWF_R - 1) / SWF_R, ncb = (K + C - 1) / C;
+  const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
+  const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
+  const int x = blockIdx.x;
+  if (x >= nrb * ncb) {
+    // ---- XTY: thread = (element el of the workgroup's 64, fold fl): as in sweep_finish_kernel
+    if (M == 0 || !Hout) return;
+    const int el = tid % SWF4_EPW, fl = tid / SWF4_EPW;
+    const int e = (x - nrb * ncb) * SWF4_EPW + el;
+    const bool evalid = e < K * M, fvalid = fl < P;
+    const int ga = evalid ? e / M : 0, m = evalid ? e - ga * M : 0;
+    const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
+    double (*uh)[SWF4_EPW + 1] = reinterpret_cast<double (*)[SWF4_EPW + 1]>(dsm);     // (SWF_MAX x 65 doubles: 8.3 KB)
+    double u = 0;
+    if (fvalid) {
+      const char *pf = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T) + (size_t)fl * a.splits * g.unit_bytes;
+      for (int p0 = 0; p0 < a.s_diag; p0 += 8) {
+        const int cnt = a.s_diag - p0 < 8 ? a.s_diag - p0 : 8;
+        T t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = *reinterpret_cast<const T *>(pf + (size_t)(p0 + (j < cnt ? j : 0)) * g.unit_bytes);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < cnt) u += (double)t8[j];
+      }
+      uh[fl][el] = u;
+    }
+    lds_barrier();
+    double h = 0;
+    for (int f = 0; f < P; ++f) h += uh[f][el];
+    const T hT = (T)h;
+    if (!evalid) return;
+    if (fl == 0) Hout[(size_t)ga * M + m] = hT;
+    if (!a.out_XTY || !fvalid) return;
+    {
+      const double *fs = a.fstats + (size_t)fl * fstat_len(K, M);
+      const double swt = fs[2 * K + 2 * M];
+      double v = (double)hT - u;
+      if (cX || cY) v -= swt * (fs[ga] * fs[2 * K + m]);
+      if (sX && sY) v = v * (fs[K + ga] * fs[2 * K + M + m]);
+      else if (sX) v = v * fs[K + ga];
+      else if (sY) v = v * fs[2 * K + M + m];
+      ((T *)a.out_XTY)[((size_t)(a.seg0 + fl) * K + ga) * M + m] = (T)v;
+    }
+    return;
+  }
+  const int rb = x / ncb, cb = x - rb * ncb;
+  const int a0 = rb * SWF_R, b0 = cb * C;
+  if (b0 + C - 1 < a0) return;               // the whole block is below the diagonal
+  const int pid = tid & 255, fg = __builtin_amdgcn_readfirstlane(tid >> 8);     // piece of the block, fold group
+  const int lr = pid >> 4, lc = (pid & 15) * VW;
+  const int gr = a0 + lr, gc = b0 + lc;
+  const int ti = a0 / TILE, tj = b0 / TILE;
+  const int nsp = (ti == tj) ? a.s_diag : a.s_off;
+  const size_t off = (size_t)tile_id(ti, tj, g.P) * TILE * TILE + (size_t)(a0 - ti * TILE + lr) * TILE + (b0 - tj * TILE + lc);
+  const char *pp = a.ws + off * sizeof(T);
+  constexpr int SL = 32 + 2 * C + 1;
+  // dynamic LDS: [P][256][VW] float64 updates | [P][SL] float64 statistics | [FG][16][C + 1] T transposition buffers
+  double *Us = reinterpret_cast<double *>(dsm);
+  double (*stl)[SL] = reinterpret_cast<double (*)[SL]>(dsm + (size_t)P * 256 * VW * 8);
+  T (*tm)[SWF_R][C + 1] = reinterpret_cast<T (*)[SWF_R][C + 1]>(dsm + (size_t)P * 256 * VW * 8 + (size_t)P * SL * 8);
+  if (a.out_XTX) {
+    for (int q = tid; q < P * SL; q += SWF4_T) {
+      const int f = q / SL, i = q - f * SL;
+      const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
+      double v;
+      if (i < 16) v = (cX && a0 + i < K) ? fs[a0 + i] : 0.0;
+      else if (i < 32) v = (sX && a0 + i - 16 < K) ? fs[K + a0 + i - 16] : 1.0;
+      else if (i < 32 + C) v = (cX && b0 + i - 32 < K) ? fs[b0 + i - 32] : 0.0;
+      else if (i < 32 + 2 * C) v = (sX && b0 + i - 32 - C < K) ? fs[K + b0 + i - 32 - C] : 1.0;
+      else v = fs[2 * K + 2 * M];
+      stl[f][i] = v;
+    }
+  }
+  // ---- this group's folds: the update of this thread's piece, in split order (up to 8 partials in flight) -> LDS
+  for (int f = fg; f < P; f += SWF4_FG) {
+    double u[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) u[e] = 0;
+    const char *pf = pp + (size_t)f * a.splits * g.unit_bytes;
+    for (int p0 = 0; p0 < nsp; p0 += 8) {
+      const int cnt = nsp - p0 < 8 ? nsp - p0 : 8;
+      vld_t q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const vld_t *>(pf + (size_t)(p0 + (j < cnt ? j : 0)) * g.unit_bytes);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < cnt) {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) u[e] += (double)q[j][e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) Us[((size_t)f * 256 + pid) * VW + e] = u[e];
+  }
+  lds_barrier();
+  // ---- G = sum of the folds' updates in fold order (every group forms it for itself: the same chain)
+  double gsum[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) gsum[e] = 0;
+  for (int f = 0; f < P; ++f) {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) gsum[e] += Us[((size_t)f * 256 + pid) * VW + e];
+  }
+  bool ok[VW];
+  const bool all_ok = gr < K && gc + VW <= K && gr <= gc;
+#pragma unroll
+  for (int e = 0; e < VW; ++e) ok[e] = gr < K && gc + e < K && gr <= gc + e;
+  T gT[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) gT[e] = (T)gsum[e];
+  // ---- outputs: o = 0 the full-data matrix, o >= 1 fold o - 1; group fg takes o = fg, fg + 4, ...: finished pieces are
+  // stored as rows a / columns b and parked in the group's buffer; after one barrier the image is stored transposed
+  const int mc = pid / (SWF_R / VW), mr = (pid - mc * (SWF_R / VW)) * VW;
+  const int n_out = a.out_XTX ? P + 1 : 1;
+  for (int o0 = 0; o0 < n_out; o0 += SWF4_FG) {
+    const int o = o0 + fg;
+    T *out = nullptr;
+    if (o < n_out) {
+      T vals[VW];
+      if (o == 0) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vals[e] = gT[e];
+        out = Gout;
+      } else {
+        const double *st = stl[o - 1];
+        const double swt = st[32 + 2 * C], mur = st[lr], sdr = st[16 + lr];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          double v = (double)gT[e] - Us[((size_t)(o - 1) * 256 + pid) * VW + e];
+          if (cX) v -= swt * (mur * st[32 + lc + e]);
+          if (sX) v = v * (sdr * st[32 + C + lc + e]);
+          vals[e] = (T)v;
+        }
+        out = (T *)a.out_XTX + (size_t)(a.seg0 + o - 1) * K * K;
+      }
+      T *dst = out + (size_t)gr * K + gc;
+      if (all_ok) {
+        vld_t vv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vv[e] = vals[e];
+        if (o) out_store(reinterpret_cast<vld_t *>(dst), vv); else *reinterpret_cast<vld_t *>(dst) = vv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) if (ok[e]) dst[e] = vals[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VW; ++e) tm[fg][lr][lc + e] = vals[e];
+    }
+    lds_barrier();
+    const int orow = b0 + mc, ocol = a0 + mr;
+    if (o < n_out && orow < K) {
+      T *md = out + (size_t)orow * K + ocol;
+      if (ocol + VW <= K && ocol + VW - 1 < orow) {
+        vld_t vv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) vv[e] = tm[fg][mr + e][mc];
+        if (o) out_store(reinterpret_cast<vld_t *>(md), vv); else *reinterpret_cast<vld_t *>(md) = vv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) if (ocol + e < K && ocol + e < orow) md[e] = tm[fg][mr + e][mc];
+      }
+    }
+    lds_barrier();
+  }
+}

@@ -30,10 +30,12 @@
  *     optional launch-timing recorder below (mutex-guarded), once-per-device kernel
  *     attributes (atomic flags) and one 1 MiB device allocation per device, made on first use
  *     and kept (1024 work-queue blocks of the persistent Gram kernel, one per stream that uses
- *     it, handed out under a mutex and RECYCLED: when all are taken, the block of the stream
- *     that has gone longest without a Gram launch and has nothing in flight changes hands, so
- *     a service may create and destroy streams without bound); planning depends on the
- *     arguments alone.
+ *     it, handed out under a mutex and RECYCLED: when all are taken, the least recently used
+ *     block whose last Gram launch is over -- by an event the library itself recorded behind
+ *     that launch, once the process has used more than 64 streams on the device; never by a
+ *     query of a foreign stream handle -- changes hands, so a service may create and destroy
+ *     streams without bound); the optional clock-probe buffer and forced split plan are single
+ *     atomic words; planning depends on the arguments alone.
  */
 #ifndef CVMHIP_H
 #define CVMHIP_H
