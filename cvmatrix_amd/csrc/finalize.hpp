@@ -1359,7 +1359,13 @@ template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_ke
   const int gr = a0 + lr, gc = b0 + lc;
   const int ti = a0 / TILE, tj = b0 / TILE;
   const int nsp = (ti == tj) ? a.s_diag : a.s_off;
+#ifdef CVM_SWF_CONTIG_PROBE
+  // (timing probe only, WRONG results: what the kernel would take if a block's pieces of a partial tile were 4 KB in a row)
+  const size_t off = (size_t)tile_id(ti, tj, g.P) * TILE * TILE +
+                     (size_t)(((a0 - ti * TILE) / SWF_R) * (TILE / C) + (b0 - tj * TILE) / C) * (SWF_R * C) + (size_t)lr * C + lc;
+#else
   const size_t off = (size_t)tile_id(ti, tj, g.P) * TILE * TILE + (size_t)(a0 - ti * TILE + lr) * TILE + (b0 - tj * TILE + lc);
+#endif
   const char *pp = a.ws + off * sizeof(T);
   constexpr int SL = 32 + 2 * C + 1;
   // dynamic LDS: [P][256][VW] float64 updates | [P][SL] float64 statistics | [FG][16][C + 1] T transposition buffers
@@ -1442,21 +1448,31 @@ template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_ke
         out = (T *)a.out_XTX + (size_t)(a.seg0 + o - 1) * K * K;
       }
       T *dst = out + (size_t)gr * K + gc;
+#ifdef CVM_SWF_NO_DIRECT_PROBE
+      if (false) {
+#else
       if (all_ok) {
+#endif
         vld_t vv;
 #pragma unroll
         for (int e = 0; e < VW; ++e) vv[e] = vals[e];
         if (o) out_store(reinterpret_cast<vld_t *>(dst), vv); else *reinterpret_cast<vld_t *>(dst) = vv;
       } else {
+#ifndef CVM_SWF_NO_DIRECT_PROBE
 #pragma unroll
         for (int e = 0; e < VW; ++e) if (ok[e]) dst[e] = vals[e];
+#endif
       }
 #pragma unroll
       for (int e = 0; e < VW; ++e) tm[fg][lr][lc + e] = vals[e];
     }
     lds_barrier();
     const int orow = b0 + mc, ocol = a0 + mr;
+#ifdef CVM_SWF_NO_MIRROR_PROBE
+    if (o < n_out && orow < K && tm[fg][0][0] == (T)12345.678) {      // (timing probe: never true)
+#else
     if (o < n_out && orow < K) {
+#endif
       T *md = out + (size_t)orow * K + ocol;
       if (ocol + VW <= K && ocol + VW - 1 < orow) {
         vld_t vv;
