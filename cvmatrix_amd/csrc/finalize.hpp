@@ -1290,35 +1290,43 @@ template <typename T> __global__ __launch_bounds__(SWF_T) void sweep_finish_kern
 // barrier round through four transposition buffers.  Dynamic LDS: P x 256 pieces x 16 or 32 bytes + the statistics
 // + the buffers (65 KB at C3); the host falls back to sweep_finish_kernel when that does not fit.
 // ----------------------------------------------------------------------------------
+// PPR = 16-byte pieces per block row: 16 (blocks of 16 rows x 256 bytes, 1024 threads, 272 blocks at K = 512) or 8 (16 rows x
+// 128 bytes, 512 threads, 528 blocks: two to four workgroups per CU, so that one's loads overlap another's stores).
 constexpr int SWF4_FG = 4;
-constexpr int SWF4_T = 256 * SWF4_FG;
-constexpr int SWF4_EPW = SWF4_T / SWF_MAX;       // XTY elements per workgroup
-template <typename T> constexpr size_t swf4_lds_bytes(int P) {
-  constexpr int VW = 16 / (int)sizeof(T), C = 16 * VW, SL = 32 + 2 * C + 1;
-  return (size_t)P * 256 * VW * 8 + (size_t)P * SL * 8 + (size_t)SWF4_FG * 16 * (C + 1) * sizeof(T) + 16;
+#ifndef CVM_SWF4_PPR
+#define CVM_SWF4_PPR 8
+#endif
+template <int PPR> constexpr int swf4_threads() { return 16 * PPR * SWF4_FG; }
+template <int PPR> constexpr int swf4_epw() { return swf4_threads<PPR>() / SWF_MAX; }      // XTY elements per workgroup
+template <typename T, int PPR> constexpr size_t swf4_lds_bytes(int P) {
+  constexpr int VW = 16 / (int)sizeof(T), C = PPR * VW, SL = 32 + 2 * C + 1, NP = 16 * PPR;
+  const size_t xtx = (size_t)P * NP * VW * 8 + (size_t)P * SL * 8 + (size_t)SWF4_FG * 16 * (C + 1) * sizeof(T) + 16;
+  const size_t xty = (size_t)SWF_MAX * (swf4_epw<PPR>() + 1) * 8;
+  return xtx > xty ? xtx : xty;
 }
-template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_kernel(const FinArgs a, T *Gout, T *Hout) {
+template <typename T, int PPR> __global__ __launch_bounds__(16 * PPR * SWF4_FG) void sweep_finish4_kernel(const FinArgs a, T *Gout, T *Hout) {
+  constexpr int SWF4_T = swf4_threads<PPR>(), SWF4_EPW = swf4_epw<PPR>(), NP = 16 * PPR;
   static_assert(SWF_R == 16, "blocks of 16 rows x 256 bytes");
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const Geom &g = a.g;
   const int K = g.K, M = g.M, P = a.n_seg;
   const int tid = threadIdx.x;
   constexpr int VW = 16 / (int)sizeof(T);
-  constexpr int C = 16 * VW;                 // block columns
+  constexpr int C = PPR * VW;                // block columns
   typedef T vld_t __attribute__((ext_vector_type(VW)));
   const int nrb = (K + SWF_R - 1) / SWF_R, ncb = (K + C - 1) / C;
   const bool cX = a.flags & CVM_CENTER_X, cY = a.flags & CVM_CENTER_Y;
   const bool sX = a.flags & CVM_SCALE_X, sY = a.flags & CVM_SCALE_Y;
   const int x = blockIdx.x;
   if (x >= nrb * ncb) {
-    // ---- XTY: thread = (element el of the workgroup's 64, fold fl): as in sweep_finish_kernel
+    // ---- XTY: thread = (element el of the workgroup's EPW, fold fl): as in sweep_finish_kernel
     if (M == 0 || !Hout) return;
     const int el = tid % SWF4_EPW, fl = tid / SWF4_EPW;
     const int e = (x - nrb * ncb) * SWF4_EPW + el;
     const bool evalid = e < K * M, fvalid = fl < P;
     const int ga = evalid ? e / M : 0, m = evalid ? e - ga * M : 0;
     const size_t hoff = (g.tile_elems * sizeof(T) + 255) / 256 * 256;
-    double (*uh)[SWF4_EPW + 1] = reinterpret_cast<double (*)[SWF4_EPW + 1]>(dsm);     // (SWF_MAX x 65 doubles: 8.3 KB)
+    double (*uh)[SWF4_EPW + 1] = reinterpret_cast<double (*)[SWF4_EPW + 1]>(dsm);     // (SWF_MAX x (EPW + 1) doubles)
     double u = 0;
     if (fvalid) {
       const char *pf = a.ws + hoff + ((size_t)ga * g.Mp + m) * sizeof(T) + (size_t)fl * a.splits * g.unit_bytes;
@@ -1354,8 +1362,8 @@ template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_ke
   const int rb = x / ncb, cb = x - rb * ncb;
   const int a0 = rb * SWF_R, b0 = cb * C;
   if (b0 + C - 1 < a0) return;               // the whole block is below the diagonal
-  const int pid = tid & 255, fg = __builtin_amdgcn_readfirstlane(tid >> 8);     // piece of the block, fold group
-  const int lr = pid >> 4, lc = (pid & 15) * VW;
+  const int pid = tid % NP, fg = __builtin_amdgcn_readfirstlane(tid / NP);      // piece of the block, fold group
+  const int lr = pid / PPR, lc = (pid % PPR) * VW;
   const int gr = a0 + lr, gc = b0 + lc;
   const int ti = a0 / TILE, tj = b0 / TILE;
   const int nsp = (ti == tj) ? a.s_diag : a.s_off;
@@ -1368,10 +1376,10 @@ template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_ke
 #endif
   const char *pp = a.ws + off * sizeof(T);
   constexpr int SL = 32 + 2 * C + 1;
-  // dynamic LDS: [P][256][VW] float64 updates | [P][SL] float64 statistics | [FG][16][C + 1] T transposition buffers
+  // dynamic LDS: [P][NP][VW] float64 updates | [P][SL] float64 statistics | [FG][16][C + 1] T transposition buffers
   double *Us = reinterpret_cast<double *>(dsm);
-  double (*stl)[SL] = reinterpret_cast<double (*)[SL]>(dsm + (size_t)P * 256 * VW * 8);
-  T (*tm)[SWF_R][C + 1] = reinterpret_cast<T (*)[SWF_R][C + 1]>(dsm + (size_t)P * 256 * VW * 8 + (size_t)P * SL * 8);
+  double (*stl)[SL] = reinterpret_cast<double (*)[SL]>(dsm + (size_t)P * NP * VW * 8);
+  T (*tm)[SWF_R][C + 1] = reinterpret_cast<T (*)[SWF_R][C + 1]>(dsm + (size_t)P * NP * VW * 8 + (size_t)P * SL * 8);
   if (a.out_XTX) {
     for (int q = tid; q < P * SL; q += SWF4_T) {
       const int f = q / SL, i = q - f * SL;
@@ -1404,7 +1412,7 @@ template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_ke
         }
     }
 #pragma unroll
-    for (int e = 0; e < VW; ++e) Us[((size_t)f * 256 + pid) * VW + e] = u[e];
+    for (int e = 0; e < VW; ++e) Us[((size_t)f * NP + pid) * VW + e] = u[e];
   }
   lds_barrier();
   // ---- G = sum of the folds' updates in fold order (every group forms it for itself: the same chain)
@@ -1413,7 +1421,7 @@ template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_ke
   for (int e = 0; e < VW; ++e) gsum[e] = 0;
   for (int f = 0; f < P; ++f) {
 #pragma unroll
-    for (int e = 0; e < VW; ++e) gsum[e] += Us[((size_t)f * 256 + pid) * VW + e];
+    for (int e = 0; e < VW; ++e) gsum[e] += Us[((size_t)f * NP + pid) * VW + e];
   }
   bool ok[VW];
   const bool all_ok = gr < K && gc + VW <= K && gr <= gc;
@@ -1440,7 +1448,7 @@ template <typename T> __global__ __launch_bounds__(SWF4_T) void sweep_finish4_ke
         const double swt = st[32 + 2 * C], mur = st[lr], sdr = st[16 + lr];
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
-          double v = (double)gT[e] - Us[((size_t)(o - 1) * 256 + pid) * VW + e];
+          double v = (double)gT[e] - Us[((size_t)(o - 1) * NP + pid) * VW + e];
           if (cX) v -= swt * (mur * st[32 + lc + e]);
           if (sX) v = v * (sdr * st[32 + C + lc + e]);
           vals[e] = (T)v;

@@ -1203,17 +1203,21 @@ int sweep_all_impl(const void *X, const void *Y, const void *w, const int64_t *i
   // (round 6) the folds' partial loads dealt over four groups of threads -- 2-3 dependent round trips per thread instead
   // of ten, the same sums -- when its LDS (the folds' updates of a block, float64) fits; CVM_SWF4=0: the 256-thread kernel
   static const bool swf4 = !(getenv("CVM_SWF4") && atoi(getenv("CVM_SWF4")) == 0);
-  const size_t lds4 = swf4_lds_bytes<T>((int)n_folds);
+  constexpr int PPR = CVM_SWF4_PPR;
+  const size_t lds4 = swf4_lds_bytes<T, PPR>((int)n_folds);
   if (swf4 && lds4 <= (size_t)150 * 1024) {
     int dev = 0;
     HIP_OK(hipGetDevice(&dev));
     static std::atomic<unsigned long long> attr_done{0};   // one bit per device
     if (attr_needed(attr_done, dev)) {
-      HIP_OK(hipFuncSetAttribute((const void *)sweep_finish4_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIP_OK(hipFuncSetAttribute((const void *)sweep_finish4_kernel<T, PPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       attr_set(attr_done, dev);
     }
-    const unsigned hb4 = (Y && M > 0) ? (unsigned)(((size_t)K * M + SWF4_EPW - 1) / SWF4_EPW) : 0u;
-    hipLaunchKernelGGL((sweep_finish4_kernel<T>), dim3(xb + hb4), dim3(SWF4_T), lds4, st, f, (T *)G, (T *)((Y && M > 0) ? H : nullptr));
+    constexpr int C4 = PPR * (16 / (int)sizeof(T));
+    const unsigned xb4 = (unsigned)(((K + SWF_R - 1) / SWF_R) * ((K + C4 - 1) / C4));
+    const unsigned hb4 = (Y && M > 0) ? (unsigned)(((size_t)K * M + swf4_epw<PPR>() - 1) / swf4_epw<PPR>()) : 0u;
+    hipLaunchKernelGGL((sweep_finish4_kernel<T, PPR>), dim3(xb4 + hb4), dim3(swf4_threads<PPR>()), lds4, st, f, (T *)G,
+                       (T *)((Y && M > 0) ? H : nullptr));
     HIP_OK(hipGetLastError());
     if (splits_out) *splits_out = (int64_t)p.s_off | ((int64_t)p.s_diag << 20);
     return CVM_OK;
