@@ -1837,7 +1837,7 @@ def test_negative_device_weights_raise_in_fit_or_at_the_first_hand_out(amd):
                 lambda m: [m.training_XTX_XTY(v) for v in amd.Partitioner(np.arange(200)).folds_dict.values()]]
         for flags in ((True,) * 4, (False,) * 4):
             for iu, use in enumerate(uses):
-                m = amd.CVMatrix(*flags, lazy_fit=lazy)
+                m = amd.CVMatrix(*flags, lazy_fit=lazy, validate_weights="deferred")
                 m.fit(X, Y, w)                                         # returns: nothing has been read back
                 if flags[0] is False and 6 <= iu <= 8:
                     continue                                           # (those attributes are None without flags)
@@ -1864,7 +1864,7 @@ def test_deferred_weight_validation_counts_folds_only_where_the_bound_does_not_d
     Xh, wh = rng.random((N, K)), rng.random(N) + 0.1
     p = amd.Partitioner(np.arange(N) % 3)
     # plenty of non-zero weights: nothing is counted, nothing is read back
-    m = amd.CVMatrix()
+    m = amd.CVMatrix(validate_weights="deferred")
     m.fit(torch.from_numpy(Xh).cuda(), None, torch.from_numpy(wh).cuda())
     b = m.prepare_folds(p)
     m.training_XTX_batched(b)
@@ -1874,7 +1874,7 @@ def test_deferred_weight_validation_counts_folds_only_where_the_bound_does_not_d
     ref = amd.CVMatrix()
     ref.fit(Xh, None, wz)
     for folds, msg in (([p.folds_dict[0]], "must be greater than zero"), ([p.folds_dict[1]], None)):
-        m = amd.CVMatrix()
+        m = amd.CVMatrix(validate_weights="deferred")
         m.fit(torch.from_numpy(Xh).cuda(), None, torch.from_numpy(wz).cuda())
         if msg:
             with pytest.raises(ValueError, match=msg):
@@ -1886,7 +1886,7 @@ def test_deferred_weight_validation_counts_folds_only_where_the_bound_does_not_d
             assert torch_equal(got[0], want[0])
     # exactly ddof + 0 non-zero weights left for training -> the ddof raise
     w1 = np.zeros(N); w1[0] = 1.0; w1[1] = 2.0
-    m = amd.CVMatrix(ddof=1)
+    m = amd.CVMatrix(ddof=1, validate_weights="deferred")
     m.fit(torch.from_numpy(Xh).cuda(), None, torch.from_numpy(w1).cuda())
     with pytest.raises(ValueError, match="must be greater than `ddof`"):
         m.training_XTX(np.array([1, 5, 7]))
