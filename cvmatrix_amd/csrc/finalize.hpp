@@ -1393,61 +1393,29 @@ template <typename T, int PPR> __global__ __launch_bounds__(16 * PPR * SWF4_FG) 
       stl[f][i] = v;
     }
   }
-  // ---- this group's folds: the update of this thread's piece, in split order -> LDS.  At most 8 partials per fold (every
-  // plan the planner makes for <= 16 folds): the NEXT fold of the group is requested before the current one is added, two
-  // folds' loads in flight (a runtime loop over two register sets: nothing is unrolled over the folds)
-  auto request = [&](int f, vld_t (&q)[8]) {
-    const char *pf = pp + (size_t)f * a.splits * g.unit_bytes;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const vld_t *>(pf + (size_t)(j < nsp ? j : 0) * g.unit_bytes);
-  };
-  auto reduce_store = [&](int f, const vld_t (&q)[8]) {
+  // ---- this group's folds: the update of this thread's piece, in split order (up to 8 partials in flight) -> LDS
+  // (the NEXT fold of the group requested before the current one is added -- two folds' loads in flight -- was measured
+  //  SLOWER, 22.7 -> 26.9 us: like the 256-thread kernel's same experiment in round 2, more loads in flight per thread do
+  //  not help a kernel whose CUs' memory pipes are already full)
+  for (int f = fg; f < P; f += SWF4_FG) {
     double u[VW];
 #pragma unroll
     for (int e = 0; e < VW; ++e) u[e] = 0;
+    const char *pf = pp + (size_t)f * a.splits * g.unit_bytes;
+    for (int p0 = 0; p0 < nsp; p0 += 8) {
+      const int cnt = nsp - p0 < 8 ? nsp - p0 : 8;
+      vld_t q[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < nsp) {
+      for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const vld_t *>(pf + (size_t)(p0 + (j < cnt ? j : 0)) * g.unit_bytes);
 #pragma unroll
-        for (int e = 0; e < VW; ++e) u[e] += (double)q[j][e];
-      }
+      for (int j = 0; j < 8; ++j)
+        if (j < cnt) {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) u[e] += (double)q[j][e];
+        }
+    }
 #pragma unroll
     for (int e = 0; e < VW; ++e) Us[((size_t)f * NP + pid) * VW + e] = u[e];
-  };
-  if (nsp <= 8) {
-    vld_t qa[8], qb[8];
-    int f = fg;
-    if (f < P) request(f, qa);
-    for (; f < P; f += 2 * SWF4_FG) {
-      const int f1 = f + SWF4_FG, f2 = f + 2 * SWF4_FG;
-      if (f1 < P) request(f1, qb);
-      reduce_store(f, qa);
-      if (f1 < P) {
-        if (f2 < P) request(f2, qa);
-        reduce_store(f1, qb);
-      }
-    }
-  } else {
-    for (int f = fg; f < P; f += SWF4_FG) {
-      double u[VW];
-#pragma unroll
-      for (int e = 0; e < VW; ++e) u[e] = 0;
-      const char *pf = pp + (size_t)f * a.splits * g.unit_bytes;
-      for (int p0 = 0; p0 < nsp; p0 += 8) {
-        const int cnt = nsp - p0 < 8 ? nsp - p0 : 8;
-        vld_t q[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const vld_t *>(pf + (size_t)(p0 + (j < cnt ? j : 0)) * g.unit_bytes);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < cnt) {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) u[e] += (double)q[j][e];
-          }
-      }
-#pragma unroll
-      for (int e = 0; e < VW; ++e) Us[((size_t)f * NP + pid) * VW + e] = u[e];
-    }
   }
   lds_barrier();
   // ---- G = sum of the folds' updates in fold order (every group forms it for itself: the same chain)
