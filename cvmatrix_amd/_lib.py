@@ -24,7 +24,7 @@ IDX_HOST = 0x40
 
 EXPORTS = (
     "cvm_version", "cvm_source_hash", "cvm_last_error", "cvm_gstats_len", "cvm_fit_workspace_bytes",
-    "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_fold_update_ex", "cvm_plan_fold", "cvm_debug_force_splits",
+    "cvm_gram_fit", "cvm_fold_workspace_bytes", "cvm_fold_update", "cvm_fold_update_ex", "cvm_plan_fold", "cvm_debug_force_splits", "cvm_debug_resident",
     "cvm_timing_enable", "cvm_timing_read", "cvm_timing_read_kinds", "cvm_fill_probe", "cvm_clock_probe",
     "cvm_sweep_workspace_bytes", "cvm_sweep_fit", "cvm_sweep_folds", "cvm_sweep_fold_range", "cvm_sweep_all",
     "cvm_partition_workspace_bytes", "cvm_partition_labels", "cvm_partition_periodic", "cvm_weights_check",
@@ -128,6 +128,8 @@ def load():
     lib.cvm_clock_probe.argtypes = [vp, sz]
     lib.cvm_debug_force_splits.restype = C.c_int
     lib.cvm_debug_force_splits.argtypes = [C.c_int, C.c_int]
+    lib.cvm_debug_resident.restype = C.c_int
+    lib.cvm_debug_resident.argtypes = [C.c_int]
     lib.cvm_plan_fold.restype = C.c_int
     lib.cvm_plan_fold.argtypes = [i64, i64, C.c_int, C.c_int, C.c_int, u32, sz, vp]
     _lib = lib

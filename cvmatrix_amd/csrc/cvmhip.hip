@@ -39,6 +39,7 @@ namespace {
 #include "finalize.hpp"
 #include "colstats.hpp"
 #include "small_folds.hpp"
+#include "resident.hpp"
 #include "mid_tile.hpp"
 #include "host.hpp"
 #include "partition.hpp"
@@ -88,7 +89,7 @@ size_t cvm_fold_workspace_bytes(int64_t n_folds, int64_t n_idx, int64_t max_fold
   (void)n_idx;
   if (max_fold_rows <= SMALL_ROWS) {   // direct path: only the per-fold statistics live in ws
     const int64_t nb = n_folds < 32768 ? (n_folds > 0 ? n_folds : 1) : 32768;
-    const size_t small = (size_t)nb * small_ws_per_fold(K, M, dtype == CVM_F64 ? 8 : 4) + 512;
+    const size_t small = (size_t)nb * small_ws_per_fold(K, M, dtype == CVM_F64 ? 8 : 4, max_fold_rows) + 512;
     // (batches of folds of 8 rows or more may take mid_tile_kernel behind the statistics pre-pass: one
     //  statistics unit and one statistics vector per fold)
     const Geom gs = make_geom(K, M, dtype == CVM_F64 ? 8 : 4, 1);
@@ -402,6 +403,11 @@ int cvm_debug_force_splits(int s_off, int s_diag) {
   if (s_off == 0 && s_diag == 0) { g_force_splits.store(0, std::memory_order_relaxed); return CVM_OK; }
   if (s_off < 1 || s_diag < 1 || s_off > 65535 || s_diag > 65535) return fail(CVM_EINVAL, "cvm_debug_force_splits: 1 <= splits <= 65535, or 0, 0%s");
   g_force_splits.store(((unsigned)s_off << 16) | (unsigned)s_diag, std::memory_order_relaxed);
+  return CVM_OK;
+}
+
+int cvm_debug_resident(int on) {
+  g_resident.store(on ? 1 : 0, std::memory_order_relaxed);
   return CVM_OK;
 }
 

@@ -590,10 +590,27 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // 1.91 / 1.87, 64 rows 1.59 / 1.73; K=1024 ... 4096 64 rows 2.13 / 2.02 ... 2.38 / 2.35, 80 rows
 // 1.77 / 1.84 ... 2.04 / 2.24.  CVM_SMALL_MAXN (32 .. 128) overrides the table for measurements
 // and tests.
-// workspace of the direct small-fold route per fold: the statistics vector
-inline size_t small_ws_per_fold(int K, int M, int esize) {
-  (void)esize;
-  return fstat_len(K, M) * 8;
+// Round 6, the resident route (resident.hpp: float32 XTX of folds of at most 16 rows with G in the register files of the
+// whole chip): K a multiple of the 1024-column block, at least 4 folds per workgroup set.
+// OPT-IN (cvm_debug_resident(1) / CVM_RESIDENT=1, read once as the initial value): measured at parity with small_apply_kernel
+// at K = 4096 and slower at K = 1024 ... 3072 (profiles/r6/hbm_regime/, DESIGN.md 4.4 "round 6").
+constexpr int RES_NP = 16;
+std::atomic<int> g_resident{-1};                        // -1: environment not consulted yet
+inline bool resident_on() {
+  int v = g_resident.load(std::memory_order_relaxed);
+  if (v >= 0) return v != 0;
+  const char *e = getenv("CVM_RESIDENT");
+  int init = (e && atoi(e) != 0) ? 1 : 0, expect = -1;
+  g_resident.compare_exchange_strong(expect, init, std::memory_order_relaxed);
+  return g_resident.load(std::memory_order_relaxed) != 0;
+}
+inline bool res_shape_ok(int K, int esize, int64_t max_rows) {
+  return resident_on() && esize == 4 && max_rows <= RES_NP && K >= RES_BC && K % RES_BC == 0;
+}
+inline size_t res_pack_bytes(int K) { return (size_t)2 * (RES_NP + 4) * K * 4; }
+// workspace of the direct small-fold route per fold: the statistics vector (+ the resident route's operand block)
+inline size_t small_ws_per_fold(int K, int M, int esize, int64_t max_rows) {
+  return align_up(fstat_len(K, M) * 8, 256) + (res_shape_ok(K, esize, max_rows) ? res_pack_bytes(K) : 0);
 }
 int small_route_limit(int K, int esize) {
   static const int forced = [] {
@@ -615,7 +632,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
                     void *out_muX, void *out_sdX, void *out_muY, void *out_sdY, double *out_fold,
                     void *ws, size_t ws_bytes, hipStream_t st) {
   // per fold: the float64 statistics vector
-  const size_t per_fold = small_ws_per_fold(K, M, (int)sizeof(T));
+  const size_t per_fold = small_ws_per_fold(K, M, (int)sizeof(T), max_rows);
   int64_t nb_max = (int64_t)((ws_bytes > 256 ? ws_bytes - 256 : 0) / per_fold);
   if (nb_max < 1) return fail(CVM_EWORKSPACE, "cvm_fold_update: workspace cannot hold one fold%s");
   if (nb_max > 32768) nb_max = 32768;   // grid.y
@@ -697,10 +714,46 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
         else CVM_ROWS(256);
 #undef CVM_ROWS
       } else {
-        a.gx = (int)ga.x; a.gy = (int)ga.y;
-        const dim3 g1((unsigned)(8 * (((size_t)ga.x * ga.y + 7) / 8)));
-        if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), g1, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((small_apply_kernel<T, false>), g1, dim3(256), 0, st, a);
+        // XTX by the resident route where the shape allows it (the XTY panels stay with small_apply_kernel)
+        bool resident = false;
+        if constexpr (sizeof(T) == 4) {
+          const bool shape = res_shape_ok(K, 4, max_rows);            // (K >= 1024 then)
+          const int nblk_all = shape ? (K / 32) * (K / RES_BC) : 1;
+          int groups = nblk_all >= RES_WG ? 1 : RES_WG / nblk_all;
+          if (groups > nb / 4) groups = (int)(nb / 4);
+          resident = shape && a.out_XTX && !(flags & CVM_IDX_HOST) && groups >= 1 &&
+                     (uintptr_t)G % 4 == 0 && (uintptr_t)a.out_XTX % 4 == 0;
+          if (resident) {
+            int dev = 0;
+            HIP_OK(hipGetDevice(&dev));
+            constexpr int lds = 4 * 7 * (RES_NP + 4) * 128;
+            static std::atomic<unsigned long long> attr_done{0};   // one bit per device
+            if (attr_needed(attr_done, dev)) {
+              HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<RES_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+              attr_set(attr_done, dev);
+            }
+            float *pk = (float *)((char *)ws + align_up((size_t)nb_max * align_up(fstat_len(K, M) * 8, 256), 256));
+            const dim3 gp((unsigned)nb, (unsigned)(K / 1024));
+            if (w) hipLaunchKernelGGL((res_pack_kernel<float, RES_NP, true>), gp, dim3(256), 0, st, a, pk);
+            else hipLaunchKernelGGL((res_pack_kernel<float, RES_NP, false>), gp, dim3(256), 0, st, a, pk);
+            ResArgs r;
+            memset(&r, 0, sizeof(r));
+            r.G = G; r.out = a.out_XTX; r.pk = pk; r.K = K; r.nb = (int)nb; r.seg0 = f0; r.nbc = K / RES_BC; r.groups = groups;
+            for (int b0 = 0; b0 < nblk_all; b0 += RES_WG) {
+              r.blk0 = b0; r.nblk = nblk_all - b0 < RES_WG ? nblk_all - b0 : RES_WG;
+              const unsigned wgs = (unsigned)(8 * (((size_t)r.nblk * groups + 7) / 8));
+              hipLaunchKernelGGL((res_apply_kernel<RES_NP>), dim3(wgs), dim3(256), lds, st, r);
+            }
+          }
+        }
+        if (resident) { a.x0 = a.nT64; a.gx = a.P64; a.gy = (int)ga.y; }
+        else { a.x0 = 0; a.gx = (int)ga.x; a.gy = (int)ga.y; }
+        if (!resident || (a.out_XTY && M > 0)) {
+          const dim3 g1((unsigned)(8 * (((size_t)a.gx * a.gy + 7) / 8)));
+          if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), g1, dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((small_apply_kernel<T, false>), g1, dim3(256), 0, st, a);
+        }
+        a.x0 = 0;
       }
     }
     timed_end(t_up, st);
@@ -927,6 +980,8 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
                           max_rows <= mid_maxn && mid_operands_ok<T>(X, Y, w, N, K, M) && !sw.force_fallback && !sw.no_fused;
   // (... and only if the fold stage is planned with one unit per fold -- always, unless a test forces a split plan)
   bool skip_small_ok = skip_small;
+  // (round 6: float32 batches the resident route takes -- K a multiple of 1024, folds of at most 16 rows -- stay small folds)
+  if (skip_small_ok && res_shape_ok(K, esize, max_rows) && n_folds >= 8 && K >= 2048) skip_small_ok = false;
   if (skip_small_ok) {
     Plan pp;
     if (make_plan(n_folds, max_rows, K, M, dtype, flags, (size_t)1 << 60, true, pp) != CVM_OK || pp.splits != 1) skip_small_ok = false;

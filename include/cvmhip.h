@@ -304,6 +304,15 @@ int cvm_clock_probe(void *device_buf, size_t bytes);
  * rounding per extra partial, cvmatrix_amd/fp32_gate.py).  No reference counterpart. */
 int cvm_debug_force_splits(int s_off, int s_diag);
 
+/* Experiments and tests: route float32 XTX batches of folds of at most 16 rows, K a multiple of 1024, through the
+ * round-6 "resident" kernel (csrc/resident.hpp: G in the register files of the whole chip, every tile computed
+ * directly; measured at parity with the default kernel at K = 4096 and slower below: opt-in).  on = 0 (the default)
+ * switches it off again; the environment variable CVM_RESIDENT=1 is read once, as the initial value.  Results stay
+ * within the float32 parity bar and exactly symmetric on either route; a caller that switches it on must size the
+ * workspace with cvm_fold_workspace_bytes AFTER the call (the route keeps an operand block per fold there; with a
+ * smaller workspace the folds are walked in smaller batches).  No reference counterpart. */
+int cvm_debug_resident(int on);
+
 /* Introspection for benchmarks/profiles: geometry chosen for a problem (info: int64[8]).
  * info[0]=row splits per fold of the off-diagonal 128x128 tiles, [6]=row splits of the diagonal
  * tiles (which also produce XTY and the column sums and cost less per row: the two kinds are cut

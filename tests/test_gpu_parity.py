@@ -1767,6 +1767,61 @@ def test_mid_tile_route_shapes(amd, dtype, K, M, sizes):
             assert bool((bx[f] == bx[f].T).all())
 
 
+@pytest.mark.parametrize("K,M,sizes,reps", [
+    (1024, 3, (16, 1, 0, 7, 16, 2, 9), 1),          # 32 blocks x up to 16 workgroup sets; ragged folds incl. an empty one
+    (1024, 0, (5,) * 70, 1),                         # more folds than workgroup sets: several folds per workgroup; no Y
+    (2048, 2, (16, 3, 12, 16, 8, 1, 16, 4, 11), 1),  # 128 blocks, two workgroup sets
+    (4096, 1, (16, 15, 2, 9), 2),                    # every block of the chip's 512; the diagonal tile in every wave position
+])
+def test_resident_route_float32(amd, K, M, sizes, reps):
+    """float32 XTX of batches of folds of at most 16 rows, K a multiple of 1024: res_apply_kernel (resident.hpp) -- G in
+    the register files of the whole chip, every tile computed directly from wave-private LDS-DMA operands behind counted
+    waits.  Every flag set that changes the operand block, weights with zeros and none, ragged folds, against the float64
+    oracle with the oracle's own float32 run as the yardstick; exact symmetry; bit-identical repetitions (a misplaced
+    wait would show as rare wrong tiles)."""
+    import torch
+    from cvmatrix_amd import _lib
+
+    lib = _lib.load()
+    assert lib.cvm_debug_resident(1) == 0        # the route is opt-in (measured at parity / slower: DESIGN.md 4.4)
+    try:
+        _resident_case(amd, K, M, sizes, reps, torch)
+    finally:
+        lib.cvm_debug_resident(0)
+
+
+def _resident_case(amd, K, M, sizes, reps, torch):
+    rng = np.random.default_rng(K + M)
+    N = sum(sizes) + 40
+    X = (rng.standard_normal((N, K)) * 0.5 + 0.25).astype(np.float32)
+    Y = rng.random((N, M)).astype(np.float32) if M else None
+    w = rng.random(N).astype(np.float32)
+    w[rng.choice(N, N // 10, replace=False)] = 0
+    perm = rng.permutation(N)
+    folds, o_ = [], 0
+    for n in sizes:
+        folds.append(np.sort(perm[o_:o_ + n])); o_ += n
+    check = range(len(folds)) if len(folds) <= 9 else (0, 1, 17, 33, len(folds) - 1)
+    cases = (((True,) * 4, w), ((False,) * 4, w), ((True, False, False, True), None), ((False, True, True, False), w))
+    for flags, wt in (cases if K < 4096 else cases[:1]):
+        m = amd.CVMatrix(*flags, dtype=np.float32)
+        m.fit(X, Y, wt)
+        o = OracleCVMatrix(*flags)
+        o.fit(X.astype(np.float64), None if Y is None else Y.astype(np.float64), None if wt is None else wt.astype(np.float64))
+        o32 = OracleCVMatrix(*flags, dtype=np.float32)
+        o32.fit(X, Y, wt)
+        bx = m.training_XTX_XTY_batched(folds)[0][0] if M else m.training_XTX_batched(folds)[0]
+        for f in check:
+            rx = o.training_XTX(folds[f])[0]
+            sx = o32.training_XTX(folds[f])[0]
+            assert_fp32_like_reference(bx[f], rx, sx, f"fold{f} XTX")
+        for f in range(len(folds)):
+            assert bool((bx[f] == bx[f].T).all()), f
+        for _ in range(reps):
+            bx2 = m.training_XTX_XTY_batched(folds)[0][0] if M else m.training_XTX_batched(folds)[0]
+            assert torch.equal(bx, bx2)
+
+
 @pytest.mark.parametrize("tool,args,env", [("fuzz_all.py", ["300", "101"], {}), ("fuzz_small.py", ["500", "102"], {}),
                                            ("fuzz_small.py", ["250", "103"], {"CVM_SMALL_MAXN": "128"})])
 def test_randomised_routes_against_the_oracle(tool, args, env):

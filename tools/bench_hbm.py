@@ -55,6 +55,21 @@ def fill():
 if __name__ == "__main__":
     print("CVM_SMALL_TILE =", os.environ.get("CVM_SMALL_TILE", "(default)"), " CVM_SMALL_FPB =", os.environ.get("CVM_SMALL_FPB", "-"))
     fill()
+    if len(sys.argv) > 1 and sys.argv[1] == "resident":     # the shapes of the round-6 resident route (opt-in: CVM_RESIDENT=1; otherwise the round-3 kernels)
+        print("CVM_RESIDENT =", os.environ.get("CVM_RESIDENT", "(default)"))
+        run("C5-hbm K=4096 M=1 f32 n=16", 20000, 4096, 1, 16, 48, np.float32)
+        run("K=4096 M=1 f32 n=8", 20000, 4096, 1, 8, 48, np.float32)
+        run("K=4096 M=1 f32 n=1", 20000, 4096, 1, 1, 48, np.float32)
+        if len(sys.argv) > 2 and sys.argv[2] == "first":
+            sys.exit(0)
+        run("K=4096 M=1 f32 n=16 12 folds", 20000, 4096, 1, 16, 12, np.float32)
+        run("K=3072 M=1 f32 n=16", 20000, 3072, 1, 16, 80, np.float32)
+        run("K=2048 M=8 f32 n=16 no centre/scale", 20000, 2048, 8, 16, 400, np.float32, flags=(False,) * 4)
+        run("K=2048 M=8 f32 n=16", 20000, 2048, 8, 16, 400, np.float32)
+        run("K=2048 M=1 f32 n=4", 20000, 2048, 1, 4, 400, np.float32)
+        run("K=1024 M=1 f32 n=16", 50000, 1024, 1, 16, 1000, np.float32)
+        run("K=1024 M=1 f32 n=4", 50000, 1024, 1, 4, 1000, np.float32)
+        sys.exit(0)
     run("C5-hbm K=4096 M=1 f32 n=16", 20000, 4096, 1, 16, 48, np.float32)
     run("K=4096 M=1 f64 n=16", 20000, 4096, 1, 16, 48, np.float64)
     run("LOOCV K=500 M=10 f64 n=1", 100000, 500, 10, 1, 2000, np.float64)
