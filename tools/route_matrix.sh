@@ -4,13 +4,13 @@
 # general Gram kernel instead of the LDS-DMA one, the separate finalize kernels instead of the
 # one-call sweep's, the tile kernel instead of the whole-rows kernel for tiny folds, no compaction /
 # inline statistics, no loop serving, the direct kernels for folds of up to 64 / 128 rows, the mid-size tile
-# kernel off / from one row per fold / up to 1000 rows per fold.
+# kernel off / from one row per fold / up to 1000 rows per fold, the round-6 resident route for float32 folds of <= 16 rows.
 #   bash tools/route_matrix.sh        (on the GPU box; about two minutes per switch)
 cd "$(dirname "$0")/.."
 for e in "CVM_FORCE_SPLITS=3,5" "CVM_FORCE_SPLITS=7,2" "CVM_NO_FUSED=1" "CVM_FORCE_FALLBACK=1" \
          "CVM_NO_SWEEP_MERGE=1" "CVM_NO_DIRECT=1" "CVM_PAD=0" "CVM_NO_COMPACT=1" "CVM_NO_INLINE_STATS=1" \
          "CVM_SERVE_LOOPS=0" "CVM_SMALL_MAXN=128" "CVM_SMALL_MAXN=64" "CVM_MID_TILE=0" "CVM_MID_MINN=1" "CVM_MID_MAXN=1000" \
-         "CVM_FUSED_PREPASS=1" "CVM_FUSED_ORDER=1" "CVM_VALIDATE_WEIGHTS=sync"; do
+         "CVM_FUSED_PREPASS=1" "CVM_FUSED_ORDER=1" "CVM_VALIDATE_WEIGHTS=sync" "CVM_RESIDENT=1"; do
   echo "== $e"
   mark="gpu"
   extra=""
