@@ -1016,10 +1016,16 @@ def main():
                 supp[name] = {"folds": nf_, "ms": round(ms1, 4), "folds_per_s": round(nf_ / ms1 * 1e3, 1),
                               "timing": "median of 3 samples of 8 calls back to back between one pair of events, after "
                                         ">= 40 ms of the same calls (like the headline's steps)",
+                              "route": ("res_apply_kernel (round 6: G resident in the register files of 512 persistent workgroups, both "
+                                        "triangles computed directly; float32, K >= 4096, >= 40 folds per batch) behind res_pack_kernel"
+                                        if (dt_ is np.float32 and k_ >= 4096 and k_ % 1024 == 0 and nv_ <= 16
+                                            and nf_ >= (32 if nv_ <= 8 else 40) and os.environ.get("CVM_RESIDENT", "2") != "0")
+                                        else ("small_rows_kernel" if nv_ <= 2 and k_ <= 512 else "small_apply_kernel")),
                               "kernel_ms": {"small_stats_kernel": round(kms[2] / max(kn[2], 1), 4),
                                             "update_kernels": round(kms[3] / max(kn[3], 1), 4),
                                             "what": "the library's events around the statistics kernel and around the update "
-                                                    "kernels of a call (tile / whole-rows kernel + XTY panels), mean of 4 calls"},
+                                                    "kernels of a call (operand blocks + resident kernel, or tile / whole-rows kernel "
+                                                    "+ XTY panels), mean of 4 calls"},
                               "fill_probe_GBps": round(fill_gbs, 1),
                               "roofline": {"bound": "hbm", "achieved": round(ach, 1),
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s",

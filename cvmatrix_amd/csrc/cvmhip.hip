@@ -406,8 +406,9 @@ int cvm_debug_force_splits(int s_off, int s_diag) {
   return CVM_OK;
 }
 
-int cvm_debug_resident(int on) {
-  g_resident.store(on ? 1 : 0, std::memory_order_relaxed);
+int cvm_debug_resident(int mode) {
+  if (mode < 0 || mode > 2) return fail(CVM_EINVAL, "cvm_debug_resident: 0 (never), 1 (wherever the shape allows) or 2 (the default rule)%s");
+  g_resident.store(mode, std::memory_order_relaxed);
   return CVM_OK;
 }
 

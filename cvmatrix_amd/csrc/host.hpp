@@ -592,21 +592,30 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // and tests.
 // Round 6, the resident route (resident.hpp: float32 XTX of folds of at most 16 rows with G in the register files of the
 // whole chip): K a multiple of the 1024-column block, at least 4 folds per workgroup set.
-// OPT-IN (cvm_debug_resident(1) / CVM_RESIDENT=1, read once as the initial value): measured at parity with small_apply_kernel
-// at K = 4096 and slower at K = 1024 ... 3072 (profiles/r6/hbm_regime/, DESIGN.md 4.4 "round 6").
+// Where it is the route (cvm_debug_resident / CVM_RESIDENT: 2 = this rule, the default; 1 = wherever the shape allows: tests and
+// measurements; 0 = never): K >= 4096 and batches of at least 40 folds (32 for folds of at most 8 rows).  Same-box alternations at
+// K = 4096 (profiles/r6/hbm_regime/resident_route.txt), ms per call against small_apply_kernel: 48 folds of 16 / 8 / 1 rows 0.659 /
+// 0.630 / 0.619 against 0.679 / 0.679 / 0.663; 160 folds 2.00-2.09 against 2.14-2.16; 32 folds 0.465 against 0.454, 12 folds 0.210
+// against 0.190 (a launch first reads all of G and writes its operand blocks: ~45 us, then 12.9 us per fold against 14.2); at
+// K = 1024 ... 3072 the shipped kernels win.
 constexpr int RES_NP = 16;
+constexpr int RES_AUTO_MINK = 4096;
 std::atomic<int> g_resident{-1};                        // -1: environment not consulted yet
-inline bool resident_on() {
+inline int resident_mode() {
   int v = g_resident.load(std::memory_order_relaxed);
-  if (v >= 0) return v != 0;
+  if (v >= 0) return v;
   const char *e = getenv("CVM_RESIDENT");
-  int init = (e && atoi(e) != 0) ? 1 : 0, expect = -1;
+  int init = e ? atoi(e) : 2, expect = -1;
+  if (init < 0 || init > 2) init = 2;
   g_resident.compare_exchange_strong(expect, init, std::memory_order_relaxed);
-  return g_resident.load(std::memory_order_relaxed) != 0;
+  return g_resident.load(std::memory_order_relaxed);
 }
+// the shape alone (workspace sizing); the number of folds is looked at when the batch is launched
 inline bool res_shape_ok(int K, int esize, int64_t max_rows) {
-  return resident_on() && esize == 4 && max_rows <= RES_NP && K >= RES_BC && K % RES_BC == 0;
+  const int mode = resident_mode();
+  return mode != 0 && esize == 4 && max_rows <= RES_NP && K >= RES_BC && K % RES_BC == 0 && (mode == 1 || K >= RES_AUTO_MINK);
 }
+inline bool res_folds_ok(int64_t nb, int64_t max_rows) { return resident_mode() == 1 || nb >= (max_rows <= 8 ? 32 : 40); }
 inline size_t res_pack_bytes(int K) { return (size_t)2 * (RES_NP + 4) * K * 4; }
 // workspace of the direct small-fold route per fold: the statistics vector (+ the resident route's operand block)
 inline size_t small_ws_per_fold(int K, int M, int esize, int64_t max_rows) {
@@ -715,40 +724,49 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
 #undef CVM_ROWS
       } else {
         // XTX by the resident route where the shape allows it (the XTY panels stay with small_apply_kernel)
-        bool resident = false;
+        bool resident = false, xty_packed = false;
         if constexpr (sizeof(T) == 4) {
           const bool shape = res_shape_ok(K, 4, max_rows);            // (K >= 1024 then)
           const int nblk_all = shape ? (K / 32) * (K / RES_BC) : 1;
           int groups = nblk_all >= RES_WG ? 1 : RES_WG / nblk_all;
           if (groups > nb / 4) groups = (int)(nb / 4);
-          resident = shape && a.out_XTX && !(flags & CVM_IDX_HOST) && groups >= 1 &&
+          resident = shape && res_folds_ok(nb, max_rows) && a.out_XTX && !(flags & CVM_IDX_HOST) && groups >= 1 &&
                      (uintptr_t)G % 4 == 0 && (uintptr_t)a.out_XTX % 4 == 0;
           if (resident) {
-            int dev = 0;
-            HIP_OK(hipGetDevice(&dev));
-            constexpr int lds = 4 * 7 * (RES_NP + 4) * 128;
-            static std::atomic<unsigned long long> attr_done{0};   // one bit per device
-            if (attr_needed(attr_done, dev)) {
-              HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<RES_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-              attr_set(attr_done, dev);
-            }
             float *pk = (float *)((char *)ws + align_up((size_t)nb_max * align_up(fstat_len(K, M) * 8, 256), 256));
-            const dim3 gp((unsigned)nb, (unsigned)(K / 1024));
-            if (w) hipLaunchKernelGGL((res_pack_kernel<float, RES_NP, true>), gp, dim3(256), 0, st, a, pk);
-            else hipLaunchKernelGGL((res_pack_kernel<float, RES_NP, false>), gp, dim3(256), 0, st, a, pk);
+            xty_packed = a.out_XTY && M > 0 && M <= RES_XTY_M;
             ResArgs r;
             memset(&r, 0, sizeof(r));
             r.G = G; r.out = a.out_XTX; r.pk = pk; r.K = K; r.nb = (int)nb; r.seg0 = f0; r.nbc = K / RES_BC; r.groups = groups;
-            for (int b0 = 0; b0 < nblk_all; b0 += RES_WG) {
-              r.blk0 = b0; r.nblk = nblk_all - b0 < RES_WG ? nblk_all - b0 : RES_WG;
-              const unsigned wgs = (unsigned)(8 * (((size_t)r.nblk * groups + 7) / 8));
-              hipLaunchKernelGGL((res_apply_kernel<RES_NP>), dim3(wgs), dim3(256), lds, st, r);
-            }
+            int dev = 0;
+            HIP_OK(hipGetDevice(&dev));
+            // (operand blocks of 8 rows for batches of folds of at most 8 rows: five k-pairs per tile instead of nine, two
+            //  LDS-DMA instructions per operand instead of three)
+            auto run = [&](auto np_tag) -> int {
+              constexpr int NPR = decltype(np_tag)::value;
+              constexpr int lds = 4 * 7 * (NPR + 4) * 128;
+              static std::atomic<unsigned long long> attr_done{0};   // one bit per device (one per instantiation)
+              if (attr_needed(attr_done, dev)) {
+                HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                attr_set(attr_done, dev);
+              }
+              const dim3 gp((unsigned)nb, (unsigned)(K / 1024));
+              if (w) hipLaunchKernelGGL((res_pack_kernel<float, NPR, true>), gp, dim3(256), 0, st, a, pk, (int)xty_packed);
+              else hipLaunchKernelGGL((res_pack_kernel<float, NPR, false>), gp, dim3(256), 0, st, a, pk, (int)xty_packed);
+              for (int b0 = 0; b0 < nblk_all; b0 += RES_WG) {
+                r.blk0 = b0; r.nblk = nblk_all - b0 < RES_WG ? nblk_all - b0 : RES_WG;
+                const unsigned wgs = (unsigned)(8 * (((size_t)r.nblk * groups + 7) / 8));
+                hipLaunchKernelGGL((res_apply_kernel<NPR>), dim3(wgs), dim3(256), lds, st, r);
+              }
+              return CVM_OK;
+            };
+            const int rc = max_rows <= 8 ? run(std::integral_constant<int, 8>{}) : run(std::integral_constant<int, RES_NP>{});
+            if (rc != CVM_OK) return rc;
           }
         }
         if (resident) { a.x0 = a.nT64; a.gx = a.P64; a.gy = (int)ga.y; }
         else { a.x0 = 0; a.gx = (int)ga.x; a.gy = (int)ga.y; }
-        if (!resident || (a.out_XTY && M > 0)) {
+        if (!resident || (a.out_XTY && M > 0 && !xty_packed)) {
           const dim3 g1((unsigned)(8 * (((size_t)a.gx * a.gy + 7) / 8)));
           if (w) hipLaunchKernelGGL((small_apply_kernel<T, true>), g1, dim3(256), 0, st, a);
           else hipLaunchKernelGGL((small_apply_kernel<T, false>), g1, dim3(256), 0, st, a);
@@ -981,7 +999,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   // (... and only if the fold stage is planned with one unit per fold -- always, unless a test forces a split plan)
   bool skip_small_ok = skip_small;
   // (round 6: float32 batches the resident route takes -- K a multiple of 1024, folds of at most 16 rows -- stay small folds)
-  if (skip_small_ok && res_shape_ok(K, esize, max_rows) && n_folds >= 8 && K >= 2048) skip_small_ok = false;
+  if (skip_small_ok && res_shape_ok(K, esize, max_rows) && res_folds_ok(n_folds, max_rows) && n_folds >= 8 && K >= 2048) skip_small_ok = false;
   if (skip_small_ok) {
     Plan pp;
     if (make_plan(n_folds, max_rows, K, M, dtype, flags, (size_t)1 << 60, true, pp) != CVM_OK || pp.splits != 1) skip_small_ok = false;

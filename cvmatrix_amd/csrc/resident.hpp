@@ -20,10 +20,10 @@
 // Operands: res_pack_kernel writes, per fold and 32-column tile, RB = NP + 4 rows x 32 columns  {x_0 .. x_NP-1 (zero rows
 // beyond the fold), sqrt(sw) mu, 0, sd^-1, 0}  ("P") and then the same with {-w x, -sqrt(sw) mu, 0, sd^-1, 0} ("Q"); an MFMA
 // operand of a tile is 2560 contiguous bytes and arrives by three LDS-DMA instructions, WAVE-PRIVATE
-// (no workgroup barrier anywhere in the kernel), one step (two tiles) ahead, behind a counted s_waitcnt vmcnt(stores of
-// the previous step + DMAs of the next) -- loads and stores retire in order, so a wait for a DMA issued BEFORE a step's
-// stores never waits for a store.  The row-side operands of a block are the same kind of operand (the block's 32 rows as
-// columns of P and Q), fetched once per fold.
+// (no workgroup barrier anywhere in the kernel), requested one step (two tiles) ahead; every step then drains its wave's
+// memory operations (CVM_RES_SAFE below: counted waits that never wait for a store were built first and measure SLOWER).
+// The row-side operands of a block are the same kind of operand (the block's 32 rows as columns of P and Q), fetched once
+// per fold.
 // tools/resident_probe.hip is the measurement this is built on (profiles/r6/hbm_regime/resident_probe.txt).
 #pragma once
 
@@ -42,39 +42,66 @@ struct ResArgs {
 };
 
 #ifndef CVM_RES_PROBE                    // (tools/res_kernel_probe.hip includes this file for res_apply_kernel alone)
-template <typename T, int NP, bool WEIGHTED> __global__ __launch_bounds__(256) void res_pack_kernel(const SmallArgs a, T *pk) {
+// (with_xty: the launch also writes the fold's XTY -- M <= RES_XTY_M responses -- in small_apply_kernel's arithmetic: the sum over
+//  the fold's rows of T(w x) * y in row order, then total - update, centring and scaling in float64)
+constexpr int RES_XTY_M = 16;
+template <typename T, int NP, bool WEIGHTED> __global__ __launch_bounds__(256) void res_pack_kernel(const SmallArgs a, T *pk, int with_xty) {
   constexpr int RB = NP + 4;
   const int f = blockIdx.x, K = a.K, M = a.M, tid = threadIdx.x;
   const int64_t o0 = a.offs[a.seg0 + f];
   const int n = (int)(a.offs[a.seg0 + f + 1] - o0);
   __shared__ int64_t rows[NP];
   __shared__ T wl[NP];
+  __shared__ T yl[NP][RES_XTY_M];
   if (tid < NP) {
     const int64_t r = tid < n ? a.idx[o0 + tid] : 0;
     rows[tid] = r;
     wl[tid] = tid < n ? (WEIGHTED ? ((const T *)a.w)[r] : (T)1) : (T)0;
   }
   __syncthreads();
+  if (with_xty && tid < NP * RES_XTY_M) {
+    const int r = tid / RES_XTY_M, m = tid - r * RES_XTY_M;
+    yl[r][m] = (r < n && m < M) ? ((const T *)a.Y)[rows[r] * (int64_t)M + m] : (T)0;
+  }
+  if (with_xty) __syncthreads();
   const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
   const double swt = fs[2 * K + 2 * M];
-  const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X;
+  const bool cX = a.flags & CVM_CENTER_X, sX = a.flags & CVM_SCALE_X, cY = a.flags & CVM_CENTER_Y, sY = a.flags & CVM_SCALE_Y;
   const double rsw = sqrt(swt);
   // tile-major: column tile j = c / 32 holds its P operand (RB rows x 32 columns) and then its Q operand
   T *blk = pk + (size_t)f * 2 * RB * K;
   const T *X = (const T *)a.X;
   for (int c = blockIdx.y * 256 + tid; c < K; c += gridDim.y * 256) {
     T *P = blk + (size_t)(c >> 5) * (2 * RB * 32) + (c & 31), *Q = P + RB * 32;
-#pragma unroll 4
+    T wx[NP];
+#pragma unroll
     for (int r = 0; r < NP; ++r) {
       const T x = r < n ? X[rows[r] * (int64_t)K + c] : (T)0;
+      wx[r] = WEIGHTED ? (T)(wl[r] * x) : x;
       P[r * 32] = x;
-      Q[r * 32] = r < n ? -(WEIGHTED ? (T)(wl[r] * x) : x) : (T)0;
+      Q[r * 32] = r < n ? -wx[r] : (T)0;
     }
     const T cm = cX ? (T)(rsw * fs[c]) : (T)0, sd = sX ? (T)fs[K + c] : (T)1;
     P[NP * 32] = cm; Q[NP * 32] = -cm;
     P[(NP + 1) * 32] = (T)0; Q[(NP + 1) * 32] = (T)0;
     P[(NP + 2) * 32] = sd; Q[(NP + 2) * 32] = sd;
     P[(NP + 3) * 32] = (T)0; Q[(NP + 3) * 32] = (T)0;
+    if (with_xty) {
+      const T *Ht = (const T *)a.H;
+      T *out = (T *)a.out_XTY + (size_t)(a.seg0 + f) * (size_t)K * M;
+      for (int m = 0; m < M; ++m) {
+        T s_ = 0;
+#pragma unroll
+        for (int r = 0; r < NP; ++r)
+          if (r < n) s_ += wx[r] * yl[r][m];
+        double v = (double)Ht[(size_t)c * M + m] - (double)s_;
+        if (cX || cY) v -= swt * (fs[c] * fs[2 * K + m]);
+        if (sX && sY) v = v * (fs[K + c] * fs[2 * K + M + m]);
+        else if (sX) v = v * fs[K + c];
+        else if (sY) v = v * fs[2 * K + M + m];
+        out[(size_t)c * M + m] = (T)v;
+      }
+    }
   }
 }
 #endif
@@ -98,8 +125,19 @@ __device__ __forceinline__ void res_wait_vmcnt(int n) {
 #undef CVM_W
 }
 
+// How a step waits for its operands (same-box runs of tools/res_kernel_probe.hip, K = 4096, TB/s of outputs, 48 / 160 folds):
+//   0  counted: vmcnt(32 stores of the previous step + 6 DMAs of the next) -- loads and stores retire in order, so the wait never
+//      waits for a store                                                                              5.15-5.21 / 5.18-5.20
+//   1  request the next step's operands, then vmcnt(0): every step drains its wave's stores AND waits out the round trip of the
+//      operands it has just requested                                                                 5.22-5.34 / 5.65-5.67
+//   2  vmcnt(0) first, then request the next step's operands (drained, but the operands a step ahead) 5.14 / 5.19-5.52
+// The wave that stalls longest is the fastest: fewer stores in flight per wave keep the workgroups of the chip inside the same
+// one or two output matrices (counted waits let them drift apart over a long batch).  1 is the product.
 #ifndef CVM_RES_SAFE
-#define CVM_RES_SAFE 0                   // 1: every counted wait becomes vmcnt(0) (debugging)
+#define CVM_RES_SAFE 1
+#endif
+#ifndef CVM_RES_DRAIN
+#define CVM_RES_DRAIN 0                  // measurements: 1 = s_waitcnt vmcnt(0) behind every tile's stores, 2 = vmcnt(16) there
 #endif
 #ifndef CVM_RES_ABLATE
 #define CVM_RES_ABLATE 0                 // probe builds only (wrong results by design): 1 no MFMA, 2 no DMA, 4 no stores, 8 no scaling multiply
@@ -125,14 +163,33 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
   if (nfm <= 0) return;
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)res_lds) + (unsigned)(wave * WAVE_LDS);
   const float *ldsf = reinterpret_cast<const float *>(res_lds + wave * WAVE_LDS);
-  // ---- the block of G ----
+  // ---- the block of G: four (two) 32 x 32 tiles at a time by LDS-DMA into the (still unused) operand buffers -- a DMA instruction moves
+  //      8 rows x 128 bytes (lane l: row l / 8, 16-byte piece l % 8), 16 instructions per group of four tiles instead of 64 two-line
+  //      loads -- then into the MFMA's C layout by LDS reads (launch prologue 50 -> ~20 us: it is what a call of few folds pays)
   f16v g[RES_NT];
   {
-    const float *G = (const float *)a.G + (size_t)r0 * K + cw + l32;
+    const unsigned vg = (unsigned)(((lane >> 3) * K) * 4 + (lane & 7) * 16);
+    const char *Gb = (const char *)a.G + ((size_t)r0 * K + cw) * 4;
+    constexpr int TGL = WAVE_LDS >= 16384 ? 4 : 2;          // tiles staged at a time (4 KB each)
 #pragma unroll
-    for (int t = 0; t < RES_NT; ++t)
+    for (int t0 = 0; t0 < RES_NT; t0 += TGL) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) g[t][v] = G[(size_t)((v & 3) + 8 * (v >> 2) + 4 * lh) * K + 32 * t];
+      for (int t = 0; t < TGL; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const char *sb = Gb + (size_t)(8 * i) * K * 4 + 128 * (t0 + t);
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(vg), "s"(sb), "s"(lds0 + (unsigned)(4096 * t + 1024 * i)) : "memory");
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < TGL; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) g[t0 + t][v] = ldsf[1024 * t + ((v & 3) + 8 * (v >> 2) + 4 * lh) * 32 + l32];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
   const unsigned vdma = (unsigned)(lane * 16);                                 // lane l of a DMA: 16-byte piece l of 1 KiB
   const unsigned vout = (unsigned)((4 * lh * K + l32) * 4);
@@ -189,7 +246,14 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       const int par = s & 1;                       // STEPS is even: the parity of a step does not depend on the fold
-      // ---- next step's operands, then wait for this step's ----
+      // ---- this step's operands have arrived; next step's are requested ----
+#if CVM_RES_SAFE == 2
+      // drain FIRST (this step's operands were requested a step ago, in front of that step's stores), then request the next
+      // step's: the operands still travel a whole step ahead, and no store of an earlier step is in flight beside this step's
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (s + 1 < STEPS) issue_step(fb, s + 1, par ^ 1);
+      else if (fi + 1 < nfm) issue_step(fb + pk_step, 0, par ^ 1);
+#else
       if (s + 1 < STEPS) issue_step(fb, s + 1, par ^ 1);
       else if (fi + 1 < nfm) issue_step(fb + pk_step, 0, par ^ 1);
 #if CVM_RES_SAFE
@@ -198,6 +262,7 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
       if (s == 0 && fi == 0) res_wait_vmcnt(NDMA);
       else if (s + 1 == STEPS && fi + 1 == nfm) res_wait_vmcnt(NST);
       else res_wait_vmcnt(NST + NDMA);
+#endif
 #endif
       if (s == 0) {
         const float *A0 = ldsf + 6 * (OPB / 4), *A1 = ldsf + 5 * (OPB / 4);
@@ -249,6 +314,8 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
             asm volatile("" : "+s"(obv));
           }
         }
+        if (CVM_RES_DRAIN == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (CVM_RES_DRAIN == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       }
     }
   }

@@ -304,14 +304,15 @@ int cvm_clock_probe(void *device_buf, size_t bytes);
  * rounding per extra partial, cvmatrix_amd/fp32_gate.py).  No reference counterpart. */
 int cvm_debug_force_splits(int s_off, int s_diag);
 
-/* Experiments and tests: route float32 XTX batches of folds of at most 16 rows, K a multiple of 1024, through the
- * round-6 "resident" kernel (csrc/resident.hpp: G in the register files of the whole chip, every tile computed
- * directly; measured at parity with the default kernel at K = 4096 and slower below: opt-in).  on = 0 (the default)
- * switches it off again; the environment variable CVM_RESIDENT=1 is read once, as the initial value.  Results stay
- * within the float32 parity bar and exactly symmetric on either route; a caller that switches it on must size the
- * workspace with cvm_fold_workspace_bytes AFTER the call (the route keeps an operand block per fold there; with a
- * smaller workspace the folds are walked in smaller batches).  No reference counterpart. */
-int cvm_debug_resident(int on);
+/* Experiments and tests: where float32 XTX batches of folds of at most 16 rows, K a multiple of 1024, take the round-6
+ * "resident" kernel (csrc/resident.hpp: G in the register files of the whole chip, every tile computed directly, no
+ * mirrored store).  mode 2 (the default): K >= 4096 and at least 32 folds per batch, where it measures 2-7 % faster than
+ * the tile kernel; 1: wherever the shape allows (slower below K = 4096 and for few folds); 0: never.  The environment
+ * variable CVM_RESIDENT=0|1|2 is read once, as the initial value.  Results stay within the float32 parity bar and exactly
+ * symmetric on either route; size the workspace with cvm_fold_workspace_bytes AFTER changing the mode (the route keeps an
+ * operand block per fold there; with a smaller workspace the folds are walked in smaller batches or take the tile
+ * kernel).  No reference counterpart. */
+int cvm_debug_resident(int mode);
 
 /* Introspection for benchmarks/profiles: geometry chosen for a problem (info: int64[8]).
  * info[0]=row splits per fold of the off-diagonal 128x128 tiles, [6]=row splits of the diagonal

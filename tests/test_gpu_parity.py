@@ -1783,11 +1783,11 @@ def test_resident_route_float32(amd, K, M, sizes, reps):
     from cvmatrix_amd import _lib
 
     lib = _lib.load()
-    assert lib.cvm_debug_resident(1) == 0        # the route is opt-in (measured at parity / slower: DESIGN.md 4.4)
+    assert lib.cvm_debug_resident(1) == 0        # wherever the shape allows (the default rule: K >= 4096, >= 32 folds per batch)
     try:
         _resident_case(amd, K, M, sizes, reps, torch)
     finally:
-        lib.cvm_debug_resident(0)
+        lib.cvm_debug_resident(2)
 
 
 def _resident_case(amd, K, M, sizes, reps, torch):
@@ -1820,6 +1820,52 @@ def _resident_case(amd, K, M, sizes, reps, torch):
         for _ in range(reps):
             bx2 = m.training_XTX_XTY_batched(folds)[0][0] if M else m.training_XTX_batched(folds)[0]
             assert torch.equal(bx, bx2)
+
+
+def test_resident_route_is_the_default_for_wide_float32_batches(amd):
+    """The library's own rule (cvm_debug_resident mode 2): float32, K = 4096, 40 folds of at most 16 rows -> res_apply_kernel
+    (BASELINE's C5-hbm shape).  The default call must be bit-identical to the forced route (same kernel), within the float32 gate
+    of the oracle, exactly symmetric, and agree with the tile kernel (mode 0) to float32 rounding."""
+    import torch
+    from cvmatrix_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(4096)
+    K, M, P = 4096, 1, 40
+    sizes = rng.integers(1, 17, P)
+    N = int(sizes.sum()) + 30
+    X = (rng.standard_normal((N, K)) * 0.5 + 0.25).astype(np.float32)
+    Y = rng.random((N, M)).astype(np.float32)
+    w = rng.random(N).astype(np.float32)
+    perm = rng.permutation(N)
+    folds, o_ = [], 0
+    for n in sizes:
+        folds.append(np.sort(perm[o_:o_ + int(n)])); o_ += int(n)
+    m = amd.CVMatrix(dtype=np.float32)
+    m.fit(X, Y, w)
+    (bx, by), _ = m.training_XTX_XTY_batched(folds)                      # the default rule
+    try:
+        assert lib.cvm_debug_resident(1) == 0
+        (fx, fy), _ = m.training_XTX_XTY_batched(folds)
+        assert lib.cvm_debug_resident(0) == 0
+        (tx, ty), _ = m.training_XTX_XTY_batched(folds)
+    finally:
+        lib.cvm_debug_resident(2)
+    assert torch.equal(bx, fx) and torch.equal(by, fy)
+    assert not torch.equal(bx, tx)                                       # (a different kernel: different roundings)
+    scale = float(tx.abs().max())
+    assert float((bx - tx).abs().max()) <= 1e-3 * scale                  # (sanity; the gate against the oracle is below)
+    assert torch.equal(by, ty)                                           # (XTY: the tile kernel's arithmetic in res_pack_kernel)
+    o = OracleCVMatrix()
+    o.fit(X.astype(np.float64), Y.astype(np.float64), w.astype(np.float64))
+    o32 = OracleCVMatrix(dtype=np.float32)
+    o32.fit(X, Y, w)
+    for f in (0, 17, P - 1):
+        (rx, ry), _ = o.training_XTX_XTY(folds[f])
+        (sx, sy), _ = o32.training_XTX_XTY(folds[f])
+        assert_fp32_like_reference(bx[f], rx, sx, f"fold{f} XTX")
+        assert_fp32_like_reference(by[f], ry, sy, f"fold{f} XTY")
+        assert bool((bx[f] == bx[f].T).all())
 
 
 @pytest.mark.parametrize("tool,args,env", [("fuzz_all.py", ["300", "101"], {}), ("fuzz_small.py", ["500", "102"], {}),

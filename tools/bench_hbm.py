@@ -55,7 +55,7 @@ def fill():
 if __name__ == "__main__":
     print("CVM_SMALL_TILE =", os.environ.get("CVM_SMALL_TILE", "(default)"), " CVM_SMALL_FPB =", os.environ.get("CVM_SMALL_FPB", "-"))
     fill()
-    if len(sys.argv) > 1 and sys.argv[1] == "resident":     # the shapes of the round-6 resident route (opt-in: CVM_RESIDENT=1; otherwise the round-3 kernels)
+    if len(sys.argv) > 1 and sys.argv[1] == "resident":     # the shapes of the round-6 resident route (CVM_RESIDENT=1: wherever the shape allows; 0: never; default: K >= 4096 and >= 32 folds)
         print("CVM_RESIDENT =", os.environ.get("CVM_RESIDENT", "(default)"))
         run("C5-hbm K=4096 M=1 f32 n=16", 20000, 4096, 1, 16, 48, np.float32)
         run("K=4096 M=1 f32 n=8", 20000, 4096, 1, 8, 48, np.float32)
@@ -63,6 +63,9 @@ if __name__ == "__main__":
         if len(sys.argv) > 2 and sys.argv[2] == "first":
             sys.exit(0)
         run("K=4096 M=1 f32 n=16 12 folds", 20000, 4096, 1, 16, 12, np.float32)
+        run("K=4096 M=1 f32 n=16 24 folds", 20000, 4096, 1, 16, 24, np.float32)
+        run("K=4096 M=1 f32 n=16 32 folds", 20000, 4096, 1, 16, 32, np.float32)
+        run("K=4096 M=1 f32 n=16 160 folds", 20000, 4096, 1, 16, 160, np.float32)
         run("K=3072 M=1 f32 n=16", 20000, 3072, 1, 16, 80, np.float32)
         run("K=2048 M=8 f32 n=16 no centre/scale", 20000, 2048, 8, 16, 400, np.float32, flags=(False,) * 4)
         run("K=2048 M=8 f32 n=16", 20000, 2048, 8, 16, 400, np.float32)

@@ -10,7 +10,7 @@ cd "$(dirname "$0")/.."
 for e in "CVM_FORCE_SPLITS=3,5" "CVM_FORCE_SPLITS=7,2" "CVM_NO_FUSED=1" "CVM_FORCE_FALLBACK=1" \
          "CVM_NO_SWEEP_MERGE=1" "CVM_NO_DIRECT=1" "CVM_PAD=0" "CVM_NO_COMPACT=1" "CVM_NO_INLINE_STATS=1" \
          "CVM_SERVE_LOOPS=0" "CVM_SMALL_MAXN=128" "CVM_SMALL_MAXN=64" "CVM_MID_TILE=0" "CVM_MID_MINN=1" "CVM_MID_MAXN=1000" \
-         "CVM_FUSED_PREPASS=1" "CVM_FUSED_ORDER=1" "CVM_VALIDATE_WEIGHTS=sync" "CVM_RESIDENT=1"; do
+         "CVM_FUSED_PREPASS=1" "CVM_FUSED_ORDER=1" "CVM_VALIDATE_WEIGHTS=sync" "CVM_RESIDENT=1" "CVM_RESIDENT=0"; do
   echo "== $e"
   mark="gpu"
   extra=""
