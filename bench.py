@@ -1018,7 +1018,7 @@ def main():
                                         ">= 40 ms of the same calls (like the headline's steps)",
                               "route": ("res_apply_kernel (round 6: G resident in the register files of 512 persistent workgroups, both "
                                         "triangles computed directly; float32, K >= 4096, >= 40 folds per batch) behind res_pack_kernel"
-                                        if (dt_ is np.float32 and k_ >= 4096 and k_ % 1024 == 0 and nv_ <= 16
+                                        if (dt_ is np.float32 and k_ % 4096 == 0 and nv_ <= 16
                                             and nf_ >= (32 if nv_ <= 8 else 40) and os.environ.get("CVM_RESIDENT", "2") != "0")
                                         else ("small_rows_kernel" if nv_ <= 2 and k_ <= 512 else "small_apply_kernel")),
                               "kernel_ms": {"small_stats_kernel": round(kms[2] / max(kn[2], 1), 4),

@@ -593,11 +593,13 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // Round 6, the resident route (resident.hpp: float32 XTX of folds of at most 16 rows with G in the register files of the
 // whole chip): K a multiple of the 1024-column block, at least 4 folds per workgroup set.
 // Where it is the route (cvm_debug_resident / CVM_RESIDENT: 2 = this rule, the default; 1 = wherever the shape allows: tests and
-// measurements; 0 = never): K >= 4096 and batches of at least 40 folds (32 for folds of at most 8 rows).  Same-box alternations at
+// measurements; 0 = never): K a multiple of 4096 (whole passes of 512 blocks) and batches of at least 40 folds (32 for folds of at most
+// 8 rows).  Same-box alternations at
 // K = 4096 (profiles/r6/hbm_regime/resident_route.txt), ms per call against small_apply_kernel: 48 folds of 16 / 8 / 1 rows 0.659 /
 // 0.630 / 0.619 against 0.679 / 0.679 / 0.663; 160 folds 2.00-2.09 against 2.14-2.16; 32 folds 0.465 against 0.454, 12 folds 0.210
 // against 0.190 (a launch first reads all of G and writes its operand blocks: ~45 us, then 12.9 us per fold against 14.2); at
-// K = 1024 ... 3072 the shipped kernels win.
+// K = 1024 and 3072 (288 blocks: 56 % of the workgroups) the shipped kernels win, at K = 2048 it is a wash (-3 % from 160 folds on for
+// 16-row folds, nothing for 8-row ones); K = 8192, 40 folds: 2.06-2.08 against 2.22-2.30 (16 rows), 1.95 against 1.93 (8 rows).
 constexpr int RES_NP = 16;
 constexpr int RES_AUTO_MINK = 4096;
 std::atomic<int> g_resident{-1};                        // -1: environment not consulted yet
@@ -613,7 +615,7 @@ inline int resident_mode() {
 // the shape alone (workspace sizing); the number of folds is looked at when the batch is launched
 inline bool res_shape_ok(int K, int esize, int64_t max_rows) {
   const int mode = resident_mode();
-  return mode != 0 && esize == 4 && max_rows <= RES_NP && K >= RES_BC && K % RES_BC == 0 && (mode == 1 || K >= RES_AUTO_MINK);
+  return mode != 0 && esize == 4 && max_rows <= RES_NP && K >= RES_BC && K % RES_BC == 0 && (mode == 1 || K % RES_AUTO_MINK == 0);
 }
 inline bool res_folds_ok(int64_t nb, int64_t max_rows) { return resident_mode() == 1 || nb >= (max_rows <= 8 ? 32 : 40); }
 inline size_t res_pack_bytes(int K) { return (size_t)2 * (RES_NP + 4) * K * 4; }

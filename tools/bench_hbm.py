@@ -66,6 +66,14 @@ if __name__ == "__main__":
         run("K=4096 M=1 f32 n=16 24 folds", 20000, 4096, 1, 16, 24, np.float32)
         run("K=4096 M=1 f32 n=16 32 folds", 20000, 4096, 1, 16, 32, np.float32)
         run("K=4096 M=1 f32 n=16 160 folds", 20000, 4096, 1, 16, 160, np.float32)
+        if len(sys.argv) > 2 and sys.argv[2] == "wide":
+            run("K=8192 M=1 f32 n=16 40 folds", 20000, 8192, 1, 16, 40, np.float32, R=4)
+            run("K=8192 M=1 f32 n=8 40 folds", 20000, 8192, 1, 8, 40, np.float32, R=4)
+            run("K=2048 M=1 f32 n=16 80 folds", 20000, 2048, 1, 16, 80, np.float32)
+            run("K=2048 M=1 f32 n=16 160 folds", 20000, 2048, 1, 16, 160, np.float32)
+            run("K=2048 M=1 f32 n=8 160 folds", 20000, 2048, 1, 8, 160, np.float32)
+            run("K=2048 M=1 f32 n=16 240 folds", 20000, 2048, 1, 16, 240, np.float32)
+            sys.exit(0)
         run("K=3072 M=1 f32 n=16", 20000, 3072, 1, 16, 80, np.float32)
         run("K=2048 M=8 f32 n=16 no centre/scale", 20000, 2048, 8, 16, 400, np.float32, flags=(False,) * 4)
         run("K=2048 M=8 f32 n=16", 20000, 2048, 8, 16, 400, np.float32)
