@@ -752,7 +752,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
                 HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 attr_set(attr_done, dev);
               }
-              const dim3 gp((unsigned)nb, (unsigned)(K / 1024));
+              const dim3 gp((unsigned)nb, (unsigned)(K / 256));        // one column per thread
               if (w) hipLaunchKernelGGL((res_pack_kernel<float, NPR, true>), gp, dim3(256), 0, st, a, pk, (int)xty_packed);
               else hipLaunchKernelGGL((res_pack_kernel<float, NPR, false>), gp, dim3(256), 0, st, a, pk, (int)xty_packed);
               for (int b0 = 0; b0 < nblk_all; b0 += RES_WG) {

@@ -148,7 +148,12 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
   constexpr int RB = NP + 4, KK = NP / 2 + 1;       // rows of an operand block; k-pairs of the chain (rows and the centring term)
   constexpr int OPB = RB * 128;                     // bytes of a tile operand in LDS: RB rows x 32 floats
   constexpr int NI = (RB + 7) / 8;                  // LDS-DMA instructions per operand (8 rows x 128 B each)
-  constexpr int STEPS = RES_NT / 2, ST_STORES = 32; // two tiles per step: 32 store instructions
+#ifndef CVM_RES_TS
+#define CVM_RES_TS 2                     // tiles per step: 2 = operands double-buffered, requested one step ahead; 4 = single-buffered
+#endif                                   //   steps of four tiles (the request, the drain and the round trip twice per fold instead of four times):
+                                         //   measured the same within the scatter (1.89-2.01 ms for 160 folds either way); 2 is the product
+  constexpr int TS = CVM_RES_TS, SB = TS == 4;      // (SB: the step's own operands are requested at its top)
+  constexpr int STEPS = RES_NT / TS, ST_STORES = 16 * TS;
   constexpr int WAVE_LDS = OPB * 7;                 // B[2][2] | the diagonal tile's second operand | A[2]
   extern __shared__ __attribute__((aligned(16))) char res_lds[];
   const int K = a.K, tid = threadIdx.x;
@@ -218,11 +223,11 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
   // the operands of step s of the fold at `fb` -> B buffers of parity `par`
   auto issue_step = [&](const char *fb, int s, int par) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = 2 * s + tt, j = jt0 + t;
+    for (int tt = 0; tt < TS; ++tt) {
+      const int t = TS * s + tt, j = jt0 + t;
       const char *tb = fb + (size_t)j * (2 * OPB);
       // above the diagonal (and on it): B = x (P), A = -w x; below: B = -w x (Q), A = x
-      dma_run(tb + (j >= band ? 0 : OPB), OPB, lds0 + (unsigned)((2 * par + tt) * OPB));
+      dma_run(tb + (j >= band ? 0 : OPB), OPB, lds0 + (unsigned)(((SB ? 0 : 2 * par) + tt) * OPB));
       if (j == band) dma_run(tb + OPB, OPB, lds0 + 4u * OPB);
     }
   };
@@ -233,7 +238,7 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
   char *out0 = (char *)a.out + ((size_t)(a.seg0 + group) * K * K + (size_t)r0 * K + cw) * 4;
   const size_t out_step = (size_t)a.groups * K * K * 4;
   issue_A(pk0);
-  issue_step(pk0, 0, 0);
+  if (!SB) issue_step(pk0, 0, 0);
   float aQ[KK], aP[KK], aSd = 0.f;
   // Waits.  In front of step g the wave's queue holds, oldest first: the operands of step g (issued one step ago), at
   // most one A-side run, the 32 stores of step g - 1, the operands of step g + 1 (2 NI instructions; 3 NI for the one
@@ -247,7 +252,10 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
     for (int s = 0; s < STEPS; ++s) {
       const int par = s & 1;                       // STEPS is even: the parity of a step does not depend on the fold
       // ---- this step's operands have arrived; next step's are requested ----
-#if CVM_RES_SAFE == 2
+#if CVM_RES_TS == 4
+      issue_step(fb, s, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif CVM_RES_SAFE == 2
       // drain FIRST (this step's operands were requested a step ago, in front of that step's stores), then request the next
       // step's: the operands still travel a whole step ahead, and no store of an earlier step is in flight beside this step's
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -273,9 +281,9 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
         if (fi + 1 < nfm) issue_A(fb + pk_step);   // (older than this step's stores: the next step's wait covers it)
       }
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * s + tt, j = jt0 + t;
-        const float *B = ldsf + (2 * par + tt) * (OPB / 4);
+      for (int tt = 0; tt < TS; ++tt) {
+        const int t = TS * s + tt, j = jt0 + t;
+        const float *B = ldsf + ((SB ? 0 : 2 * par) + tt) * (OPB / 4);
         const bool up = j >= band;
         f16v acc = g[t];
 #pragma unroll
