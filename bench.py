@@ -1016,10 +1016,11 @@ def main():
                 supp[name] = {"folds": nf_, "ms": round(ms1, 4), "folds_per_s": round(nf_ / ms1 * 1e3, 1),
                               "timing": "median of 3 samples of 8 calls back to back between one pair of events, after "
                                         ">= 40 ms of the same calls (like the headline's steps)",
-                              "route": ("res_apply_kernel (round 6: G resident in the register files of 512 persistent workgroups, both "
-                                        "triangles computed directly; float32, K >= 4096, >= 40 folds per batch) behind res_pack_kernel"
+                              "route": ("res8_apply_kernel (round 6: G resident in the register files of 512 persistent workgroups, both "
+                                        "triangles computed directly; float32, K = 2048 or a multiple of 4096, >= 16 folds per workgroup "
+                                        "set) behind res_pack_kernel"
                                         if (dt_ is np.float32 and k_ % 4096 == 0 and nv_ <= 16
-                                            and nf_ >= (32 if nv_ <= 8 else 40) and os.environ.get("CVM_RESIDENT", "2") != "0")
+                                            and nf_ >= 16 and os.environ.get("CVM_RESIDENT", "2") != "0")
                                         else ("small_rows_kernel" if nv_ <= 2 and k_ <= 512 else "small_apply_kernel")),
                               "kernel_ms": {"small_stats_kernel": round(kms[2] / max(kn[2], 1), 4),
                                             "update_kernels": round(kms[3] / max(kn[3], 1), 4),

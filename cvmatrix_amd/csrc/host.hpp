@@ -593,13 +593,13 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // Round 6, the resident route (resident.hpp: float32 XTX of folds of at most 16 rows with G in the register files of the
 // whole chip): K a multiple of the 1024-column block, at least 4 folds per workgroup set.
 // Where it is the route (cvm_debug_resident / CVM_RESIDENT: 2 = this rule, the default; 1 = wherever the shape allows: tests and
-// measurements; 0 = never): K a multiple of 4096 (whole passes of 512 blocks) and batches of at least 40 folds (32 for folds of at most
-// 8 rows).  Same-box alternations at
-// K = 4096 (profiles/r6/hbm_regime/resident_route.txt), ms per call against small_apply_kernel: 48 folds of 16 / 8 / 1 rows 0.659 /
-// 0.630 / 0.619 against 0.679 / 0.679 / 0.663; 160 folds 2.00-2.09 against 2.14-2.16; 32 folds 0.465 against 0.454, 12 folds 0.210
-// against 0.190 (a launch first reads all of G and writes its operand blocks: ~45 us, then 12.9 us per fold against 14.2); at
-// K = 1024 and 3072 (288 blocks: 56 % of the workgroups) the shipped kernels win, at K = 2048 it is a wash (-3 % from 160 folds on for
-// 16-row folds, nothing for 8-row ones); K = 8192, 40 folds: 2.06-2.08 against 2.22-2.30 (16 rows), 1.95 against 1.93 (8 rows).
+// measurements; 0 = never): K = 2048 or a multiple of 4096 (the blocks fill whole sets of 512 workgroups: K = 3072 has 288 blocks and
+// loses 20 %) and at least 16 folds per workgroup set (K >= 4096: 16 folds per batch; K = 2048, four sets: 64).  Same-box alternations
+// with the eight-wave kernel (profiles/r6/hbm_regime/resident_route.txt section 5), ms per call against the tile kernel / mid_tile_kernel:
+// K = 4096, 48 folds of 16 / 8 / 1 rows 0.611 / 0.583 / 0.580 against 0.673 / 0.653 / 0.642 (-9 ... -11 %), 160 folds 1.91 against
+// 2.20 (-13 %), 24 folds 0.337 against 0.352, 12 folds 0.190 against 0.189; K = 8192, 40 folds 1.95 against 2.25 (8 rows: 1.85 / 1.98);
+// K = 2048, 400 folds 1.25-1.29 against 1.42-1.45, 80 folds 0.290 against 0.31; K = 1024, 1000 folds of 16 rows 0.85 against 0.95
+// but of 4 rows 0.80 against 0.775: not in the rule.
 constexpr int RES_NP = 16;
 constexpr int RES_AUTO_MINK = 4096;
 std::atomic<int> g_resident{-1};                        // -1: environment not consulted yet
@@ -615,9 +615,12 @@ inline int resident_mode() {
 // the shape alone (workspace sizing); the number of folds is looked at when the batch is launched
 inline bool res_shape_ok(int K, int esize, int64_t max_rows) {
   const int mode = resident_mode();
-  return mode != 0 && esize == 4 && max_rows <= RES_NP && K >= RES_BC && K % RES_BC == 0 && (mode == 1 || K % RES_AUTO_MINK == 0);
+  return mode != 0 && esize == 4 && max_rows <= RES_NP && K >= RES_BC && K % RES_BC == 0 && (mode == 1 || K == 2048 || K % RES_AUTO_MINK == 0);
 }
-inline bool res_folds_ok(int64_t nb, int64_t max_rows) { return resident_mode() == 1 || nb >= (max_rows <= 8 ? 32 : 40); }
+inline bool res_folds_ok(int64_t nb, int K) {
+  const int nblk = (K / 32) * (K / RES_BC), sets = nblk >= RES_WG ? 1 : RES_WG / (nblk > 0 ? nblk : 1);
+  return resident_mode() == 1 || nb >= (int64_t)16 * sets;
+}
 inline size_t res_pack_bytes(int K) { return (size_t)2 * (RES_NP + 4) * K * 4; }
 // workspace of the direct small-fold route per fold: the statistics vector (+ the resident route's operand block)
 inline size_t small_ws_per_fold(int K, int M, int esize, int64_t max_rows) {
@@ -732,7 +735,7 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
           const int nblk_all = shape ? (K / 32) * (K / RES_BC) : 1;
           int groups = nblk_all >= RES_WG ? 1 : RES_WG / nblk_all;
           if (groups > nb / 4) groups = (int)(nb / 4);
-          resident = shape && res_folds_ok(nb, max_rows) && a.out_XTX && !(flags & CVM_IDX_HOST) && groups >= 1 &&
+          resident = shape && res_folds_ok(nb, K) && a.out_XTX && !(flags & CVM_IDX_HOST) && groups >= 1 &&
                      (uintptr_t)G % 4 == 0 && (uintptr_t)a.out_XTX % 4 == 0;
           if (resident) {
             float *pk = (float *)((char *)ws + align_up((size_t)nb_max * align_up(fstat_len(K, M) * 8, 256), 256));
@@ -746,10 +749,13 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
             //  LDS-DMA instructions per operand instead of three)
             auto run = [&](auto np_tag) -> int {
               constexpr int NPR = decltype(np_tag)::value;
-              constexpr int lds = 4 * 7 * (NPR + 4) * 128;
+              // eight waves per workgroup (four per SIMD) unless CVM_RES_WAVES=4 asks for the first kernel (comparisons)
+              static const bool four = getenv("CVM_RES_WAVES") && atoi(getenv("CVM_RES_WAVES")) == 4;
+              constexpr int lds4 = 4 * 7 * (NPR + 4) * 128, lds8 = 21 * (NPR + 4) * 128;
               static std::atomic<unsigned long long> attr_done{0};   // one bit per device (one per instantiation)
               if (attr_needed(attr_done, dev)) {
-                HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+                HIP_OK(hipFuncSetAttribute((const void *)res8_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
                 attr_set(attr_done, dev);
               }
               const dim3 gp((unsigned)nb, (unsigned)(K / 256));        // one column per thread
@@ -758,7 +764,8 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
               for (int b0 = 0; b0 < nblk_all; b0 += RES_WG) {
                 r.blk0 = b0; r.nblk = nblk_all - b0 < RES_WG ? nblk_all - b0 : RES_WG;
                 const unsigned wgs = (unsigned)(8 * (((size_t)r.nblk * groups + 7) / 8));
-                hipLaunchKernelGGL((res_apply_kernel<NPR>), dim3(wgs), dim3(256), lds, st, r);
+                if (four) hipLaunchKernelGGL((res_apply_kernel<NPR>), dim3(wgs), dim3(256), lds4, st, r);
+                else hipLaunchKernelGGL((res8_apply_kernel<NPR>), dim3(wgs), dim3(512), lds8, st, r);
               }
               return CVM_OK;
             };
@@ -1001,7 +1008,7 @@ int fold_update_impl(const void *X, const void *Y, const void *w, const int64_t 
   // (... and only if the fold stage is planned with one unit per fold -- always, unless a test forces a split plan)
   bool skip_small_ok = skip_small;
   // (round 6: float32 batches the resident route takes -- K a multiple of 1024, folds of at most 16 rows -- stay small folds)
-  if (skip_small_ok && res_shape_ok(K, esize, max_rows) && res_folds_ok(n_folds, max_rows) && n_folds >= 8 && K >= 2048) skip_small_ok = false;
+  if (skip_small_ok && res_shape_ok(K, esize, max_rows) && res_folds_ok(n_folds, K) && n_folds >= 8 && K >= 2048) skip_small_ok = false;
   if (skip_small_ok) {
     Plan pp;
     if (make_plan(n_folds, max_rows, K, M, dtype, flags, (size_t)1 << 60, true, pp) != CVM_OK || pp.splits != 1) skip_small_ok = false;

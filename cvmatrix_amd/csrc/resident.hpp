@@ -328,3 +328,151 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
     }
   }
 }
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// Third version (round 6): the same 32 x 1024 block per workgroup, EIGHT waves of four tiles each -- 64 registers of G per lane,
+// 512 threads, two workgroups per CU = four waves per SIMD instead of two: while one wave is held at the issue of its MFMA
+// chain (640 cycles per tile of a 16-row fold) three others can issue stores.  What had to give: the row-side operands are
+// shared by the workgroup (one LDS copy per fold, requested by wave 0 a fold ahead, handed over behind ONE LDS-only barrier
+// per fold) and read from LDS per tile instead of living in registers; a step is two tiles whose operands are requested at its
+// top (single-buffered: csrc comment on CVM_RES_TS -- the same rate as requesting a step ahead once every step drains anyway).
+// LDS per workgroup: A[2 folds][P | Q] | the diagonal tile's second operand | B[8 waves][2 tiles] = 21 operands (53.8 KB).
+constexpr int RES8_NT = 4;
+template <int NP> __global__ __launch_bounds__(512, 2) void res8_apply_kernel(const ResArgs a) {
+  typedef float f16v __attribute__((ext_vector_type(16)));
+  constexpr int RB = NP + 4, KK = NP / 2 + 1, OPB = RB * 128;
+  constexpr int TS = 2, STEPS = RES8_NT / TS;
+  extern __shared__ __attribute__((aligned(16))) char res_lds[];
+  const int K = a.K, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
+  const unsigned lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int group = (int)(lin / (unsigned)a.nblk), bl = (int)(lin % (unsigned)a.nblk);
+  if (group >= a.groups) return;
+  const int blk = a.blk0 + bl, band = blk / a.nbc, ch = blk - band * a.nbc;
+  const int r0 = band * 32, cw = ch * RES_BC + wave * (RES8_NT * 32), jt0 = cw >> 5;
+  const int nfm = (a.nb - group + a.groups - 1) / a.groups;
+  if (nfm <= 0) return;
+  const unsigned ldsA = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)res_lds);
+  const unsigned ldsD = ldsA + 4u * OPB, ldsB = ldsA + 5u * OPB + (unsigned)(wave * 2 * OPB);
+  const float *fA = reinterpret_cast<const float *>(res_lds), *fD = fA + 4 * (OPB / 4), *fB = fA + (5 + 2 * wave) * (OPB / 4);
+  // ---- the block of G, a tile at a time through this wave's operand buffers (2 OPB >= 4 KB) ----
+  f16v g[RES8_NT];
+  {
+    static_assert(2 * OPB >= 4096 || NP < 16, "staging");
+    const unsigned vg = (unsigned)(((lane >> 3) * K) * 4 + (lane & 7) * 16);
+    const char *Gb = (const char *)a.G + ((size_t)r0 * K + cw) * 4;
+    constexpr int ROWS_AT_ONCE = 2 * OPB >= 4096 ? 32 : 16;          // (8-row operands: 3 KB per wave -> half a tile at a time)
+#pragma unroll
+    for (int t = 0; t < RES8_NT; ++t)
+#pragma unroll
+      for (int h = 0; h < 32; h += ROWS_AT_ONCE) {
+#pragma unroll
+        for (int i = 0; i < ROWS_AT_ONCE / 8; ++i) {
+          const char *sb = Gb + (size_t)(h + 8 * i) * K * 4 + 128 * t;
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(vg), "s"(sb), "s"(ldsB + (unsigned)(1024 * i)) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = (v & 3) + 8 * (v >> 2);                    // + 4 lh; rows h .. h + ROWS_AT_ONCE - 1 are staged
+          if (ROWS_AT_ONCE == 32 || (row >= h && row < h + ROWS_AT_ONCE))
+            g[t][v] = fB[(row - h + 4 * lh) * 32 + l32];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+  }
+  const unsigned vdma = (unsigned)(lane * 16);
+  const unsigned vout = (unsigned)((4 * lh * K + l32) * 4);
+  const size_t pkf = (size_t)2 * RB * K * 4;
+  const size_t K4 = (size_t)K * 4, K20 = (size_t)K * 20;
+  auto dma_run = [&](const char *src, int bytes, unsigned lds_addr) {
+#pragma unroll
+    for (int o = 0; o < bytes; o += 1024) {
+      unsigned keep;
+      if (bytes - o >= 1024) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vdma), "s"(src + o), "s"(lds_addr + (unsigned)o) : "memory");
+      } else {
+        unsigned long long ex;
+        const unsigned long long mask = (1ull << ((bytes - o) / 16)) - 1;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex) : "v"(vdma), "s"(src + o), "s"(lds_addr + (unsigned)o), "s"(mask) : "memory");
+      }
+    }
+  };
+  const char *pk0 = (const char *)a.pk + (size_t)group * pkf;
+  const size_t pk_step = (size_t)a.groups * pkf;
+  char *out0 = (char *)a.out + ((size_t)(a.seg0 + group) * K * K + (size_t)r0 * K + cw) * 4;
+  const size_t out_step = (size_t)a.groups * K * K * 4;
+  // the A side of fold fi: column tile `band` of the fold's P and Q (2 OPB contiguous bytes) -> A buffer fi & 1, by wave 0
+  if (wave == 0) dma_run(pk0 + (size_t)band * (2 * OPB), 2 * OPB, ldsA);
+  for (int fi = 0; fi < nfm; ++fi) {
+    const char *fb = pk0 + (size_t)fi * pk_step;
+    char *ob = out0 + (size_t)fi * out_step;
+    const float *Ap = fA + (fi & 1) * (2 * (OPB / 4)), *Aq = Ap + OPB / 4;       // P | Q at the block's rows
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      // ---- this step's operands: requested, then everything of this wave drained ----
+#pragma unroll
+      for (int tt = 0; tt < TS; ++tt) {
+        const int t = TS * s + tt, j = jt0 + t;
+        const char *tb = fb + (size_t)j * (2 * OPB);
+        dma_run(tb + (j >= band ? 0 : OPB), OPB, ldsB + (unsigned)(tt * OPB));
+        if (j == band) dma_run(tb + OPB, OPB, ldsD);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (s == 0) {
+        // every wave has left the previous fold (its A buffer may be overwritten) and wave 0 has drained this fold's A side
+        lds_barrier();
+        if (wave == 0 && fi + 1 < nfm) dma_run(fb + pk_step + (size_t)band * (2 * OPB), 2 * OPB, ldsA + (unsigned)(((fi + 1) & 1) * 2 * OPB));
+      }
+#pragma unroll
+      for (int tt = 0; tt < TS; ++tt) {
+        const int t = TS * s + tt, j = jt0 + t;
+        const float *B = fB + tt * (OPB / 4);
+        const float *Aside = j >= band ? Aq : Ap;
+        f16v acc = g[t];
+        if (j == band) {
+          // the diagonal tile: elements below the diagonal from the mirrored product x[row] * (-w x)[column], first
+          f16v acc2 = g[t];
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk)
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[(2 * kk + lh) * 32 + l32], fD[(2 * kk + lh) * 32 + l32], acc2, 0, 0, 0);
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[(2 * kk + lh) * 32 + l32], B[(2 * kk + lh) * 32 + l32], acc, 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int row = (v & 3) + 8 * (v >> 2) + 4 * lh;
+            acc[v] = row > l32 ? acc2[v] : acc[v];
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Aside[(2 * kk + lh) * 32 + l32], B[(2 * kk + lh) * 32 + l32], acc, 0, 0, 0);
+        }
+        f16v ps;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) ps[v] = 0.f;
+        ps = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[(NP + 2 + lh) * 32 + l32], B[(NP + 2 + lh) * 32 + l32], ps, 0, 0, 0);
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        const char *obv = ob + 128 * t;
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+          const f2v val = (f2v){acc[v], acc[v + 1]} * (f2v){ps[v], ps[v + 1]};
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(vout), "v"(val[e]), "s"(obv) : "memory");
+            obv += ((v + e) & 3) == 3 ? K20 : K4;
+            asm volatile("" : "+s"(obv));
+          }
+        }
+      }
+    }
+  }
+}

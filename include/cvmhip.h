@@ -306,8 +306,8 @@ int cvm_debug_force_splits(int s_off, int s_diag);
 
 /* Experiments and tests: where float32 XTX batches of folds of at most 16 rows, K a multiple of 1024, take the round-6
  * "resident" kernel (csrc/resident.hpp: G in the register files of the whole chip, every tile computed directly, no
- * mirrored store).  mode 2 (the default): K a multiple of 4096 and at least 40 folds per batch (32 for folds of at most 8 rows),
- * where it measures 3-8 % faster than the tile kernel; 1: wherever the shape allows (slower below K = 4096 and for few folds); 0: never.  The environment
+ * mirrored store).  mode 2 (the default): K = 2048 or a multiple of 4096 and at least 16 folds per workgroup set (16 folds per
+ * batch from K = 4096 on, 64 at K = 2048), where it measures 6-13 % faster than the tile kernel; 1: wherever the shape allows (slower below K = 4096 and for few folds); 0: never.  The environment
  * variable CVM_RESIDENT=0|1|2 is read once, as the initial value.  Results stay within the float32 parity bar and exactly
  * symmetric on either route; size the workspace with cvm_fold_workspace_bytes AFTER changing the mode (the route keeps an
  * operand block per fold there; with a smaller workspace the folds are walked in smaller batches or take the tile
