@@ -590,7 +590,7 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // 1.91 / 1.87, 64 rows 1.59 / 1.73; K=1024 ... 4096 64 rows 2.13 / 2.02 ... 2.38 / 2.35, 80 rows
 // 1.77 / 1.84 ... 2.04 / 2.24.  CVM_SMALL_MAXN (32 .. 128) overrides the table for measurements
 // and tests.
-// Round 6, the resident route (resident.hpp: float32 XTX of folds of at most 16 rows with G in the register files of the
+// Round 6, the resident route (resident.hpp: float32 XTX of folds of at most 32 rows with G in the register files of the
 // whole chip): K a multiple of the 1024-column block, at least 4 folds per workgroup set.
 // Where it is the route (cvm_debug_resident / CVM_RESIDENT: 2 = this rule, the default; 1 = wherever the shape allows: tests and
 // measurements; 0 = never): K = 2048 or a multiple of 4096 (the blocks fill whole sets of 512 workgroups: K = 3072 has 288 blocks and
@@ -599,8 +599,9 @@ int gram_fit_impl(const void *X, const void *Y, const void *w, int64_t N, int K,
 // K = 4096, 48 folds of 16 / 8 / 1 rows 0.611 / 0.583 / 0.580 against 0.673 / 0.653 / 0.642 (-9 ... -11 %), 160 folds 1.91 against
 // 2.20 (-13 %), 24 folds 0.337 against 0.352, 12 folds 0.190 against 0.189; K = 8192, 40 folds 1.95 against 2.25 (8 rows: 1.85 / 1.98);
 // K = 2048, 400 folds 1.25-1.29 against 1.42-1.45, 80 folds 0.290 against 0.31; K = 1024, 1000 folds of 16 rows 0.85 against 0.95
-// but of 4 rows 0.80 against 0.775: not in the rule.
-constexpr int RES_NP = 16;
+// but of 4 rows 0.80 against 0.775: not in the rule.  Folds of 17 to 32 rows (operand blocks of 36 rows, one tile per step): K = 4096,
+// 48 folds of 32 / 24 rows 0.689 / 0.670 against 0.821 / 0.748 (-16 / -10 %).
+constexpr int RES_NP = 32;                               // rows per fold at most (operand blocks of 8, 16 or 32 rows)
 constexpr int RES_AUTO_MINK = 4096;
 std::atomic<int> g_resident{-1};                        // -1: environment not consulted yet
 inline int resident_mode() {
@@ -621,10 +622,10 @@ inline bool res_folds_ok(int64_t nb, int K) {
   const int nblk = (K / 32) * (K / RES_BC), sets = nblk >= RES_WG ? 1 : RES_WG / (nblk > 0 ? nblk : 1);
   return resident_mode() == 1 || nb >= (int64_t)16 * sets;
 }
-inline size_t res_pack_bytes(int K) { return (size_t)2 * (RES_NP + 4) * K * 4; }
+inline size_t res_pack_bytes(int K, int64_t max_rows) { return (size_t)2 * ((max_rows <= 16 ? 16 : 32) + 4) * K * 4; }
 // workspace of the direct small-fold route per fold: the statistics vector (+ the resident route's operand block)
 inline size_t small_ws_per_fold(int K, int M, int esize, int64_t max_rows) {
-  return align_up(fstat_len(K, M) * 8, 256) + (res_shape_ok(K, esize, max_rows) ? res_pack_bytes(K) : 0);
+  return align_up(fstat_len(K, M) * 8, 256) + (res_shape_ok(K, esize, max_rows) ? res_pack_bytes(K, max_rows) : 0);
 }
 int small_route_limit(int K, int esize) {
   static const int forced = [] {
@@ -750,11 +751,14 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
             auto run = [&](auto np_tag) -> int {
               constexpr int NPR = decltype(np_tag)::value;
               // eight waves per workgroup (four per SIMD) unless CVM_RES_WAVES=4 asks for the first kernel (comparisons)
-              static const bool four = getenv("CVM_RES_WAVES") && atoi(getenv("CVM_RES_WAVES")) == 4;
-              constexpr int lds4 = 4 * 7 * (NPR + 4) * 128, lds8 = 21 * (NPR + 4) * 128;
+              static const bool four_env = getenv("CVM_RES_WAVES") && atoi(getenv("CVM_RES_WAVES")) == 4;
+              constexpr bool has4 = NPR <= 16;                       // (the four-wave kernel's LDS holds blocks of at most 16 rows)
+              const bool four = four_env && has4;
+              constexpr int lds4 = 4 * 7 * (NPR + 4) * 128, lds8 = res8_lds<NPR>();
               static std::atomic<unsigned long long> attr_done{0};   // one bit per device (one per instantiation)
               if (attr_needed(attr_done, dev)) {
-                HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+                if constexpr (has4)
+                  HIP_OK(hipFuncSetAttribute((const void *)res_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
                 HIP_OK(hipFuncSetAttribute((const void *)res8_apply_kernel<NPR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
                 attr_set(attr_done, dev);
               }
@@ -764,12 +768,15 @@ int small_fold_impl(const void *X, const void *Y, const void *w, const int64_t *
               for (int b0 = 0; b0 < nblk_all; b0 += RES_WG) {
                 r.blk0 = b0; r.nblk = nblk_all - b0 < RES_WG ? nblk_all - b0 : RES_WG;
                 const unsigned wgs = (unsigned)(8 * (((size_t)r.nblk * groups + 7) / 8));
-                if (four) hipLaunchKernelGGL((res_apply_kernel<NPR>), dim3(wgs), dim3(256), lds4, st, r);
-                else hipLaunchKernelGGL((res8_apply_kernel<NPR>), dim3(wgs), dim3(512), lds8, st, r);
+                if constexpr (has4) {
+                  if (four) { hipLaunchKernelGGL((res_apply_kernel<NPR>), dim3(wgs), dim3(256), lds4, st, r); continue; }
+                }
+                hipLaunchKernelGGL((res8_apply_kernel<NPR>), dim3(wgs), dim3(512), lds8, st, r);
               }
               return CVM_OK;
             };
-            const int rc = max_rows <= 8 ? run(std::integral_constant<int, 8>{}) : run(std::integral_constant<int, RES_NP>{});
+            const int rc = max_rows <= 8 ? run(std::integral_constant<int, 8>{})
+                                          : (max_rows <= 16 ? run(std::integral_constant<int, 16>{}) : run(std::integral_constant<int, 32>{}));
             if (rc != CVM_OK) return rc;
           }
         }

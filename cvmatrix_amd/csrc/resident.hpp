@@ -1,5 +1,7 @@
 // resident.hpp -- part of libcvmhip.so (included by cvmhip.hip inside its anonymous namespace).
-// Round 6: the HBM regime with G RESIDENT IN THE REGISTER FILES OF THE WHOLE CHIP (float32 XTX of folds of at most 16 rows).
+// Round 6: the HBM regime with G RESIDENT IN THE REGISTER FILES OF THE WHOLE CHIP (float32 XTX of folds of at most 32 rows).
+// (Three versions, kept in this order below: the operand kernel, the four-wave kernel of the first two versions -- CVM_RES_WAVES=4 --
+//  and, at the end of the file, the eight-wave kernel that is the product.)
 //
 // small_apply_kernel keeps a 64 x 64 tile of G for eight folds, computes the upper triangle and writes it twice (direct +
 // mirrored); its store pattern alone tops out at 5.1-5.4 TB/s (tools/xcd_stack_probe.hip) and every group of eight folds
@@ -59,10 +61,11 @@ template <typename T, int NP, bool WEIGHTED> __global__ __launch_bounds__(256) v
     wl[tid] = tid < n ? (WEIGHTED ? ((const T *)a.w)[r] : (T)1) : (T)0;
   }
   __syncthreads();
-  if (with_xty && tid < NP * RES_XTY_M) {
-    const int r = tid / RES_XTY_M, m = tid - r * RES_XTY_M;
-    yl[r][m] = (r < n && m < M) ? ((const T *)a.Y)[rows[r] * (int64_t)M + m] : (T)0;
-  }
+  if (with_xty)
+    for (int e = tid; e < NP * RES_XTY_M; e += 256) {
+      const int r = e / RES_XTY_M, m = e - r * RES_XTY_M;
+      yl[r][m] = (r < n && m < M) ? ((const T *)a.Y)[rows[r] * (int64_t)M + m] : (T)0;
+    }
   if (with_xty) __syncthreads();
   const double *fs = a.fstats + (size_t)f * fstat_len(K, M);
   const double swt = fs[2 * K + 2 * M];
@@ -337,11 +340,15 @@ template <int NP> __global__ __launch_bounds__(256, 2) void res_apply_kernel(con
 // per fold) and read from LDS per tile instead of living in registers; a step is two tiles whose operands are requested at its
 // top (single-buffered: csrc comment on CVM_RES_TS -- the same rate as requesting a step ahead once every step drains anyway).
 // LDS per workgroup: A[2 folds][P | Q] | the diagonal tile's second operand | B[8 waves][2 tiles] = 21 operands (53.8 KB).
+// Folds of 17 to 32 rows take operand blocks of 36 rows and one tile per step (13 operands, 59.9 KB; 17 + 1 k-pairs per tile).
 constexpr int RES8_NT = 4;
+// (folds of 17 to 32 rows: operand blocks of 36 rows, ONE tile per step -- 13 operands of 4.6 KB per workgroup)
+template <int NP> constexpr int res8_ts() { return NP <= 16 ? 2 : 1; }
+template <int NP> constexpr int res8_lds() { return (5 + 8 * res8_ts<NP>()) * (NP + 4) * 128; }
 template <int NP> __global__ __launch_bounds__(512, 2) void res8_apply_kernel(const ResArgs a) {
   typedef float f16v __attribute__((ext_vector_type(16)));
   constexpr int RB = NP + 4, KK = NP / 2 + 1, OPB = RB * 128;
-  constexpr int TS = 2, STEPS = RES8_NT / TS;
+  constexpr int TS = res8_ts<NP>(), STEPS = RES8_NT / TS;
   extern __shared__ __attribute__((aligned(16))) char res_lds[];
   const int K = a.K, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
@@ -353,15 +360,15 @@ template <int NP> __global__ __launch_bounds__(512, 2) void res8_apply_kernel(co
   const int nfm = (a.nb - group + a.groups - 1) / a.groups;
   if (nfm <= 0) return;
   const unsigned ldsA = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)res_lds);
-  const unsigned ldsD = ldsA + 4u * OPB, ldsB = ldsA + 5u * OPB + (unsigned)(wave * 2 * OPB);
-  const float *fA = reinterpret_cast<const float *>(res_lds), *fD = fA + 4 * (OPB / 4), *fB = fA + (5 + 2 * wave) * (OPB / 4);
-  // ---- the block of G, a tile at a time through this wave's operand buffers (2 OPB >= 4 KB) ----
+  const unsigned ldsD = ldsA + 4u * OPB, ldsB = ldsA + 5u * OPB + (unsigned)(wave * TS * OPB);
+  const float *fA = reinterpret_cast<const float *>(res_lds), *fD = fA + 4 * (OPB / 4), *fB = fA + (5 + TS * wave) * (OPB / 4);
+  // ---- the block of G, a tile (half a tile) at a time through this wave's operand buffers ----
   f16v g[RES8_NT];
   {
-    static_assert(2 * OPB >= 4096 || NP < 16, "staging");
     const unsigned vg = (unsigned)(((lane >> 3) * K) * 4 + (lane & 7) * 16);
     const char *Gb = (const char *)a.G + ((size_t)r0 * K + cw) * 4;
-    constexpr int ROWS_AT_ONCE = 2 * OPB >= 4096 ? 32 : 16;          // (8-row operands: 3 KB per wave -> half a tile at a time)
+    constexpr int ROWS_AT_ONCE = TS * OPB >= 4096 ? 32 : 16;         // (8-row operands: 3 KB per wave -> half a tile at a time)
+    static_assert(TS * OPB >= 2048, "staging");
 #pragma unroll
     for (int t = 0; t < RES8_NT; ++t)
 #pragma unroll

@@ -304,7 +304,7 @@ int cvm_clock_probe(void *device_buf, size_t bytes);
  * rounding per extra partial, cvmatrix_amd/fp32_gate.py).  No reference counterpart. */
 int cvm_debug_force_splits(int s_off, int s_diag);
 
-/* Experiments and tests: where float32 XTX batches of folds of at most 16 rows, K a multiple of 1024, take the round-6
+/* Experiments and tests: where float32 XTX batches of folds of at most 32 rows, K a multiple of 1024, take the round-6
  * "resident" kernel (csrc/resident.hpp: G in the register files of the whole chip, every tile computed directly, no
  * mirrored store).  mode 2 (the default): K = 2048 or a multiple of 4096 and at least 16 folds per workgroup set (16 folds per
  * batch from K = 4096 on, 64 at K = 2048), where it measures 6-13 % faster than the tile kernel; 1: wherever the shape allows (slower below K = 4096 and for few folds); 0: never.  The environment

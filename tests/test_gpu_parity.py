@@ -1772,9 +1772,11 @@ def test_mid_tile_route_shapes(amd, dtype, K, M, sizes):
     (1024, 0, (5,) * 70, 1),                         # more folds than workgroup sets: several folds per workgroup; no Y
     (2048, 2, (16, 3, 12, 16, 8, 1, 16, 4, 11), 1),  # 128 blocks, two workgroup sets
     (4096, 1, (16, 15, 2, 9), 2),                    # every block of the chip's 512; the diagonal tile in every wave position
+    (1024, 2, (32, 17, 1, 25, 0, 32, 20, 9), 1),     # folds of 17 to 32 rows: operand blocks of 36 rows, one tile per step
+    (2048, 1, (31, 32, 18, 32), 2),
 ])
 def test_resident_route_float32(amd, K, M, sizes, reps):
-    """float32 XTX of batches of folds of at most 16 rows, K a multiple of 1024: res_apply_kernel (resident.hpp) -- G in
+    """float32 XTX of batches of folds of at most 32 rows, K a multiple of 1024: res8_apply_kernel (resident.hpp) -- G in
     the register files of the whole chip, every tile computed directly from wave-private LDS-DMA operands behind counted
     waits.  Every flag set that changes the operand block, weights with zeros and none, ragged folds, against the float64
     oracle with the oracle's own float32 run as the yardstick; exact symmetry; bit-identical repetitions (a misplaced

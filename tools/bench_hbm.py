@@ -60,6 +60,8 @@ if __name__ == "__main__":
         run("C5-hbm K=4096 M=1 f32 n=16", 20000, 4096, 1, 16, 48, np.float32)
         run("K=4096 M=1 f32 n=8", 20000, 4096, 1, 8, 48, np.float32)
         run("K=4096 M=1 f32 n=1", 20000, 4096, 1, 1, 48, np.float32)
+        run("K=4096 M=1 f32 n=32", 20000, 4096, 1, 32, 48, np.float32)
+        run("K=4096 M=1 f32 n=24", 20000, 4096, 1, 24, 48, np.float32)
         if len(sys.argv) > 2 and sys.argv[2] == "first":
             sys.exit(0)
         run("K=4096 M=1 f32 n=16 12 folds", 20000, 4096, 1, 16, 12, np.float32)

@@ -17,7 +17,7 @@ for c in range(cases):
     if rng.random() < 0.3:
         K += int(rng.integers(1, 4))
     if os.environ.get("CVM_RESIDENT") == "1" and dt is np.float32 and rng.random() < 0.6:
-        K = 1024      # (the resident route, csrc/resident.hpp: float32, K a multiple of 1024, folds of at most 16 rows, >= 4 folds)
+        K = 1024      # (the resident route, csrc/resident.hpp: float32, K a multiple of 1024, folds of at most 32 rows, >= 4 folds)
     M = int(rng.choice([0, 1, 3, 10, 40, 70]))      # (70: two 64-response panels of XTY in the tile kernel)
     nmax = int(rng.choice([1, 2, 3, 8, 16, 32, 33, 50, 100, 128]))      # (beyond 32: several chunks, where the limit of the shape -- or CVM_SMALL_MAXN -- sends them there)
     P = int(rng.choice([1, 2, 9, 40, 300] if nmax <= 32 else [1, 2, 9, 40]))
@@ -77,7 +77,7 @@ for c in range(cases):
     nmax_rows = max(len(v) for v in folds)
     minn = int(os.environ["CVM_MID_MINN"]) if os.environ.get("CVM_MID_MINN") else (8 if (Kd < 768 or (es == 4 and Kd <= 1024)) else 16)
     mid_route = os.environ.get("CVM_MID_TILE", "1") != "0" and Kd <= 2048 and nmax_rows >= minn
-    resident = (os.environ.get("CVM_RESIDENT") == "1" and dt is np.float32 and Kd % 1024 == 0 and nmax_rows <= 16 and P >= 4)
+    resident = (os.environ.get("CVM_RESIDENT") == "1" and dt is np.float32 and Kd % 1024 == 0 and nmax_rows <= 32 and P >= 4)
     if rows_kernel or mid_route or resident or nmax_rows > 32:      # (beyond 32 rows batch and single call may take different routes)
         assert float((one - bx[0]).abs().max()) <= (1e-12 if dt is np.float64 else 1e-5) * float(bx[0].abs().max()), (c, "per-call vs batch")
     else:

@@ -1,6 +1,6 @@
 // res8_apply_kernel (cvmatrix_amd/csrc/resident.hpp: eight waves per workgroup) alone on synthetic operands, next to res_apply_kernel:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o tools/res8_kernel_probe tools/res8_kernel_probe.hip
-//   tools/res8_kernel_probe [K] [folds] [NP: 16 | 8]
+//   tools/res8_kernel_probe [K] [folds] [NP: 16 | 8 | 32]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,15 +22,15 @@ template <int NP> void run(int K, int nb) {
   int groups = nblk_all >= RES_WG ? 1 : RES_WG / nblk_all;
   if (groups > nb / 4) groups = nb / 4;
   r.G = G; r.out = out; r.pk = pk; r.K = K; r.nb = nb; r.seg0 = 0; r.nbc = K / RES_BC; r.groups = groups;
-  constexpr int lds4 = 4 * 7 * RB * 128, lds8 = 21 * RB * 128;
-  hipFuncSetAttribute((const void *)res_apply_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+  constexpr int lds4 = 4 * 7 * RB * 128, lds8 = res8_lds<NP>();
+  if (NP <= 16) hipFuncSetAttribute((const void *)res_apply_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
   hipFuncSetAttribute((const void *)res8_apply_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
-  for (int which = 0; which < 2; ++which) {
+  for (int which = (NP > 16 ? 1 : 0); which < 2; ++which) {
     auto launch = [&] {
       for (int b0 = 0; b0 < nblk_all; b0 += RES_WG) {
         r.blk0 = b0; r.nblk = nblk_all - b0 < RES_WG ? nblk_all - b0 : RES_WG;
         const unsigned wgs = (unsigned)(8 * (((size_t)r.nblk * groups + 7) / 8));
-        if (which == 0) hipLaunchKernelGGL((res_apply_kernel<NP>), dim3(wgs), dim3(256), lds4, 0, r);
+        if (which == 0) { if constexpr (NP <= 16) hipLaunchKernelGGL((res_apply_kernel<NP>), dim3(wgs), dim3(256), lds4, 0, r); }
         else hipLaunchKernelGGL((res8_apply_kernel<NP>), dim3(wgs), dim3(512), lds8, 0, r);
       }
     };
@@ -50,6 +50,6 @@ template <int NP> void run(int K, int nb) {
 }
 int main(int argc, char **argv) {
   const int K = argc > 1 ? atoi(argv[1]) : 4096, nb = argc > 2 ? atoi(argv[2]) : 48, np = argc > 3 ? atoi(argv[3]) : 16;
-  if (np == 8) run<8>(K, nb); else run<16>(K, nb);
+  if (np == 8) run<8>(K, nb); else if (np == 32) run<32>(K, nb); else run<16>(K, nb);
   return 0;
 }
