@@ -6,7 +6,8 @@
 // small_apply_kernel keeps a 64 x 64 tile of G for eight folds, computes the upper triangle and writes it twice (direct +
 // mirrored); its store pattern alone tops out at 5.1-5.4 TB/s (tools/xcd_stack_probe.hip) and every group of eight folds
 // fetches G again.  Here a launch is 512 PERSISTENT workgroups (two per CU) that each own a 32-row x 1024-column block of G
-// in registers -- 128 per lane, 64 MiB over the chip: all of a K = 4096 float32 G -- for ALL folds of the call:
+// in registers -- 64 MiB over the chip: all of a K = 4096 float32 G; 64 registers per lane in the eight-wave kernel, 128 in
+// the four-wave one -- for ALL folds of the call:
 //   * G crosses the memory system once per launch, not once per fold group;
 //   * every tile of the output is computed directly (both triangles: a 16-row fold keeps the matrix cores busy a third of
 //     the time a fold's stores take), so there is no transposed copy through LDS and no mirrored store: a store
@@ -21,11 +22,10 @@
 //     from the tile of G (C operand), so the finish costs one vector instruction per element.
 // Operands: res_pack_kernel writes, per fold and 32-column tile, RB = NP + 4 rows x 32 columns  {x_0 .. x_NP-1 (zero rows
 // beyond the fold), sqrt(sw) mu, 0, sd^-1, 0}  ("P") and then the same with {-w x, -sqrt(sw) mu, 0, sd^-1, 0} ("Q"); an MFMA
-// operand of a tile is 2560 contiguous bytes and arrives by three LDS-DMA instructions, WAVE-PRIVATE
-// (no workgroup barrier anywhere in the kernel), requested one step (two tiles) ahead; every step then drains its wave's
-// memory operations (CVM_RES_SAFE below: counted waits that never wait for a store were built first and measure SLOWER).
-// The row-side operands of a block are the same kind of operand (the block's 32 rows as columns of P and Q), fetched once
-// per fold.
+// operand of a tile is 2560 contiguous bytes (NP = 16) and arrives by three LDS-DMA instructions into the wave's own buffers; the
+// row-side operands of a block are the same kind of operand (the block's 32 rows as columns of P and Q), fetched once per fold.
+// Every step (two tiles) ends in a full drain of its wave's memory operations: hand-counted waits that never wait for a store were
+// built first and measure SLOWER (CVM_RES_SAFE below) -- the drain is what keeps the workgroups of the chip in step.
 // tools/resident_probe.hip is the measurement this is built on (profiles/r6/hbm_regime/resident_probe.txt).
 #pragma once
 
