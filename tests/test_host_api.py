@@ -218,6 +218,41 @@ def test_launch_planning_is_host_logic():
     assert odd["mfma_per_4_rows"] == (528 - 32) * 64 + 32 * 48 + 32 * 16
 
 
+def test_resident_route_rule_is_host_logic():
+    """Where the round-6 resident route of the HBM regime is taken is decided on the host (csrc/host.hpp: res_shape_ok /
+    res_folds_ok) and shows in the workspace the small-fold route asks for: the route keeps an operand block per fold
+    there (2 x 20 rows x K floats for folds of at most 16 rows, 2 x 36 for 17 to 32).  float32, K = 2048 or a multiple of
+    4096, folds of at most 32 rows under the default rule; every multiple of 1024 under mode 1; nothing under mode 0; and
+    never float64."""
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    lib = _lib.load()
+
+    def ws(K, rows, dtype=_lib.CVM_F32, folds=48):
+        return int(lib.cvm_fold_workspace_bytes(folds, folds * rows, rows, K, 1, dtype, 0x3F))
+
+    assert lib.cvm_debug_resident(3) != 0 and lib.cvm_debug_resident(-1) != 0
+    try:
+        assert lib.cvm_debug_resident(0) == 0
+        base = {K: ws(K, 16) for K in (1024, 2048, 3072, 4096, 8192)}
+        base32 = ws(4096, 32)
+        assert lib.cvm_debug_resident(2) == 0
+        for K in (2048, 4096, 8192):
+            assert ws(K, 16) > base[K] and ws(K, 16) >= 48 * 2 * 20 * K * 4, K     # (the workspace is a maximum over routes)
+        for K in (1024, 3072):
+            assert ws(K, 16) == base[K], K
+        assert ws(4096, 32) > base32 and ws(4096, 32) >= 48 * 2 * 36 * 4096 * 4
+        assert ws(4096, 16, _lib.CVM_F64) == int(lib.cvm_fold_workspace_bytes(48, 48 * 16, 16, 4096, 1, _lib.CVM_F64, 0x3F))
+        assert lib.cvm_debug_resident(1) == 0
+        for K in (1024, 3072):
+            assert ws(K, 16) > base[K] and ws(K, 16) >= 48 * 2 * 20 * K * 4, K
+        assert ws(1000, 16) == int(lib.cvm_fold_workspace_bytes(48, 48 * 16, 16, 1000, 1, _lib.CVM_F32, 0x3F))
+    finally:
+        lib.cvm_debug_resident(2)
+
+
 def test_package_metadata():
     assert cvmatrix_amd.__all__ == ["CVMatrix", "Partitioner", "FoldBatch"]
 
