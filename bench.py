@@ -475,20 +475,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the clock the chip holds under the Gram kernel, read by the kernel itself (cvm_clock_probe: two scalar clock
+    # pairs per workgroup lifetime, nothing inside the item loop; every launch overwrites the buffer, what is read
+    # after the timed region are the stamps of its LAST Gram launch).  The buffer is allocated HERE, before the
+    # warm-up: an allocation + fill between the warm-up and the timed steps idles the GPU long enough for its clock
+    # to fall, and a timed region of 20 steps (10 ms) then runs inside the ramp back (2.2 instead of 2.39 GHz,
+    # 0.53 instead of 0.48 ms per step with `--steps 20 --warmup 5`, whatever the length of the warm-up)
+    clock_buf = torch.zeros(1024 * 4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
     # the GPU needs ~30 ms of work to reach its steady clocks: bring it there whatever --warmup says
     # (a fixed number of steps, the same on every rank: the step contains a collective when N > 1)
-    for _ in range(75 if args.workload in ("C2", "C3") else 3):
+    for _ in range(int(os.environ.get("CVM_BENCH_PREWARM", "75")) if args.workload in ("C2", "C3") else 3):
         out = step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = step()
+    lib.cvm_clock_probe(C.c_void_p(clock_buf.data_ptr()), C.c_size_t(clock_buf.numel() * 8))      # (host only)
     fence()
     lib.cvm_timing_enable(1)
-    # the clock the chip holds under the Gram kernel, read by the kernel itself (cvm_clock_probe: two scalar clock
-    # pairs per workgroup lifetime, nothing inside the item loop; every launch overwrites the buffer, what is read
-    # after the timed region are the stamps of its LAST Gram launch)
-    clock_buf = torch.zeros(1024 * 4, dtype=torch.int64, device=dev)
-    lib.cvm_clock_probe(C.c_void_p(clock_buf.data_ptr()), C.c_size_t(clock_buf.numel() * 8))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -741,7 +745,7 @@ def main():
         am.fit(Xd, Yd, wd)
         ab = am.prepare_folds(fold_lists) if n_mine else None
         ast_ = step_of(am, ab)
-        for _ in range(75 if args.workload in ("C2", "C3") else 3):
+        for _ in range(int(os.environ.get("CVM_BENCH_PREWARM", "75")) if args.workload in ("C2", "C3") else 3):
             ast_()
         alt_ms = timed(ast_, reps=100 if args.workload in ("C2", "C3") else 5)
         alt = {"outputs": "reused buffers (reuse_outputs=True)" if not reuse else "fresh tensors every call (the API's default)",
