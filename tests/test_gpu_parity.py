@@ -1772,6 +1772,7 @@ def test_mid_tile_route_shapes(amd, dtype, K, M, sizes):
     (1024, 0, (5,) * 70, 1),                         # more folds than workgroup sets: several folds per workgroup; no Y
     (2048, 2, (16, 3, 12, 16, 8, 1, 16, 4, 11), 1),  # 128 blocks, two workgroup sets
     (4096, 1, (16, 15, 2, 9), 2),                    # every block of the chip's 512; the diagonal tile in every wave position
+    (1024, 20, (16, 4, 9, 16, 1), 1),                # M > 16: XTY by the tile kernel's panels behind the resident XTX
     (1024, 2, (32, 17, 1, 25, 0, 32, 20, 9), 1),     # folds of 17 to 32 rows: operand blocks of 36 rows, one tile per step
     (2048, 1, (31, 32, 18, 32), 2),
 ])
@@ -1813,10 +1814,15 @@ def _resident_case(amd, K, M, sizes, reps, torch):
         o32 = OracleCVMatrix(*flags, dtype=np.float32)
         o32.fit(X, Y, wt)
         bx = m.training_XTX_XTY_batched(folds)[0][0] if M else m.training_XTX_batched(folds)[0]
+        by = m.training_XTX_XTY_batched(folds)[0][1] if M else None
         for f in check:
             rx = o.training_XTX(folds[f])[0]
             sx = o32.training_XTX(folds[f])[0]
             assert_fp32_like_reference(bx[f], rx, sx, f"fold{f} XTX")
+            if M:
+                ry = o.training_XTX_XTY(folds[f])[0][1]
+                sy = o32.training_XTX_XTY(folds[f])[0][1]
+                assert_fp32_like_reference(by[f], ry, sy, f"fold{f} XTY")
         for f in range(len(folds)):
             assert bool((bx[f] == bx[f].T).all()), f
         for _ in range(reps):
